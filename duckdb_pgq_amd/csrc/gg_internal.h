@@ -1,0 +1,168 @@
+// gg_internal.h — shared internals of libgg.so (HIP, gfx950 only; not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gg.h"
+
+namespace gg {
+
+void set_error(const char *fmt, ...);
+
+#define GG_HIP(call)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      gg::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return (e_ == hipErrorOutOfMemory) ? GG_ERR_OOM : GG_ERR_HIP;                                \
+    }                                                                                              \
+  } while (0)
+
+#define GG_TRY(call)            \
+  do {                          \
+    int rc_ = (call);           \
+    if (rc_ != GG_OK) return rc_; \
+  } while (0)
+
+constexpr uint32_t INVALID_U32 = 0xFFFFFFFFu;
+constexpr int64_t HT_EMPTY = INT64_MIN;  // empty-slot sentinel of the id hash table
+
+// digest constants — must match oracle/gg_oracle.c (DESIGN.md "Row digest")
+constexpr uint32_t DIG_K32 = 0x9E3779B1u;
+constexpr uint64_t DIG_GOLD = 0x9E3779B97F4A7C15ULL;
+
+struct DevBlock {
+  void *ptr;
+  size_t size;
+  bool in_use;
+};
+
+struct ProfRec {
+  int name_idx;
+  hipEvent_t start, stop;
+};
+
+struct Column {
+  int64_t *dev = nullptr;
+  size_t cap = 0;  // rows
+};
+
+}  // namespace gg
+
+struct gg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+
+  // ---- staging (guarded by mu) ----
+  std::mutex mu;
+  gg::Column c_vid, c_src, c_dst, c_rowid;
+  uint64_t n_vertices = 0, n_edges = 0;          // rows resident or in flight to the device
+  static constexpr size_t STAGE_ROWS = 1u << 20; // rows per pinned staging block
+  int64_t *pin_v[2] = {nullptr, nullptr};        // vertex ids
+  int64_t *pin_e[2] = {nullptr, nullptr};        // edge block: [src | dst | rowid] each STAGE_ROWS
+  hipEvent_t pin_v_free[2] = {nullptr, nullptr}, pin_e_free[2] = {nullptr, nullptr};
+  int cur_v = 0, cur_e = 0;
+  size_t fill_v = 0, fill_e = 0;
+
+  // ---- caching device allocator ----
+  std::vector<gg::DevBlock> blocks;
+  size_t bytes_allocated = 0;
+
+  // ---- profiling ----
+  bool profiling = false;
+  std::vector<std::string> prof_names;
+  std::vector<uint64_t> prof_launches;
+  std::vector<double> prof_ms;
+  std::vector<gg::ProfRec> prof_pending;
+
+  // small pinned scratch for D2H of counters
+  uint64_t *pin_scratch = nullptr;  // 64 x u64
+
+  int dev_alloc(void **out, size_t bytes);
+  void dev_free(void *p);
+  int prof_begin(const char *name);
+  void prof_end(int rec);
+  int prof_flush();
+};
+
+struct gg_csr {
+  gg_ctx *ctx = nullptr;
+  uint64_t V = 0, E = 0, dropped = 0;
+  uint32_t *off = nullptr;   // V+1
+  uint32_t *nbr = nullptr;   // E dense neighbour indices
+  int64_t *eid = nullptr;    // E edge rowids
+  int64_t *vid = nullptr;    // V vertex ids by dense index
+  int64_t *ht_keys = nullptr;  // id hash table (open addressing)
+  uint32_t *ht_vals = nullptr;
+  uint32_t ht_shift = 0;     // slot = (key * GOLD) >> ht_shift
+  uint64_t ht_cap = 0;
+  int64_t ht_min_idx = -1;   // dense index of the vertex whose id == HT_EMPTY, if any
+};
+
+struct gg_result {
+  gg_ctx *ctx = nullptr;
+  int k_min = 0, k_max = 0;
+  uint64_t rows[GG_MAX_HOPS + 1] = {0};
+  int64_t *cols[GG_MAX_HOPS + 1][GG_MAX_HOPS + 1] = {{nullptr}};  // cols[h][c], device
+};
+
+namespace gg {
+
+// RAII-free helper: launch wrapper that records events when profiling is on.
+#define GG_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                         \
+  do {                                                                                \
+    int prof_rec_ = (ctx)->profiling ? (ctx)->prof_begin(name) : -1;                  \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);       \
+    if (prof_rec_ >= 0) (ctx)->prof_end(prof_rec_);                                   \
+    GG_HIP(hipGetLastError());                                                        \
+  } while (0)
+
+// exclusive scan of n uint32 values (in place allowed: out may equal in); writes the grand
+// total (as uint64) to *total_dev if non-null.  Three hand-written kernels (gg_scan.hip).
+int scan_exclusive_u32(gg_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint64_t *total_dev);
+// exclusive scan of n uint64 values
+int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *total_dev);
+
+// id -> dense lookup of n host ids; writes dense (uint32, INVALID_U32 if absent) to out_dev
+int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev);
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+__device__ __forceinline__ uint64_t dig_q(uint64_t p, int j) { return fmix64(p + DIG_GOLD * (uint64_t)(j + 1)); }
+__device__ __forceinline__ uint64_t dig_leaf(uint64_t q, uint32_t d) {
+  return q ^ ((uint64_t)d * (uint64_t)DIG_K32);  // one v_mad_u64_u32
+}
+
+__device__ __forceinline__ uint32_t ht_lookup(const int64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                              uint32_t shift, uint64_t mask, int64_t min_idx, int64_t key) {
+  if (key == HT_EMPTY) return min_idx >= 0 ? (uint32_t)min_idx : INVALID_U32;
+  uint64_t slot = ((uint64_t)key * DIG_GOLD) >> shift;
+  while (true) {
+    int64_t k = keys[slot];
+    if (k == key) return vals[slot];
+    if (k == HT_EMPTY) return INVALID_U32;
+    slot = (slot + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace gg

@@ -1,0 +1,819 @@
+// gg_khop.hip — fixed-length path expansion (k-hop MATCH) over the device CSR.
+//
+// Replaces the probe side of the reference's hash-join chain:
+//   PhysicalHashJoin::Execute -> JoinHashTable::Probe + ScanStructure::NextInnerJoin/AdvancePointers
+//   (src/execution/operator/join/physical_hash_join.cpp:217-254, src/execution/join_hashtable.cpp:304-476)
+// whose cost is a dependent pointer chase per matching build row.  Here a path prefix ending in
+// vertex v expands into CSR row v, read as a contiguous, coalesced run.
+//
+// Work decomposition ("flattened frontier"): a frontier is a list of path prefixes; entry i ends
+// in vertex fv[i] and owns deg(fv[i]) children; foff[] is the exclusive prefix sum of those
+// degrees, so child positions 0..M-1 enumerate every (prefix, neighbour) pair.  A workgroup takes
+// a tile of 256 consecutive child positions (k_tile_partition finds the entry each tile starts
+// in), so work per workgroup is balanced on EDGES, not vertices.
+//
+//   k_expand_fused2  last two hops fused: phase 1 resolves the tile's 256 children x (one
+//                    coalesced nbr read + two offset reads each) and stages {row start, row
+//                    length, hash state} in LDS; phase 2: each wavefront streams whole CSR rows
+//                    (64 lanes x 4 B coalesced) and folds every entry into the row digest.
+//   k_expand_step    one hop, materialising the next frontier (only needed for k_max >= 3)
+//   k_expand_last1   single last hop (k_max == 1)
+// Count-only mode never writes rows: algorithmic bytes 8*TE + 16*frontier entries.
+#include "gg_internal.h"
+
+using namespace gg;
+
+namespace gg {
+
+constexpr int XT = 256;  // child positions per tile == threads per workgroup
+
+// tile t starts in entry  upper_bound(foff, foff[0] + t*XT) - 1
+template <typename OffT>
+__global__ __launch_bounds__(256) void k_tile_partition(const OffT *__restrict__ foff, uint64_t n_entries,
+                                                        uint64_t n_tiles, uint32_t *__restrict__ tile_entry) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint64_t target = (uint64_t)foff[0] + t * XT;
+  uint64_t lo = 0, hi = n_entries;  // first idx in [0,n_entries] with foff[idx] > target
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if ((uint64_t)foff[mid] <= target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  tile_entry[t] = (uint32_t)(lo - 1);
+}
+
+// Locate the frontier entry that owns flattened child position p.  s_foff holds foff[i0..i0+XT]
+// (UINT64_MAX past the end).  Returns entry index and writes the position inside the entry.
+template <typename OffT>
+__device__ __forceinline__ uint64_t locate_entry(const uint64_t *s_foff, const OffT *__restrict__ foff,
+                                                 uint64_t n_entries, uint64_t i0, uint64_t p, uint64_t *k) {
+  uint32_t lo = 0, hi = XT + 1;  // first idx in [0, XT+1) with s_foff[idx] > p
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (s_foff[mid] <= p)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  uint64_t idx = i0 + lo - 1;
+  uint64_t start = s_foff[lo - 1];
+  if (lo == XT + 1) {  // window exhausted by zero-degree entries: finish the search in global memory
+    uint64_t glo = i0 + XT, ghi = n_entries;
+    while (glo < ghi) {
+      uint64_t mid = (glo + ghi) >> 1;
+      if ((uint64_t)foff[mid] <= p)
+        glo = mid + 1;
+      else
+        ghi = mid;
+    }
+    idx = glo - 1;
+    start = (uint64_t)foff[idx];
+  }
+  *k = p - start;
+  return idx;
+}
+
+template <typename OffT>
+__device__ __forceinline__ void load_window(uint64_t *s_foff, const OffT *__restrict__ foff, uint64_t n_entries,
+                                            uint64_t i0) {
+  for (uint32_t t = threadIdx.x; t <= XT; t += XT) {
+    uint64_t gi = i0 + t;
+    s_foff[t] = gi <= n_entries ? (uint64_t)foff[gi] : UINT64_MAX;
+  }
+}
+
+struct Frontier {
+  const uint32_t *fv;   // last vertex per entry (nullptr: identity, vertex = ident_base + i)
+  const uint64_t *fq;   // hash state q_j per entry (nullptr: q_0 computed from the vertex)
+  uint64_t n_entries;
+  uint32_t ident_base;
+  int j;                // hops already in the prefix
+};
+
+__device__ __forceinline__ void entry_vertex_q(const Frontier &f, uint64_t i, uint32_t *v, uint64_t *q) {
+  uint32_t vv = f.fv ? f.fv[i] : (uint32_t)(f.ident_base + i);
+  *v = vv;
+  *q = f.fq ? f.fq[i] : dig_q((uint64_t)vv, 0);
+}
+
+// block reduce of three u64 values -> partial[blockIdx.x*4 + 0..2]
+__device__ __forceinline__ void block_store_partials(uint64_t a, uint64_t b, uint64_t c, uint64_t *s_red /*12*/,
+                                                     unsigned long long *__restrict__ partial) {
+  a = wave_reduce_add_u64(a);
+  b = wave_reduce_add_u64(b);
+  c = wave_reduce_add_u64(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_red[wave * 3 + 0] = a;
+    s_red[wave * 3 + 1] = b;
+    s_red[wave * 3 + 2] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    uint64_t s = s_red[threadIdx.x] + s_red[3 + threadIdx.x] + s_red[6 + threadIdx.x] + s_red[9 + threadIdx.x];
+    partial[(uint64_t)blockIdx.x * 4 + threadIdx.x] = s;
+  }
+}
+
+// ---- fused last two hops -----------------------------------------------------------------------
+template <typename OffT>
+__global__ __launch_bounds__(XT) void k_expand_fused2(const uint32_t *__restrict__ off,
+                                                      const uint32_t *__restrict__ nbr, const OffT *__restrict__ foff,
+                                                      Frontier f, uint64_t M, const uint32_t *__restrict__ tile_entry,
+                                                      int emit_mid, unsigned long long *__restrict__ partial) {
+  __shared__ uint64_t s_foff[XT + 1];
+  __shared__ uint64_t s_q[XT];
+  __shared__ uint32_t s_start[XT];
+  __shared__ uint32_t s_len[XT];
+  __shared__ uint64_t s_red[12];
+
+  const uint64_t fbase = (uint64_t)foff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, foff, f.n_entries, i0);
+  __syncthreads();
+
+  uint64_t mid_sum = 0, rows_last = 0;
+  uint32_t my_len = 0;
+  if (p < fbase + M) {
+    uint64_t k;
+    uint64_t i = locate_entry(s_foff, foff, f.n_entries, i0, p, &k);
+    uint32_t v;
+    uint64_t q;
+    entry_vertex_q(f, i, &v, &q);
+    const uint32_t x = nbr[(uint64_t)off[v] + k];
+    const uint64_t P = dig_leaf(q, x);
+    if (emit_mid) mid_sum = P;
+    const uint32_t st = off[x];
+    my_len = off[x + 1] - st;
+    s_start[threadIdx.x] = st;
+    s_q[threadIdx.x] = dig_q(P, f.j + 1);
+    rows_last = my_len;
+  }
+  s_len[threadIdx.x] = my_len;
+  __syncthreads();
+
+  // phase 2: a wavefront per staged row; lanes stride the row, 4 independent loads in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t acc = 0;
+  for (int r = wave; r < XT; r += XT / 64) {
+    const uint32_t len = s_len[r];
+    if (len == 0) continue;
+    const uint32_t st = s_start[r];
+    const uint64_t q2 = s_q[r];
+    const uint32_t *__restrict__ row = nbr + st;
+    uint32_t jj = lane;
+    for (; jj + 192 < len; jj += 256) {
+      uint32_t w0 = row[jj], w1 = row[jj + 64], w2 = row[jj + 128], w3 = row[jj + 192];
+      acc += dig_leaf(q2, w0);
+      acc += dig_leaf(q2, w1);
+      acc += dig_leaf(q2, w2);
+      acc += dig_leaf(q2, w3);
+    }
+    for (; jj < len; jj += 64) acc += dig_leaf(q2, row[jj]);
+  }
+  block_store_partials(mid_sum, acc, rows_last, s_red, partial);
+}
+
+// ---- one hop, materialising the next frontier (fv', fq', deg') -----------------------------------
+template <typename OffT>
+__global__ __launch_bounds__(XT) void k_expand_step(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                    const OffT *__restrict__ foff, Frontier f, uint64_t M,
+                                                    const uint32_t *__restrict__ tile_entry, int emit,
+                                                    uint32_t *__restrict__ nv, uint64_t *__restrict__ nq,
+                                                    uint64_t *__restrict__ ndeg,
+                                                    unsigned long long *__restrict__ partial) {
+  __shared__ uint64_t s_foff[XT + 1];
+  __shared__ uint64_t s_red[12];
+  const uint64_t fbase = (uint64_t)foff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, foff, f.n_entries, i0);
+  __syncthreads();
+  uint64_t sum = 0;
+  if (p < fbase + M) {
+    uint64_t k;
+    uint64_t i = locate_entry(s_foff, foff, f.n_entries, i0, p, &k);
+    uint32_t v;
+    uint64_t q;
+    entry_vertex_q(f, i, &v, &q);
+    const uint32_t x = nbr[(uint64_t)off[v] + k];
+    const uint64_t P = dig_leaf(q, x);
+    if (emit) sum = P;
+    const uint64_t o = p - fbase;
+    nv[o] = x;
+    nq[o] = dig_q(P, f.j + 1);
+    ndeg[o] = (uint64_t)(off[x + 1] - off[x]);
+  }
+  block_store_partials(sum, 0, 0, s_red, partial);
+}
+
+// ---- single last hop -----------------------------------------------------------------------------
+template <typename OffT>
+__global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict__ off,
+                                                     const uint32_t *__restrict__ nbr, const OffT *__restrict__ foff,
+                                                     Frontier f, uint64_t M, const uint32_t *__restrict__ tile_entry,
+                                                     unsigned long long *__restrict__ partial) {
+  __shared__ uint64_t s_foff[XT + 1];
+  __shared__ uint64_t s_red[12];
+  const uint64_t fbase = (uint64_t)foff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, foff, f.n_entries, i0);
+  __syncthreads();
+  uint64_t sum = 0;
+  if (p < fbase + M) {
+    uint64_t k;
+    uint64_t i = locate_entry(s_foff, foff, f.n_entries, i0, p, &k);
+    uint32_t v;
+    uint64_t q;
+    entry_vertex_q(f, i, &v, &q);
+    sum = dig_leaf(q, nbr[(uint64_t)off[v] + k]);
+  }
+  block_store_partials(0, sum, 0, s_red, partial);
+}
+
+// sum partial[b*4 + c] over b -> out[c]  (c < 3)
+__global__ __launch_bounds__(256) void k_reduce_partials(const unsigned long long *__restrict__ partial,
+                                                         uint64_t nblocks, unsigned long long *__restrict__ out) {
+  __shared__ uint64_t s_red[12];
+  uint64_t a = 0, b = 0, c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += (uint64_t)gridDim.x * blockDim.x) {
+    a += partial[i * 4];
+    b += partial[i * 4 + 1];
+    c += partial[i * 4 + 2];
+  }
+  a = wave_reduce_add_u64(a);
+  b = wave_reduce_add_u64(b);
+  c = wave_reduce_add_u64(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_red[wave * 3] = a;
+    s_red[wave * 3 + 1] = b;
+    s_red[wave * 3 + 2] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicAdd(&out[threadIdx.x],
+              s_red[threadIdx.x] + s_red[3 + threadIdx.x] + s_red[6 + threadIdx.x] + s_red[9 + threadIdx.x]);
+}
+
+// ---- source list -> frontier 0 -------------------------------------------------------------------
+// ballot/popcount compaction of the valid (found) sources; order inside the list is irrelevant
+// for a multiset result, so a wave-granular atomic cursor is fine.
+__global__ __launch_bounds__(256) void k_compact_sources(const uint32_t *__restrict__ dense, uint64_t n,
+                                                         uint32_t *__restrict__ fv, uint64_t *__restrict__ fq,
+                                                         uint64_t *__restrict__ fdeg, const uint32_t *__restrict__ off,
+                                                         unsigned long long *__restrict__ cursor) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t d = i < n ? dense[i] : INVALID_U32;
+  const bool ok = d != INVALID_U32;
+  const uint64_t m = __ballot(ok);
+  const int lane = threadIdx.x & 63;
+  uint64_t base = 0;
+  if (lane == 0 && m) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (ok) {
+    uint64_t o = base + __popcll(m & ((1ULL << lane) - 1ULL));
+    fv[o] = d;
+    fq[o] = dig_q((uint64_t)d, 0);
+    fdeg[o] = (uint64_t)(off[d + 1] - off[d]);
+  }
+}
+
+// per-vertex 2-hop work estimate for gg_khop_partition: sum over v in adj(u) of (1 + deg(v))
+__global__ __launch_bounds__(256) void k_twohop_work(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                     uint64_t V, uint64_t *__restrict__ work) {
+  const uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // a wavefront per vertex
+  const int lane = threadIdx.x & 63;
+  if (u >= V) return;
+  uint64_t s = 0;
+  for (uint32_t i = off[u] + lane; i < off[u + 1]; i += 64) {
+    uint32_t v = nbr[i];
+    s += 1 + (uint64_t)(off[v + 1] - off[v]);
+  }
+  s = wave_reduce_add_u64(s);
+  if (lane == 0) work[u] = s;
+}
+
+// ---- materialisation -------------------------------------------------------------------------------
+// parent table: cols_in[c][i] (c <= j), child row p: copies the parent's columns and appends the child.
+template <typename OffT>
+__global__ __launch_bounds__(XT) void k_mat_fill(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                 const OffT *__restrict__ foff, uint64_t n_entries, uint64_t M,
+                                                 const uint32_t *__restrict__ tile_entry, int j,
+                                                 const uint32_t *const *__restrict__ cols_in,
+                                                 uint32_t *const *__restrict__ cols_out, uint64_t *__restrict__ ndeg) {
+  __shared__ uint64_t s_foff[XT + 1];
+  const uint64_t fbase = (uint64_t)foff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, foff, n_entries, i0);
+  __syncthreads();
+  if (p >= fbase + M) return;
+  uint64_t k;
+  uint64_t i = locate_entry(s_foff, foff, n_entries, i0, p, &k);
+  const uint32_t v = cols_in[j][i];
+  const uint32_t x = nbr[(uint64_t)off[v] + k];
+  const uint64_t o = p - fbase;
+  for (int c = 0; c <= j; c++) cols_out[c][o] = cols_in[c][i];
+  cols_out[j + 1][o] = x;
+  if (ndeg) ndeg[o] = (uint64_t)(off[x + 1] - off[x]);
+}
+
+__global__ __launch_bounds__(256) void k_gather_ids(const uint32_t *__restrict__ dense, const int64_t *__restrict__ vid,
+                                                    uint64_t n, int64_t *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vid[dense[i]];
+}
+
+__global__ __launch_bounds__(256) void k_iota_deg(uint32_t base, uint64_t n, const uint32_t *__restrict__ off,
+                                                  uint32_t *__restrict__ fv, uint64_t *__restrict__ fdeg) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint32_t v = base + (uint32_t)i;
+    fv[i] = v;
+    fdeg[i] = (uint64_t)(off[v + 1] - off[v]);
+  }
+}
+
+}  // namespace gg
+
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevFrontier {  // explicit frontier living in pool memory
+  uint32_t *fv = nullptr;
+  uint64_t *fq = nullptr;
+  uint64_t *foff = nullptr;  // n+1
+  uint64_t n = 0;
+  uint64_t M = 0;  // flattened children
+};
+
+void free_frontier(gg_ctx *ctx, DevFrontier &f) {
+  ctx->dev_free(f.fv);
+  ctx->dev_free(f.fq);
+  ctx->dev_free(f.foff);
+  f = DevFrontier();
+}
+
+// read one u64 from device memory (synchronises the stream)
+int read_u64(gg_ctx *ctx, const uint64_t *dev, uint64_t *host) {
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, dev, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  *host = ctx->pin_scratch[0];
+  return GG_OK;
+}
+
+// degrees (u64, n entries) -> exclusive offsets (n+1 entries), returns total
+int offsets_from_deg(gg_ctx *ctx, uint64_t *deg_then_off /* n+1 */, uint64_t n, uint64_t *total_host) {
+  uint64_t *tot = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(uint64_t)));
+  GG_TRY(scan_exclusive_u64(ctx, deg_then_off, deg_then_off, n, tot));
+  GG_HIP(hipMemcpyAsync(deg_then_off + n, tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  GG_TRY(read_u64(ctx, tot, total_host));
+  ctx->dev_free(tot);
+  return GG_OK;
+}
+
+template <typename OffT>
+int make_tiles(gg_ctx *ctx, const OffT *foff, uint64_t n_entries, uint64_t M, uint32_t **tile_entry,
+               uint64_t *n_tiles) {
+  *n_tiles = (M + XT - 1) / XT;
+  if (*n_tiles > 0x7FFFFFFFull) {
+    set_error("expansion of %llu children exceeds one launch (2^31 tiles)", (unsigned long long)M);
+    return GG_ERR_TOO_LARGE;
+  }
+  GG_TRY(ctx->dev_alloc((void **)tile_entry, (*n_tiles ? *n_tiles : 1) * sizeof(uint32_t)));
+  if (*n_tiles)
+    GG_LAUNCH(ctx, "tile_partition", (k_tile_partition<OffT>), dim3((unsigned)((*n_tiles + 255) / 256)), dim3(256), 0,
+              foff, n_entries, *n_tiles, *tile_entry);
+  return GG_OK;
+}
+
+struct Sums {  // device: [0]=mid digest [1]=last digest [2]=rows_last
+  unsigned long long *dev = nullptr;
+};
+
+int reduce_partials(gg_ctx *ctx, unsigned long long *partial, uint64_t nblocks, unsigned long long *out3) {
+  GG_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  if (nblocks) {
+    unsigned grid = (unsigned)((nblocks + 255) / 256);
+    if (grid > 64) grid = 64;
+    GG_LAUNCH(ctx, "reduce_partials", k_reduce_partials, dim3(grid), dim3(256), 0, partial, nblocks, out3);
+  }
+  return GG_OK;
+}
+
+// count + digest for walks of length k_min..k_max from frontier 0 given either as an identity
+// range (csr offsets, u32) or as an explicit frontier (u64 offsets).
+int khop_count(gg_ctx *ctx, const gg_csr *csr, bool ident, uint32_t lo, uint64_t n0, uint64_t M1, DevFrontier f0,
+               int k_min, int k_max, gg_khop_stats *st) {
+  memset(st, 0, sizeof(*st));
+  uint64_t walks[GG_MAX_HOPS + 1] = {0};
+  uint64_t digests[GG_MAX_HOPS + 1] = {0};
+  walks[0] = n0;
+  walks[1] = M1;
+
+  unsigned long long *sums = nullptr;  // 3 words per level
+  GG_TRY(ctx->dev_alloc((void **)&sums, (GG_MAX_HOPS + 1) * 3 * sizeof(unsigned long long)));
+  GG_HIP(hipMemsetAsync(sums, 0, (GG_MAX_HOPS + 1) * 3 * sizeof(unsigned long long), ctx->stream));
+
+  DevFrontier cur = f0;  // j-hop frontier (explicit) — unused while `ident` at j == 0
+  bool cur_ident = ident;
+  bool own_cur = false;
+  int j = 0;
+  uint64_t M = M1;  // children of the current frontier = walks[j+1]
+
+  // materialise frontiers until two hops remain
+  while (k_max - j > 2 && M > 0) {
+    uint32_t *tile_entry = nullptr;
+    uint64_t n_tiles = 0;
+    DevFrontier nx;
+    nx.n = M;
+    GG_TRY(ctx->dev_alloc((void **)&nx.fv, M * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&nx.fq, M * sizeof(uint64_t)));
+    GG_TRY(ctx->dev_alloc((void **)&nx.foff, (M + 1) * sizeof(uint64_t)));
+    unsigned long long *partial = nullptr;
+    Frontier fr;
+    fr.j = j;
+    if (cur_ident) {
+      fr.fv = nullptr;
+      fr.fq = nullptr;
+      fr.n_entries = n0;
+      fr.ident_base = lo;
+      GG_TRY(make_tiles<uint32_t>(ctx, csr->off + lo, n0, M, &tile_entry, &n_tiles));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      GG_LAUNCH(ctx, "expand_step", (k_expand_step<uint32_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                csr->nbr, csr->off + lo, fr, M, tile_entry, (int)(j + 1 >= k_min), nx.fv, nx.fq, nx.foff, partial);
+    } else {
+      fr.fv = cur.fv;
+      fr.fq = cur.fq;
+      fr.n_entries = cur.n;
+      fr.ident_base = 0;
+      GG_TRY(make_tiles<uint64_t>(ctx, cur.foff, cur.n, M, &tile_entry, &n_tiles));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      GG_LAUNCH(ctx, "expand_step", (k_expand_step<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                csr->nbr, cur.foff, fr, M, tile_entry, (int)(j + 1 >= k_min), nx.fv, nx.fq, nx.foff, partial);
+    }
+    GG_TRY(reduce_partials(ctx, partial, n_tiles, sums + (j + 1) * 3));
+    ctx->dev_free(partial);
+    ctx->dev_free(tile_entry);
+    uint64_t Mn = 0;
+    GG_TRY(offsets_from_deg(ctx, nx.foff, M, &Mn));
+    if (own_cur) free_frontier(ctx, cur);
+    cur = nx;
+    own_cur = true;
+    cur_ident = false;
+    j++;
+    walks[j + 1] = Mn;
+    M = Mn;
+  }
+
+  // last one or two hops
+  if (M > 0) {
+    uint32_t *tile_entry = nullptr;
+    uint64_t n_tiles = 0;
+    unsigned long long *partial = nullptr;
+    Frontier fr;
+    fr.j = j;
+    const int remaining = k_max - j;  // 1 or 2
+    if (cur_ident) {
+      fr.fv = nullptr;
+      fr.fq = nullptr;
+      fr.n_entries = n0;
+      fr.ident_base = lo;
+      GG_TRY(make_tiles<uint32_t>(ctx, csr->off + lo, n0, M, &tile_entry, &n_tiles));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      if (remaining == 2)
+        GG_LAUNCH(ctx, "expand_fused2", (k_expand_fused2<uint32_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                  csr->nbr, csr->off + lo, fr, M, tile_entry, (int)(j + 1 >= k_min), partial);
+      else
+        GG_LAUNCH(ctx, "expand_last1", (k_expand_last1<uint32_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                  csr->nbr, csr->off + lo, fr, M, tile_entry, partial);
+    } else {
+      fr.fv = cur.fv;
+      fr.fq = cur.fq;
+      fr.n_entries = cur.n;
+      fr.ident_base = 0;
+      GG_TRY(make_tiles<uint64_t>(ctx, cur.foff, cur.n, M, &tile_entry, &n_tiles));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      if (remaining == 2)
+        GG_LAUNCH(ctx, "expand_fused2", (k_expand_fused2<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                  csr->nbr, cur.foff, fr, M, tile_entry, (int)(j + 1 >= k_min), partial);
+      else
+        GG_LAUNCH(ctx, "expand_last1", (k_expand_last1<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                  csr->nbr, cur.foff, fr, M, tile_entry, partial);
+    }
+    // partial layout: [0]=digest of hop j+1 (fused2 mid) [1]=digest of the last hop [2]=rows of last hop
+    unsigned long long *tmp = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
+    GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    if (remaining == 2) {
+      digests[j + 1] = ctx->pin_scratch[0];
+      digests[j + 2] = ctx->pin_scratch[1];
+      walks[j + 2] = ctx->pin_scratch[2];
+    } else {
+      digests[j + 1] = ctx->pin_scratch[1];
+    }
+    ctx->dev_free(tmp);
+    ctx->dev_free(partial);
+    ctx->dev_free(tile_entry);
+  }
+  // digests of the materialised intermediate hops
+  if (j > 0) {
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, sums, (GG_MAX_HOPS + 1) * 3 * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    for (int h = 1; h <= j; h++) digests[h] = ctx->pin_scratch[h * 3];
+  }
+  ctx->dev_free(sums);
+  if (own_cur) free_frontier(ctx, cur);
+
+  for (int h = 1; h <= k_max; h++) {
+    st->traversed_edges += walks[h];
+    if (h >= k_min) {
+      st->rows[h] = walks[h];
+      st->digest[h] = digests[h];
+    }
+  }
+  for (int h = 0; h < k_max; h++) st->frontier_entries += walks[h];
+  return GG_OK;
+}
+
+// materialise walks as int64 id columns (correctness config; level-by-level)
+int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64_t n0, int k_min, int k_max,
+                     gg_result *res) {
+  // level tables of dense columns
+  std::vector<uint32_t *> cols_prev, cols_cur;
+  uint64_t n_prev = n0;
+  uint32_t *c0 = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&c0, (n0 ? n0 : 1) * sizeof(uint32_t)));
+  if (n0) GG_HIP(hipMemcpyAsync(c0, fv0, n0 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+  cols_prev.push_back(c0);
+  // degrees of level-0 entries
+  uint64_t *foff = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&foff, (n0 + 1) * sizeof(uint64_t)));
+  {
+    uint32_t *tmpv = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&tmpv, (n0 ? n0 : 1) * sizeof(uint32_t)));
+    uint64_t *cursor = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(uint64_t)));
+    GG_HIP(hipMemsetAsync(cursor, 0, sizeof(uint64_t), ctx->stream));
+    uint64_t *fq = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&fq, (n0 ? n0 : 1) * sizeof(uint64_t)));
+    // fv0 holds only valid dense indices, so compaction is the identity here; reuse it for degrees
+    if (n0)
+      GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, fv0, n0,
+                tmpv, fq, foff, csr->off, (unsigned long long *)cursor);
+    // compaction may permute entries across waves: take the permuted list as level 0
+    if (n0) GG_HIP(hipMemcpyAsync(c0, tmpv, n0 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->dev_free(tmpv);
+    ctx->dev_free(cursor);
+    ctx->dev_free(fq);
+  }
+  uint64_t M = 0;
+  GG_TRY(offsets_from_deg(ctx, foff, n0, &M));
+
+  const uint32_t **d_in = nullptr;
+  uint32_t **d_out = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&d_in, (GG_MAX_HOPS + 1) * sizeof(void *)));
+  GG_TRY(ctx->dev_alloc((void **)&d_out, (GG_MAX_HOPS + 1) * sizeof(void *)));
+
+  for (int h = 1; h <= k_max; h++) {
+    cols_cur.assign((size_t)h + 1, nullptr);
+    for (int c = 0; c <= h; c++) GG_TRY(ctx->dev_alloc((void **)&cols_cur[c], (M ? M : 1) * sizeof(uint32_t)));
+    uint64_t *noff = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&noff, (M + 1) * sizeof(uint64_t)));
+    uint64_t Mn = 0;
+    if (M) {
+      uint32_t *tile_entry = nullptr;
+      uint64_t n_tiles = 0;
+      GG_TRY(make_tiles<uint64_t>(ctx, foff, n_prev, M, &tile_entry, &n_tiles));
+      GG_HIP(hipMemcpyAsync(d_in, cols_prev.data(), cols_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
+                            ctx->stream));
+      GG_HIP(hipMemcpyAsync(d_out, cols_cur.data(), cols_cur.size() * sizeof(void *), hipMemcpyHostToDevice,
+                            ctx->stream));
+      GG_HIP(hipStreamSynchronize(ctx->stream));  // host vectors are reused below
+      GG_LAUNCH(ctx, "mat_fill", (k_mat_fill<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
+                foff, n_prev, M, tile_entry, h - 1, d_in, d_out, noff);
+      ctx->dev_free(tile_entry);
+      if (h < k_max) GG_TRY(offsets_from_deg(ctx, noff, M, &Mn));
+    }
+    if (h >= k_min) {  // convert this level to int64 ids
+      res->rows[h] = M;
+      for (int c = 0; c <= h; c++) {
+        GG_TRY(ctx->dev_alloc((void **)&res->cols[h][c], (M ? M : 1) * sizeof(int64_t)));
+        if (M)
+          GG_LAUNCH(ctx, "gather_ids", k_gather_ids, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, cols_cur[c],
+                    csr->vid, M, res->cols[h][c]);
+      }
+    }
+    for (auto p : cols_prev) ctx->dev_free(p);
+    ctx->dev_free(foff);
+    cols_prev = cols_cur;
+    foff = noff;
+    n_prev = M;
+    M = Mn;
+  }
+  for (auto p : cols_prev) ctx->dev_free(p);
+  ctx->dev_free(foff);
+  ctx->dev_free(d_in);
+  ctx->dev_free(d_out);
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  return GG_OK;
+}
+
+int check_args(gg_ctx *ctx, const gg_csr *csr, int k_min, int k_max, gg_khop_stats *stats) {
+  if (!ctx || !csr || !stats || csr->ctx != ctx) {
+    set_error("gg_expand_khop: bad context/csr/stats argument");
+    return GG_ERR_INVALID_ARG;
+  }
+  if (k_min < 1 || k_max < k_min || k_max > GG_MAX_HOPS) {
+    set_error("gg_expand_khop: need 1 <= k_min <= k_max <= %d (got %d..%d)", GG_MAX_HOPS, k_min, k_max);
+    return GG_ERR_INVALID_ARG;
+  }
+  return GG_OK;
+}
+
+}  // namespace
+
+extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src_lo, uint64_t src_hi, int k_min,
+                                    int k_max, int materialise, gg_khop_stats *stats, gg_result **out_result) {
+  GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
+  if (out_result) *out_result = nullptr;
+  if (materialise && !out_result) return GG_ERR_INVALID_ARG;
+  if (src_hi > csr->V) src_hi = csr->V;
+  if (src_lo > src_hi) src_lo = src_hi;
+  GG_HIP(hipSetDevice(ctx->device));
+  const uint64_t n0 = src_hi - src_lo;
+  uint64_t M1 = csr->E;
+  if (!(src_lo == 0 && src_hi == csr->V)) {
+    uint32_t ends[2] = {0, 0};
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, csr->off + src_lo, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch + 1, csr->off + src_hi, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(&ends[0], ctx->pin_scratch, sizeof(uint32_t));
+    memcpy(&ends[1], ctx->pin_scratch + 1, sizeof(uint32_t));
+    M1 = (uint64_t)ends[1] - ends[0];
+  }
+  GG_TRY(khop_count(ctx, csr, true, (uint32_t)src_lo, n0, M1, DevFrontier(), k_min, k_max, stats));
+  if (materialise) {
+    gg_result *res = new gg_result();
+    res->ctx = ctx;
+    res->k_min = k_min;
+    res->k_max = k_max;
+    uint32_t *fv = nullptr;
+    uint64_t *fdeg = nullptr;
+    int rc = ctx->dev_alloc((void **)&fv, (n0 ? n0 : 1) * sizeof(uint32_t));
+    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&fdeg, (n0 ? n0 : 1) * sizeof(uint64_t));
+    if (rc == GG_OK && n0) {
+      hipLaunchKernelGGL(k_iota_deg, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)src_lo,
+                         n0, csr->off, fv, fdeg);
+    }
+    if (rc == GG_OK) rc = khop_materialise(ctx, csr, fv, n0, k_min, k_max, res);
+    ctx->dev_free(fv);
+    ctx->dev_free(fdeg);
+    if (rc != GG_OK) {
+      gg_result_destroy(res);
+      return rc;
+    }
+    *out_result = res;
+  }
+  return GG_OK;
+}
+
+extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min,
+                              int k_max, int materialise, gg_khop_stats *stats, gg_result **out_result) {
+  if (!src_ids)
+    return gg_expand_khop_range(ctx, csr, 0, csr ? csr->V : 0, k_min, k_max, materialise, stats, out_result);
+  GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
+  if (out_result) *out_result = nullptr;
+  if (materialise && !out_result) return GG_ERR_INVALID_ARG;
+  GG_HIP(hipSetDevice(ctx->device));
+
+  // ids -> dense -> compacted frontier 0
+  int64_t *ids_dev = nullptr;
+  uint32_t *dense = nullptr;
+  DevFrontier f0;
+  unsigned long long *cursor = nullptr;
+  const uint64_t n = n_src;
+  GG_TRY(ctx->dev_alloc((void **)&ids_dev, (n ? n : 1) * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&dense, (n ? n : 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&f0.fv, (n ? n : 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&f0.fq, (n ? n : 1) * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&f0.foff, (n + 1) * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
+  GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->stream));
+  uint64_t n_valid = 0, M1 = 0;
+  if (n) {
+    GG_HIP(hipMemcpyAsync(ids_dev, src_ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));  // src_ids is caller memory: consumed before return
+    GG_TRY(lookup_ids(ctx, csr, ids_dev, n, dense));
+    GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dense, n,
+              f0.fv, f0.fq, f0.foff, csr->off, cursor);
+    GG_TRY(read_u64(ctx, (const uint64_t *)cursor, &n_valid));
+    GG_TRY(offsets_from_deg(ctx, f0.foff, n_valid, &M1));
+  } else {
+    GG_HIP(hipMemsetAsync(f0.foff, 0, sizeof(uint64_t), ctx->stream));
+  }
+  f0.n = n_valid;
+  f0.M = M1;
+  int rc = khop_count(ctx, csr, false, 0, n_valid, M1, f0, k_min, k_max, stats);
+  if (rc == GG_OK && materialise) {
+    gg_result *res = new gg_result();
+    res->ctx = ctx;
+    res->k_min = k_min;
+    res->k_max = k_max;
+    rc = khop_materialise(ctx, csr, f0.fv, n_valid, k_min, k_max, res);
+    if (rc != GG_OK)
+      gg_result_destroy(res);
+    else
+      *out_result = res;
+  }
+  ctx->dev_free(ids_dev);
+  ctx->dev_free(dense);
+  ctx->dev_free(cursor);
+  free_frontier(ctx, f0);
+  return rc;
+}
+
+extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds) {
+  if (!ctx || !csr || n_parts < 1 || !bounds) return GG_ERR_INVALID_ARG;
+  GG_HIP(hipSetDevice(ctx->device));
+  const uint64_t V = csr->V;
+  bounds[0] = 0;
+  bounds[n_parts] = V;
+  if (V == 0 || n_parts == 1) {
+    for (int i = 1; i < n_parts; i++) bounds[i] = V;
+    return GG_OK;
+  }
+  uint64_t *work = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&work, (V + 1) * sizeof(uint64_t)));
+  GG_LAUNCH(ctx, "twohop_work", k_twohop_work, dim3((unsigned)((V * 64 + 255) / 256)), dim3(256), 0, csr->off,
+            csr->nbr, V, work);
+  uint64_t total = 0;
+  GG_TRY(offsets_from_deg(ctx, work, V, &total));
+  std::vector<uint64_t> h(V + 1);
+  GG_HIP(hipMemcpy(h.data(), work, (V + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  ctx->dev_free(work);
+  for (int i = 1; i < n_parts; i++) {
+    uint64_t target = (uint64_t)((__uint128_t)total * (unsigned)i / (unsigned)n_parts);
+    uint64_t lo = 0, hi = V;  // first vertex whose exclusive prefix >= target
+    while (lo < hi) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (h[mid] < target)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    bounds[i] = lo;
+  }
+  return GG_OK;
+}
+
+extern "C" int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows) {
+  if (!res || !n_rows || hops < res->k_min || hops > res->k_max) return GG_ERR_INVALID_ARG;
+  *n_rows = res->rows[hops];
+  return GG_OK;
+}
+
+extern "C" int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows,
+                               int64_t *const *cols, uint32_t *n_out) {
+  if (!res || !cols || !n_out || hops < res->k_min || hops > res->k_max) return GG_ERR_INVALID_ARG;
+  gg_ctx *ctx = res->ctx;
+  GG_HIP(hipSetDevice(ctx->device));
+  uint64_t total = res->rows[hops];
+  if (offset >= total) {
+    *n_out = 0;
+    return GG_OK;
+  }
+  uint64_t take = total - offset;
+  if (take > max_rows) take = max_rows;
+  for (int c = 0; c <= hops; c++) {
+    if (!cols[c]) return GG_ERR_INVALID_ARG;
+    GG_HIP(hipMemcpyAsync(cols[c], res->cols[hops][c] + offset, take * sizeof(int64_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+  }
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = (uint32_t)take;
+  return GG_OK;
+}
+
+extern "C" void gg_result_destroy(gg_result *res) {
+  if (!res) return;
+  gg_ctx *ctx = res->ctx;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int h = 0; h <= GG_MAX_HOPS; h++)
+      for (int c = 0; c <= GG_MAX_HOPS; c++) ctx->dev_free(res->cols[h][c]);
+  }
+  delete res;
+}

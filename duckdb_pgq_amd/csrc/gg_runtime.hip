@@ -1,0 +1,485 @@
+// gg_runtime.hip — context, staging (Sink side), caching allocator, event timing, scans.
+// HIP for gfx950; host side of the C-ABI declared in include/gg.h.
+#include "gg_internal.h"
+
+namespace gg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace gg
+
+using namespace gg;
+
+extern "C" const char *gg_version(void) { return "gg 0.1 (gfx950)"; }
+extern "C" const char *gg_last_error(void) { return g_err; }
+
+extern "C" int gg_device_count(int *out_count) {
+  if (!out_count) return GG_ERR_INVALID_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *out_count = n;
+  return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// caching device allocator: the build/expand path is re-run per query (and per bench step), so
+// blocks are recycled instead of hipMalloc/hipFree inside the hot path (guide: Guideline 9).
+// ------------------------------------------------------------------------------------------
+int gg_ctx::dev_alloc(void **out, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~size_t(255);
+  int best = -1;
+  for (size_t i = 0; i < blocks.size(); i++) {
+    if (!blocks[i].in_use && blocks[i].size >= bytes && blocks[i].size <= bytes * 2 + (1u << 20)) {
+      if (best < 0 || blocks[i].size < blocks[best].size) best = (int)i;
+    }
+  }
+  if (best >= 0) {
+    blocks[best].in_use = true;
+    *out = blocks[best].ptr;
+    return GG_OK;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // drop every cached free block and retry once
+    for (auto &b : blocks)
+      if (!b.in_use && b.ptr) {
+        (void)hipFree(b.ptr);
+        bytes_allocated -= b.size;
+        b.ptr = nullptr;
+        b.size = 0;
+      }
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+      return GG_ERR_OOM;
+    }
+  }
+  bytes_allocated += bytes;
+  blocks.push_back({p, bytes, true});
+  *out = p;
+  return GG_OK;
+}
+
+void gg_ctx::dev_free(void *p) {
+  if (!p) return;
+  for (auto &b : blocks)
+    if (b.ptr == p) {
+      b.in_use = false;
+      return;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// event timing on the library's stream
+// ------------------------------------------------------------------------------------------
+int gg_ctx::prof_begin(const char *name) {
+  int idx = -1;
+  for (size_t i = 0; i < prof_names.size(); i++)
+    if (prof_names[i] == name) {
+      idx = (int)i;
+      break;
+    }
+  if (idx < 0) {
+    idx = (int)prof_names.size();
+    prof_names.push_back(name);
+    prof_launches.push_back(0);
+    prof_ms.push_back(0.0);
+  }
+  ProfRec r;
+  r.name_idx = idx;
+  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return -1;
+  (void)hipEventRecord(r.start, stream);
+  prof_pending.push_back(r);
+  return (int)prof_pending.size() - 1;
+}
+void gg_ctx::prof_end(int rec) { (void)hipEventRecord(prof_pending[rec].stop, stream); }
+int gg_ctx::prof_flush() {
+  if (prof_pending.empty()) return GG_OK;
+  GG_HIP(hipStreamSynchronize(stream));
+  for (auto &r : prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      prof_ms[r.name_idx] += ms;
+      prof_launches[r.name_idx] += 1;
+    }
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  prof_pending.clear();
+  return GG_OK;
+}
+
+extern "C" int gg_profile_enable(gg_ctx *ctx, int on) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  GG_TRY(ctx->prof_flush());
+  ctx->profiling = on != 0;
+  return GG_OK;
+}
+extern "C" int gg_profile_reset(gg_ctx *ctx) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  GG_TRY(ctx->prof_flush());
+  ctx->prof_names.clear();
+  ctx->prof_launches.clear();
+  ctx->prof_ms.clear();
+  return GG_OK;
+}
+extern "C" int gg_profile_count(gg_ctx *ctx, int *n) {
+  if (!ctx || !n) return GG_ERR_INVALID_ARG;
+  GG_TRY(ctx->prof_flush());
+  *n = (int)ctx->prof_names.size();
+  return GG_OK;
+}
+extern "C" int gg_profile_get(gg_ctx *ctx, int index, const char **name, uint64_t *launches, double *total_ms) {
+  if (!ctx || index < 0 || index >= (int)ctx->prof_names.size()) return GG_ERR_INVALID_ARG;
+  if (name) *name = ctx->prof_names[index].c_str();
+  if (launches) *launches = ctx->prof_launches[index];
+  if (total_ms) *total_ms = ctx->prof_ms[index];
+  return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+extern "C" int gg_ctx_create(int device, gg_ctx **out) {
+  if (!out) return GG_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available: the gg hot path has no CPU fallback");
+    return GG_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range (0..%d)", device, n - 1);
+    return GG_ERR_INVALID_ARG;
+  }
+  GG_HIP(hipSetDevice(device));
+  gg_ctx *ctx = new gg_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  GG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) {
+    GG_HIP(hipHostMalloc((void **)&ctx->pin_v[i], gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
+    GG_HIP(hipHostMalloc((void **)&ctx->pin_e[i], 3 * gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
+    GG_HIP(hipEventCreateWithFlags(&ctx->pin_v_free[i], hipEventDisableTiming));
+    GG_HIP(hipEventCreateWithFlags(&ctx->pin_e_free[i], hipEventDisableTiming));
+  }
+  GG_HIP(hipHostMalloc((void **)&ctx->pin_scratch, 64 * sizeof(uint64_t), hipHostMallocDefault));
+  *out = ctx;
+  return GG_OK;
+}
+
+extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)ctx->prof_flush();
+  for (auto &b : ctx->blocks)
+    if (b.ptr) (void)hipFree(b.ptr);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->pin_v[i]) (void)hipHostFree(ctx->pin_v[i]);
+    if (ctx->pin_e[i]) (void)hipHostFree(ctx->pin_e[i]);
+    if (ctx->pin_v_free[i]) (void)hipEventDestroy(ctx->pin_v_free[i]);
+    if (ctx->pin_e_free[i]) (void)hipEventDestroy(ctx->pin_e_free[i]);
+  }
+  if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
+  // staged columns are plain hipMalloc (they grow by doubling, outside the block cache)
+  if (ctx->c_vid.dev) (void)hipFree(ctx->c_vid.dev);
+  if (ctx->c_src.dev) (void)hipFree(ctx->c_src.dev);
+  if (ctx->c_dst.dev) (void)hipFree(ctx->c_dst.dev);
+  if (ctx->c_rowid.dev) (void)hipFree(ctx->c_rowid.dev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// ------------------------------------------------------------------------------------------
+// staging: DataChunk columns -> pinned block -> HBM   (Sink side; thread-safe)
+// ------------------------------------------------------------------------------------------
+static int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows) {
+  if (need_rows <= c.cap) return GG_OK;
+  size_t ncap = c.cap ? c.cap : (size_t)1 << 16;
+  while (ncap < need_rows) ncap *= 2;
+  int64_t *p = nullptr;
+  GG_HIP(hipMalloc((void **)&p, ncap * sizeof(int64_t)));
+  if (c.dev && live_rows)
+    GG_HIP(hipMemcpyAsync(p, c.dev, live_rows * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  if (c.dev) {
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    GG_HIP(hipFree(c.dev));
+  }
+  c.dev = p;
+  c.cap = ncap;
+  return GG_OK;
+}
+
+// push the current (partially) filled pinned vertex block to the device; caller holds mu
+static int flush_vertices(gg_ctx *ctx) {
+  if (ctx->fill_v == 0) return GG_OK;
+  size_t live = ctx->n_vertices - ctx->fill_v;
+  GG_TRY(grow_column(ctx, ctx->c_vid, live, ctx->n_vertices));
+  int b = ctx->cur_v;
+  GG_HIP(hipMemcpyAsync(ctx->c_vid.dev + live, ctx->pin_v[b], ctx->fill_v * sizeof(int64_t), hipMemcpyHostToDevice,
+                        ctx->stream));
+  GG_HIP(hipEventRecord(ctx->pin_v_free[b], ctx->stream));
+  ctx->cur_v ^= 1;
+  ctx->fill_v = 0;
+  GG_HIP(hipEventSynchronize(ctx->pin_v_free[ctx->cur_v]));  // the other block must have drained
+  return GG_OK;
+}
+
+static int flush_edges(gg_ctx *ctx) {
+  if (ctx->fill_e == 0) return GG_OK;
+  size_t live = ctx->n_edges - ctx->fill_e;
+  GG_TRY(grow_column(ctx, ctx->c_src, live, ctx->n_edges));
+  GG_TRY(grow_column(ctx, ctx->c_dst, live, ctx->n_edges));
+  GG_TRY(grow_column(ctx, ctx->c_rowid, live, ctx->n_edges));
+  int b = ctx->cur_e;
+  const size_t S = gg_ctx::STAGE_ROWS;
+  size_t bytes = ctx->fill_e * sizeof(int64_t);
+  GG_HIP(hipMemcpyAsync(ctx->c_src.dev + live, ctx->pin_e[b], bytes, hipMemcpyHostToDevice, ctx->stream));
+  GG_HIP(hipMemcpyAsync(ctx->c_dst.dev + live, ctx->pin_e[b] + S, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GG_HIP(hipMemcpyAsync(ctx->c_rowid.dev + live, ctx->pin_e[b] + 2 * S, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GG_HIP(hipEventRecord(ctx->pin_e_free[b], ctx->stream));
+  ctx->cur_e ^= 1;
+  ctx->fill_e = 0;
+  GG_HIP(hipEventSynchronize(ctx->pin_e_free[ctx->cur_e]));
+  return GG_OK;
+}
+
+extern "C" int gg_vertices_append(gg_ctx *ctx, const int64_t *id, uint64_t n) {
+  if (!ctx || (!id && n)) return GG_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  GG_HIP(hipSetDevice(ctx->device));
+  if (ctx->n_vertices + n >= (uint64_t)INVALID_U32) {
+    set_error("vertex table larger than 2^32-2 rows is not supported");
+    return GG_ERR_TOO_LARGE;
+  }
+  while (n) {
+    size_t room = gg_ctx::STAGE_ROWS - ctx->fill_v;
+    size_t take = n < room ? (size_t)n : room;
+    memcpy(ctx->pin_v[ctx->cur_v] + ctx->fill_v, id, take * sizeof(int64_t));
+    ctx->fill_v += take;
+    ctx->n_vertices += take;
+    id += take;
+    n -= take;
+    if (ctx->fill_v == gg_ctx::STAGE_ROWS) GG_TRY(flush_vertices(ctx));
+  }
+  return GG_OK;
+}
+
+extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *dst, const int64_t *rowid,
+                               uint64_t n) {
+  if (!ctx || ((!src || !dst) && n)) return GG_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  GG_HIP(hipSetDevice(ctx->device));
+  if (ctx->n_edges + n >= (uint64_t)INVALID_U32) {
+    set_error("edge table larger than 2^32-2 rows is not supported");
+    return GG_ERR_TOO_LARGE;
+  }
+  const size_t S = gg_ctx::STAGE_ROWS;
+  while (n) {
+    size_t room = S - ctx->fill_e;
+    size_t take = n < room ? (size_t)n : room;
+    int64_t *blk = ctx->pin_e[ctx->cur_e];
+    memcpy(blk + ctx->fill_e, src, take * sizeof(int64_t));
+    memcpy(blk + S + ctx->fill_e, dst, take * sizeof(int64_t));
+    if (rowid) {
+      memcpy(blk + 2 * S + ctx->fill_e, rowid, take * sizeof(int64_t));
+      rowid += take;
+    } else {
+      int64_t base = (int64_t)ctx->n_edges;
+      int64_t *r = blk + 2 * S + ctx->fill_e;
+      for (size_t i = 0; i < take; i++) r[i] = base + (int64_t)i;
+    }
+    ctx->fill_e += take;
+    ctx->n_edges += take;
+    src += take;
+    dst += take;
+    n -= take;
+    if (ctx->fill_e == S) GG_TRY(flush_edges(ctx));
+  }
+  return GG_OK;
+}
+
+extern "C" int gg_staging_sync(gg_ctx *ctx) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  GG_HIP(hipSetDevice(ctx->device));
+  GG_TRY(flush_vertices(ctx));
+  GG_TRY(flush_edges(ctx));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  return GG_OK;
+}
+
+extern "C" int gg_staging_counts(gg_ctx *ctx, uint64_t *n_vertices, uint64_t *n_edges) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n_vertices) *n_vertices = ctx->n_vertices;
+  if (n_edges) *n_edges = ctx->n_edges;
+  return GG_OK;
+}
+
+extern "C" int gg_staging_clear(gg_ctx *ctx) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  GG_HIP(hipSetDevice(ctx->device));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->n_vertices = ctx->n_edges = 0;
+  ctx->fill_v = ctx->fill_e = 0;
+  return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scans (hand-written: per-block reduce -> single-block scan of block sums -> apply)
+// ------------------------------------------------------------------------------------------
+namespace gg {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;  // per thread; block tile = 4096
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix and
+// writes the block total to *total (all threads get it).
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *total, T *lds /* >= 4 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T incl = wave_incl_scan(v, lane);
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  T wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; w++) {
+    T s = lds[w];
+    if (w < wave) wbase += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return wbase + incl - v;
+}
+
+template <typename TIn, typename TAcc>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const TIn *__restrict__ in, TAcc *__restrict__ bsum,
+                                                              uint64_t n) {
+  __shared__ TAcc lds[4];
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+  TAcc s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    uint64_t idx = base + (uint64_t)i * SCAN_THREADS + threadIdx.x;
+    if (idx < n) s += (TAcc)in[idx];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// single block: exclusive scan of nb block sums in place, total to *total_dev
+template <typename TAcc>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(TAcc *__restrict__ bsum, uint64_t nb,
+                                                                 uint64_t *__restrict__ total_dev) {
+  __shared__ TAcc lds[4];
+  TAcc carry = 0;
+  for (uint64_t base = 0; base < nb; base += SCAN_THREADS) {
+    uint64_t idx = base + threadIdx.x;
+    TAcc v = idx < nb ? bsum[idx] : 0;
+    TAcc tot;
+    TAcc ex = block_excl_scan<TAcc>(v, &tot, lds);
+    if (idx < nb) bsum[idx] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total_dev) *total_dev = (uint64_t)carry;
+}
+
+template <typename TIn, typename TOut, typename TAcc>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TIn *__restrict__ in, TOut *__restrict__ out,
+                                                             const TAcc *__restrict__ bsum, uint64_t n) {
+  __shared__ TAcc lds[4];
+  // thread t owns SCAN_ITEMS consecutive elements -> serial scan in registers + block scan of sums
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  TAcc v[SCAN_ITEMS];
+  TAcc s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    uint64_t idx = base + i;
+    v[i] = idx < n ? (TAcc)in[idx] : 0;
+    s += v[i];
+  }
+  TAcc tot;
+  TAcc ex = block_excl_scan<TAcc>(s, &tot, lds) + bsum[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    uint64_t idx = base + i;
+    if (idx < n) out[idx] = (TOut)ex;
+    ex += v[i];
+  }
+}
+
+template <typename TIn, typename TOut, typename TAcc>
+static int scan_impl(gg_ctx *ctx, const TIn *in, TOut *out, uint64_t n, uint64_t *total_dev) {
+  if (n == 0) {
+    if (total_dev) GG_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint64_t), ctx->stream));
+    return GG_OK;
+  }
+  uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  TAcc *bsum = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&bsum, nb * sizeof(TAcc)));
+  GG_LAUNCH(ctx, "scan_reduce", (k_scan_reduce<TIn, TAcc>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, in, bsum, n);
+  GG_LAUNCH(ctx, "scan_blocksums", (k_scan_blocksums<TAcc>), dim3(1), dim3(SCAN_THREADS), 0, bsum, nb, total_dev);
+  GG_LAUNCH(ctx, "scan_apply", (k_scan_apply<TIn, TOut, TAcc>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, in, out,
+            bsum, n);
+  ctx->dev_free(bsum);  // stream-ordered reuse: later work on the same stream runs after these kernels
+  return GG_OK;
+}
+
+int scan_exclusive_u32(gg_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint64_t *total_dev) {
+  return scan_impl<uint32_t, uint32_t, uint64_t>(ctx, in, out, n, total_dev);
+}
+int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *total_dev) {
+  return scan_impl<uint64_t, uint64_t, uint64_t>(ctx, in, out, n, total_dev);
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lookup_ids(const int64_t *__restrict__ ids, uint64_t n,
+                                                    const int64_t *__restrict__ keys,
+                                                    const uint32_t *__restrict__ vals, uint32_t shift, uint64_t mask,
+                                                    int64_t min_idx, uint32_t *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ht_lookup(keys, vals, shift, mask, min_idx, ids[i]);
+}
+
+int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev) {
+  if (n == 0) return GG_OK;
+  GG_LAUNCH(ctx, "lookup_ids", k_lookup_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids_dev, n,
+            csr->ht_keys, csr->ht_vals, csr->ht_shift, csr->ht_cap - 1, csr->ht_min_idx, out_dev);
+  return GG_OK;
+}
+
+}  // namespace gg

@@ -1,0 +1,275 @@
+"""ctypes binding of include/gg.h (test/bench harness; the C-ABI itself is the product boundary)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgg.so")
+
+GG_MAX_HOPS = 8
+GG_BFS_LANES = 64
+GG_CHUNK_ROWS = 1024
+
+# every symbol include/gg.h declares (tests/test_abi.py checks the library exports exactly these)
+SYMBOLS = [
+    "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
+    "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
+    "gg_csr_build", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
+    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition",
+    "gg_result_rows", "gg_result_fetch", "gg_result_destroy",
+    "gg_bfs64",
+    "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
+]
+
+
+class GGError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"gg error {code}: {msg}")
+        self.code = code
+
+
+class KhopStats(C.Structure):
+    _fields_ = [
+        ("rows", C.c_uint64 * (GG_MAX_HOPS + 1)),
+        ("digest", C.c_uint64 * (GG_MAX_HOPS + 1)),
+        ("traversed_edges", C.c_uint64),
+        ("frontier_entries", C.c_uint64),
+    ]
+
+
+class BfsStats(C.Structure):
+    _fields_ = [
+        ("levels", C.c_uint32),
+        ("traversed_edges", C.c_uint64),
+        ("active_vertices", C.c_uint64),
+        ("reached_pairs", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load libgg.so; raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the gg hot path."
+        )
+    lib = C.CDLL(p)
+    P, u64, i64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_int64)
+    lib.gg_version.restype = C.c_char_p
+    lib.gg_last_error.restype = C.c_char_p
+    lib.gg_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.gg_ctx_create.argtypes = [C.c_int, C.POINTER(P)]
+    lib.gg_ctx_destroy.argtypes = [P]
+    lib.gg_ctx_destroy.restype = None
+    lib.gg_vertices_append.argtypes = [P, i64p, u64]
+    lib.gg_edges_append.argtypes = [P, i64p, i64p, i64p, u64]
+    lib.gg_staging_sync.argtypes = [P]
+    lib.gg_staging_counts.argtypes = [P, C.POINTER(u64), C.POINTER(u64)]
+    lib.gg_staging_clear.argtypes = [P]
+    lib.gg_csr_build.argtypes = [P, C.POINTER(P)]
+    lib.gg_csr_destroy.argtypes = [P]
+    lib.gg_csr_destroy.restype = None
+    lib.gg_csr_info.argtypes = [P, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    lib.gg_csr_export.argtypes = [P, i64p, i64p, i64p, i64p]
+    lib.gg_expand_khop.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
+    lib.gg_expand_khop_range.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
+    lib.gg_khop_partition.argtypes = [P, P, C.c_int, C.POINTER(u64)]
+    lib.gg_result_rows.argtypes = [P, C.c_int, C.POINTER(u64)]
+    lib.gg_result_fetch.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
+    lib.gg_result_destroy.argtypes = [P]
+    lib.gg_result_destroy.restype = None
+    lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
+    lib.gg_profile_enable.argtypes = [P, C.c_int]
+    lib.gg_profile_reset.argtypes = [P]
+    lib.gg_profile_count.argtypes = [P, C.POINTER(C.c_int)]
+    lib.gg_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class Csr:
+    def __init__(self, gg: "GG", handle):
+        self.gg, self.handle = gg, handle
+        V, E, D = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        gg._chk(gg.lib.gg_csr_info(handle, C.byref(V), C.byref(E), C.byref(D)))
+        self.V, self.E, self.dropped = V.value, E.value, D.value
+
+    def export(self):
+        off = np.empty(self.V + 1, np.int64)
+        nbr = np.empty(self.E, np.int64)
+        eid = np.empty(self.E, np.int64)
+        vid = np.empty(self.V, np.int64)
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))  # noqa: E731
+        self.gg._chk(self.gg.lib.gg_csr_export(self.handle, p(off), p(nbr), p(eid), p(vid)))
+        return off, nbr, eid, vid
+
+    def close(self):
+        if self.handle:
+            self.gg.lib.gg_csr_destroy(self.handle)
+            self.handle = None
+
+
+class GG:
+    """One gg_ctx.  Mirrors the call sequence of the C++ operators: append (Sink) -> build (Finalize)
+    -> expand / bfs (GetData)."""
+
+    def __init__(self, device: int = 0, chunk_rows: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        self._chk(self.lib.gg_ctx_create(device, C.byref(h)))
+        self.ctx = h
+        self.chunk_rows = chunk_rows  # >0: append in DataChunk-sized pieces like the Sink would
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise GGError(rc, self.lib.gg_last_error().decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.gg_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    # ---- staging
+    def append_vertices(self, ids):
+        a, p = _i64(ids)
+        step = self.chunk_rows or max(1, a.size)
+        for o in range(0, a.size, step):
+            n = min(step, a.size - o)
+            self._chk(self.lib.gg_vertices_append(self.ctx, C.cast(C.addressof(p.contents) + 8 * o, C.POINTER(C.c_int64)), n))
+
+    def append_edges(self, src, dst, rowid=None):
+        s, ps = _i64(src)
+        d, pd = _i64(dst)
+        assert s.size == d.size
+        if rowid is not None:
+            r, pr = _i64(rowid)
+        step = self.chunk_rows or max(1, s.size)
+        i64p = C.POINTER(C.c_int64)
+        for o in range(0, s.size, step):
+            n = min(step, s.size - o)
+            a = C.cast(C.addressof(ps.contents) + 8 * o, i64p)
+            b = C.cast(C.addressof(pd.contents) + 8 * o, i64p)
+            c = C.cast(C.addressof(pr.contents) + 8 * o, i64p) if rowid is not None else None
+            self._chk(self.lib.gg_edges_append(self.ctx, a, b, c, n))
+
+    def staging_sync(self):
+        self._chk(self.lib.gg_staging_sync(self.ctx))
+
+    def staging_clear(self):
+        self._chk(self.lib.gg_staging_clear(self.ctx))
+
+    def staging_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.gg_staging_counts(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- build
+    def build_csr(self) -> Csr:
+        h = C.c_void_p()
+        self._chk(self.lib.gg_csr_build(self.ctx, C.byref(h)))
+        return Csr(self, h)
+
+    # ---- k-hop
+    @staticmethod
+    def _stats_dict(st: KhopStats):
+        return {
+            "rows": list(st.rows),
+            "digest": list(st.digest),
+            "traversed_edges": st.traversed_edges,
+            "frontier_entries": st.frontier_entries,
+        }
+
+    def _collect(self, res, k_min, k_max):
+        out = {}
+        try:
+            for h in range(k_min, k_max + 1):
+                n = C.c_uint64()
+                self._chk(self.lib.gg_result_rows(res, h, C.byref(n)))
+                table = np.empty((n.value, h + 1), np.int64)
+                bufs = [np.empty(GG_CHUNK_ROWS, np.int64) for _ in range(h + 1)]
+                ptrs = (C.POINTER(C.c_int64) * (h + 1))(*[b.ctypes.data_as(C.POINTER(C.c_int64)) for b in bufs])
+                got = C.c_uint32()
+                o = 0
+                while o < n.value:  # <=1024-row slices: one DataChunk per fetch
+                    self._chk(self.lib.gg_result_fetch(res, h, o, GG_CHUNK_ROWS, ptrs, C.byref(got)))
+                    for c in range(h + 1):
+                        table[o : o + got.value, c] = bufs[c][: got.value]
+                    o += got.value
+                out[h] = table
+        finally:
+            self.lib.gg_result_destroy(res)
+        return out
+
+    def expand_khop(self, csr: Csr, k_min: int, k_max: int, sources=None, materialise=False):
+        st = KhopStats()
+        res = C.c_void_p()
+        if sources is None:
+            rc = self.lib.gg_expand_khop(self.ctx, csr.handle, None, 0, k_min, k_max, int(materialise), C.byref(st), C.byref(res))
+        else:
+            a, p = _i64(sources)
+            rc = self.lib.gg_expand_khop(self.ctx, csr.handle, p, a.size, k_min, k_max, int(materialise), C.byref(st), C.byref(res))
+        self._chk(rc)
+        d = self._stats_dict(st)
+        if materialise:
+            d["tables"] = self._collect(res, k_min, k_max)
+        return d
+
+    def expand_khop_range(self, csr: Csr, lo: int, hi: int, k_min: int, k_max: int, materialise=False):
+        st = KhopStats()
+        res = C.c_void_p()
+        self._chk(self.lib.gg_expand_khop_range(self.ctx, csr.handle, lo, hi, k_min, k_max, int(materialise), C.byref(st), C.byref(res)))
+        d = self._stats_dict(st)
+        if materialise:
+            d["tables"] = self._collect(res, k_min, k_max)
+        return d
+
+    def khop_partition(self, csr: Csr, n_parts: int):
+        b = (C.c_uint64 * (n_parts + 1))()
+        self._chk(self.lib.gg_khop_partition(self.ctx, csr.handle, n_parts, b))
+        return list(b)
+
+    # ---- bfs
+    def bfs64(self, csr: Csr, sources, max_hops: int, targets=None):
+        s, ps = _i64(sources)
+        n_out = csr.V if targets is None else len(targets)
+        out = np.empty((s.size, n_out), np.int32)
+        st = BfsStats()
+        if targets is None:
+            rc = self.lib.gg_bfs64(self.ctx, csr.handle, ps, s.size, max_hops, None, 0, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st))
+        else:
+            t, pt = _i64(targets)
+            rc = self.lib.gg_bfs64(self.ctx, csr.handle, ps, s.size, max_hops, pt, t.size, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st))
+        self._chk(rc)
+        return out, {"levels": st.levels, "traversed_edges": st.traversed_edges, "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
+
+    # ---- profiling
+    def profile(self, on: bool):
+        self._chk(self.lib.gg_profile_enable(self.ctx, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.gg_profile_reset(self.ctx))
+
+    def profile_get(self):
+        n = C.c_int()
+        self._chk(self.lib.gg_profile_count(self.ctx, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name, cnt, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self._chk(self.lib.gg_profile_get(self.ctx, i, C.byref(name), C.byref(cnt), C.byref(ms)))
+            out[name.value.decode()] = (cnt.value, ms.value)
+        return out

@@ -1,0 +1,159 @@
+/* gg.h — C-ABI of the MI355X-native graph pattern-matching hot path ("gg" = GPU graph).
+ *
+ * This is the drop-in boundary between DuckDB-style host operators (C++, see
+ * duckdb_pgq_amd/host/) and the hand-written HIP kernels for gfx950 (duckdb_pgq_amd/csrc/).
+ * Plain pointers and sizes only: no C++ types, no torch types, no exceptions cross it.
+ *
+ * What each entry point replaces in the reference (cwida/duckdb-pgq.old, paths relative to
+ * /root/reference; the reference has no C ABI at operator level — SURVEY.md §8b — so these are
+ * the calls our PhysicalOperator subclasses make where the reference's operators call their
+ * CPU data structures):
+ *
+ *   gg_vertices_append / gg_edges_append
+ *        <- PhysicalHashJoin::Sink -> JoinHashTable::Build      src/execution/operator/join/physical_hash_join.cpp:128-154,
+ *                                                               src/execution/join_hashtable.cpp:150-238
+ *           (called concurrently from Sink threads, one call per <=1024-row DataChunk column set)
+ *   gg_csr_build
+ *        <- PhysicalHashJoin::Finalize -> JoinHashTable::Finalize/InsertHashes
+ *                                                               physical_hash_join.cpp:165-185, join_hashtable.cpp:240-302
+ *           (single-threaded finalize of the adjacency index keyed on the source vertex)
+ *   gg_expand_khop / gg_result_fetch
+ *        <- PhysicalHashJoin::Execute -> JoinHashTable::Probe + ScanStructure::NextInnerJoin (chain of k joins)
+ *                                                               physical_hash_join.cpp:217-254, join_hashtable.cpp:304-476
+ *           (fixed-length path expansion; fetch hands back <=1024-row slices = one DataChunk)
+ *   gg_bfs64
+ *        <- PhysicalRecursiveCTE::{Sink,GetData,ExecuteRecursivePipelines} + GroupedAggregateHashTable::FindOrCreateGroups
+ *           + PhysicalHashAggregate (min(hopCount) GROUP BY start, friend)
+ *                                                               src/execution/operator/set/physical_recursive_cte.cpp:48-139,
+ *                                                               src/execution/aggregate_hashtable.cpp:367-504,
+ *                                                               src/execution/operator/aggregate/physical_hash_aggregate.cpp:152-266
+ *           (the friends/friends_shortest CTE pair of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31)
+ *
+ * Conventions
+ *   - every int-returning function returns GG_OK (0) or a negative GG_ERR_*; the message is
+ *     available from gg_last_error() (thread-local).  The C++ operators turn a non-zero status
+ *     into a duckdb::IOException, mirroring how the reference reports operator errors.
+ *   - all pointers are HOST memory unless the name ends in _dev; inputs are copied, outputs are
+ *     written into caller-allocated arrays.
+ *   - gg_vertices_append / gg_edges_append are thread-safe; everything else on one gg_ctx is
+ *     externally serialised (DuckDB calls Finalize/GetData single-threaded per operator).
+ *   - vertex ids are arbitrary int64 (LDBC person ids are sparse); the *dense index* of a vertex
+ *     is its 0-based position in the vertex table as appended (= DuckDB rowid of the vertex row).
+ *   - an edge whose src or dst id is not in the vertex table is dropped (inner-join semantics of
+ *     `person p1, knows k, person p2 WHERE p1.id = k.src AND k.dst = p2.id`).
+ *   - there is no CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef GG_H
+#define GG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_OK 0
+#define GG_ERR_INVALID_ARG (-1)
+#define GG_ERR_HIP (-2)
+#define GG_ERR_OOM (-3)
+#define GG_ERR_DUPLICATE_VERTEX (-4)
+#define GG_ERR_TOO_LARGE (-5)
+#define GG_ERR_STATE (-6)
+#define GG_ERR_NO_DEVICE (-7)
+
+#define GG_MAX_HOPS 8    /* longest fixed-length pattern gg_expand_khop accepts */
+#define GG_BFS_LANES 64  /* sources per bitset-BFS batch (one bit lane each) */
+#define GG_CHUNK_ROWS 1024 /* STANDARD_VECTOR_SIZE, src/include/duckdb/common/vector_size.hpp:17 */
+
+typedef struct gg_ctx gg_ctx;       /* device, stream, staging buffers; caller-owned */
+typedef struct gg_csr gg_csr;       /* device-resident CSR adjacency index; caller-owned */
+typedef struct gg_result gg_result; /* device-resident materialised path rows; caller-owned */
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char *gg_version(void);
+const char *gg_last_error(void);
+int gg_device_count(int *out_count);
+int gg_ctx_create(int device, gg_ctx **out);
+void gg_ctx_destroy(gg_ctx *ctx);
+
+/* ---- staging: base-table columns -> HBM (Sink side) -------------------------------------- */
+/* Append n vertex ids (vertex-table key column, in table order). */
+int gg_vertices_append(gg_ctx *ctx, const int64_t *id, uint64_t n);
+/* Append n edge rows.  rowid may be NULL (then the edge's 0-based append position is its rowid). */
+int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *dst, const int64_t *rowid, uint64_t n);
+/* Block until every appended row is resident in HBM (bench: the timed region starts after this). */
+int gg_staging_sync(gg_ctx *ctx);
+int gg_staging_counts(gg_ctx *ctx, uint64_t *n_vertices, uint64_t *n_edges);
+int gg_staging_clear(gg_ctx *ctx);
+
+/* ---- CSR build (Finalize side) ------------------------------------------------------------ */
+/* Densify ids (device hash table), histogram + prefix-scan + stable LSD radix scatter by source.
+ * Within a CSR row, neighbours are in ascending edge-rowid (append) order: the build is
+ * deterministic.  Staged columns stay resident, so the build can be repeated.
+ * Fails with GG_ERR_DUPLICATE_VERTEX if the vertex key column is not unique. */
+int gg_csr_build(gg_ctx *ctx, gg_csr **out);
+void gg_csr_destroy(gg_csr *csr);
+int gg_csr_info(const gg_csr *csr, uint64_t *n_vertices, uint64_t *n_edges_kept, uint64_t *n_edges_dropped);
+/* Parity export.  off: V+1 entries; nbr: E_kept dense neighbour indices; eid: E_kept edge rowids
+ * (may be NULL); vid: V vertex ids by dense index (may be NULL). */
+int gg_csr_export(const gg_csr *csr, int64_t *off, int64_t *nbr, int64_t *eid, int64_t *vid);
+
+/* ---- fixed-length path expansion (k-hop MATCH) -------------------------------------------- */
+typedef struct gg_khop_stats {
+  uint64_t rows[GG_MAX_HOPS + 1];   /* rows[h] = number of h-hop walks emitted (h in k_min..k_max) */
+  uint64_t digest[GG_MAX_HOPS + 1]; /* digest[h] = sum over those rows of gg row hash mod 2^64 */
+  uint64_t traversed_edges;         /* TE = adjacency entries read over all hops */
+  uint64_t frontier_entries;        /* path prefixes whose adjacency list was expanded */
+} gg_khop_stats;
+
+/* All walks  s -> v1 -> ... -> vh  with h in [k_min, k_max] (1 <= k_min <= k_max <= GG_MAX_HOPS),
+ * s drawn from the source list (with multiplicity).  src_ids == NULL: every vertex is a source.
+ * Source ids absent from the vertex table contribute nothing.
+ * materialise == 0: count + digest only (out_result may be NULL).
+ * materialise != 0: rows are written to HBM as int64 vertex ids, one table per length h with h+1
+ *                   columns, and handed back through *out_result. */
+int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min, int k_max,
+                   int materialise, gg_khop_stats *stats, gg_result **out_result);
+/* Same, sources = dense vertex indices [src_lo, src_hi) — the multi-GPU sharding entry point
+ * (each rank takes one contiguous range; no data-path collective). */
+int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src_lo, uint64_t src_hi, int k_min, int k_max,
+                         int materialise, gg_khop_stats *stats, gg_result **out_result);
+/* Split [0,V) into n_parts contiguous source ranges of near-equal 2-hop work (sum over u of
+ * sum over v in adj(u) of (1+deg(v))).  bounds: n_parts+1 entries. */
+int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds);
+
+int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows);
+/* Copy rows [offset, offset+max_rows) of the h-hop table into cols[0..h] (host arrays of >= max_rows). */
+int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *cols,
+                    uint32_t *n_out);
+void gg_result_destroy(gg_result *res);
+
+/* ---- 64-lane bitset BFS (shortest path length) --------------------------------------------- */
+typedef struct gg_bfs_stats {
+  uint32_t levels;               /* levels expanded */
+  uint64_t traversed_edges;      /* sum over levels of deg(v) over vertices active in any lane */
+  uint64_t active_vertices;      /* sum over levels of |{v : frontier[v] != 0}| */
+  uint64_t reached_pairs;        /* (lane, vertex) pairs with dist >= 0 */
+} gg_bfs_stats;
+
+/* Lane i starts at src_ids[i] (n_src <= 64).  out_dist[i*n + j] = length of the shortest walk from
+ * src_ids[i] to target j, or -1 if none of length <= max_hops (max_hops < 0: run to fixpoint).
+ * Targets: dst_ids == NULL -> every vertex in vertex-table order (n = V); else the n_dst given ids
+ * (ids absent from the vertex table get -1).  A source absent from the vertex table reaches nothing.
+ * Equals, for the reached pairs, the reference relation
+ *   SELECT startPerson, friend, min(hopCount) FROM friends GROUP BY startPerson, friend
+ * with the recursion bound `f.hopCount < max_hops` (bi-10-shortestpath.sql:8-31). */
+int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops, const int64_t *dst_ids,
+             uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats);
+
+/* ---- in-library kernel timing (HIP events on the library's own stream) ---------------------- */
+int gg_profile_enable(gg_ctx *ctx, int on);
+int gg_profile_reset(gg_ctx *ctx);
+/* Number of distinct kernels seen; then per index: name, launches, total milliseconds. */
+int gg_profile_count(gg_ctx *ctx, int *n);
+int gg_profile_get(gg_ctx *ctx, int index, const char **name, uint64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GG_H */

@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path (through the C-ABI, libgg.so) against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact (all integer work).  Run on the GPU box with `-m gpu`."""
+import numpy as np
+import pytest
+
+from duckdb_pgq_amd import datagen
+from tests.oracle_lib import sort_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def build_both(gg, orc, vid, src, dst, rowid=None, chunk_rows=0):
+    gg.staging_clear()
+    old = gg.chunk_rows
+    gg.chunk_rows = chunk_rows
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst, rowid)
+    gg.chunk_rows = old
+    csr = gg.build_csr()
+    rc, g = orc.csr_build(vid, src, dst, rowid)
+    assert rc == 0
+    return csr, g
+
+
+def assert_csr_equal(csr, g):
+    off, nbr, eid, vid = csr.export()
+    o_off, o_nbr, o_eid, o_vid = g.arrays()
+    assert csr.V == g.V and csr.E == g.E and csr.dropped == g.dropped
+    assert np.array_equal(off, o_off)
+    assert np.array_equal(vid, o_vid)
+    assert np.array_equal(nbr, o_nbr)  # bit-exact INCLUDING order inside rows (stable build)
+    assert np.array_equal(eid, o_eid)
+
+
+CASES = [
+    # V, E, seed, dangling, dup
+    (1, 0, 1, 0, 0),
+    (1, 5, 2, 0, 0),        # self loops only
+    (2, 1, 3, 0, 0),
+    (10, 40, 4, 0, 0),
+    (50, 400, 5, 6, 20),
+    (300, 5000, 6, 10, 100),
+    (2049, 30000, 7, 0, 0),  # > 2048 vertices: two radix passes
+    (5000, 200000, 8, 50, 0),
+]
+
+
+@pytest.mark.parametrize("V,E,seed,dangling,dup", CASES)
+def test_csr_build_bit_exact(gg, orc, V, E, seed, dangling, dup):
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    assert_csr_equal(csr, g)
+    csr.close()
+    g.close()
+
+
+def test_csr_empty_tables(gg, orc):
+    z = np.zeros(0, np.int64)
+    csr, g = build_both(gg, orc, z, z, z)
+    assert csr.V == 0 and csr.E == 0
+    st = gg.expand_khop(csr, 1, 2)
+    assert st["rows"][1] == 0 and st["rows"][2] == 0 and st["traversed_edges"] == 0
+    csr.close()
+    g.close()
+    # vertices but no edges
+    vid = datagen.person_ids(100, 3)
+    csr, g = build_both(gg, orc, vid, z, z)
+    assert_csr_equal(csr, g)
+    st = gg.expand_khop(csr, 1, 2)
+    assert st["rows"][1] == 0 and st["traversed_edges"] == 0 and st["frontier_entries"] == 100
+    dist, bst = gg.bfs64(csr, vid[:3], 5)
+    assert (dist >= 0).sum() == 3
+    csr.close()
+    g.close()
+
+
+def test_csr_rowid_and_chunked_append(gg, orc):
+    """Sink-style 1024-row appends with explicit (non-monotone) rowids; ragged last chunk."""
+    vid, src, dst = datagen.small_graph(700, 10_000 + 37, 21, dangling=5)
+    rowid = (np.arange(src.size, dtype=np.int64) * 7919) % 1_000_003
+    csr, g = build_both(gg, orc, vid, src, dst, rowid=rowid, chunk_rows=1024)
+    assert_csr_equal(csr, g)
+    csr.close()
+    g.close()
+
+
+def test_csr_sentinel_and_extreme_ids(gg, orc):
+    vid = np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).max, 0, -1, 42], np.int64)
+    src = np.array([vid[0], vid[1], vid[0], 0, 42, 42, 7], np.int64)
+    dst = np.array([vid[1], vid[0], vid[0], -1, vid[0], 42, 0], np.int64)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    assert_csr_equal(csr, g)
+    assert csr.dropped == 1
+    csr.close()
+    g.close()
+
+
+def test_duplicate_vertex_is_an_error(gg):
+    from duckdb_pgq_amd import GGError
+
+    gg.staging_clear()
+    gg.append_vertices(np.array([1, 2, 3, 2], np.int64))
+    gg.append_edges(np.array([1], np.int64), np.array([2], np.int64))
+    with pytest.raises(GGError) as e:
+        gg.build_csr()
+    assert e.value.code == -4
+
+
+def test_csr_build_repeatable(gg, orc):
+    """The staged columns stay resident: building twice gives the same bits (no atomics decide a slot)."""
+    vid, src, dst = datagen.ldbc_knows(3000, 120_000, 99)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    a = csr.export()
+    csr2 = gg.build_csr()
+    b = csr2.export()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert_csr_equal(csr2, g)
+    csr.close()
+    csr2.close()
+    g.close()
+
+
+@pytest.mark.parametrize("V,E,seed,dangling,dup", CASES[3:])
+@pytest.mark.parametrize("k", [(1, 1), (1, 2), (2, 2), (1, 3), (2, 4)])
+def test_khop_count_digest(gg, orc, V, E, seed, dangling, dup, k):
+    if k[1] >= 3 and E > 30000:
+        pytest.skip("oracle enumeration too large")
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    got = gg.expand_khop(csr, k[0], k[1])
+    ref = g.khop(k[0], k[1])
+    assert got == ref
+    csr.close()
+    g.close()
+
+
+def test_khop_materialised_rows_equal_join_formulation(gg, orc):
+    """Materialised rows (fetched in <=1024-row slices) equal the rows the reference's hash-join chain
+    produces (oracle restatement of JoinHashTable), as a sorted multiset."""
+    vid, src, dst = datagen.small_graph(120, 900, 31, dangling=6, dup_edges=15)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    got = gg.expand_khop(csr, 1, 3, materialise=True)
+    ref = orc.khop_join(vid, src, dst, 1, 3)
+    for h in (1, 2, 3):
+        r = vid[ref[h]] if ref[h].size else ref[h]
+        assert got["tables"][h].shape == r.shape
+        assert np.array_equal(sort_rows(got["tables"][h]), sort_rows(r))
+        assert got["digest"][h] == orc.digest_rows(ref[h])
+    csr.close()
+    g.close()
+
+
+def test_khop_source_list(gg, orc):
+    vid, src, dst = datagen.ldbc_knows(2000, 60_000, 5)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = np.concatenate([datagen.pick_sources(vid, 300, 8), vid[:5], vid[:5], np.array([-1, 77], np.int64)])
+    got = gg.expand_khop(csr, 1, 2, sources=sources, materialise=True)
+    dense = g.lookup(sources)
+    dense = dense[dense >= 0].astype(np.uint32)
+    ref = g.khop(1, 2, sources_dense=dense)
+    tables = got.pop("tables")
+    assert got == ref
+    rows = g.khop_rows(1, 2, sources_dense=dense)
+    for h in (1, 2):
+        assert np.array_equal(sort_rows(tables[h]), sort_rows(rows[h]))
+    # empty / all-missing source lists
+    assert gg.expand_khop(csr, 1, 2, sources=np.array([-3, -4], np.int64))["traversed_edges"] == 0
+    assert gg.expand_khop(csr, 1, 2, sources=np.zeros(0, np.int64))["traversed_edges"] == 0
+    csr.close()
+    g.close()
+
+
+def test_khop_ranges_partition_the_result(gg, orc):
+    """Sharding entry point: per-range counts/digests add up to the whole (what the multi-GPU path sums)."""
+    vid, src, dst = datagen.ldbc_knows(5000, 200_000, 17)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    whole = gg.expand_khop(csr, 1, 2)
+    assert whole == g.khop(1, 2)
+    for parts in (2, 3, 8):
+        b = gg.khop_partition(csr, parts)
+        assert b[0] == 0 and b[-1] == csr.V and all(x <= y for x, y in zip(b, b[1:]))
+        rows = [0, 0, 0]
+        dig = [0, 0, 0]
+        te = 0
+        for lo, hi in zip(b, b[1:]):
+            st = gg.expand_khop_range(csr, lo, hi, 1, 2)
+            assert st == g.khop(1, 2, lo=lo, hi=hi)
+            for h in (1, 2):
+                rows[h] += st["rows"][h]
+                dig[h] = (dig[h] + st["digest"][h]) & 0xFFFFFFFFFFFFFFFF
+            te += st["traversed_edges"]
+        assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3] and te == whole["traversed_edges"]
+    csr.close()
+    g.close()
+
+
+def test_khop_high_degree_and_zero_degree_runs(gg, orc):
+    """A hub with 5000 neighbours, followed by >256 isolated vertices (exercises the tile window
+    fallback), then a chain."""
+    V = 6000
+    vid = datagen.person_ids(V, 77)
+    hub = np.full(5000, vid[0])
+    spokes = vid[1:5001]
+    chain_s = vid[5500:5999]
+    chain_d = vid[5501:6000]
+    src = np.concatenate([hub, spokes[:100], chain_s])
+    dst = np.concatenate([spokes, hub[:100], chain_d])
+    csr, g = build_both(gg, orc, vid, src, dst)
+    assert_csr_equal(csr, g)
+    for k in [(1, 1), (1, 2), (2, 3)]:
+        assert gg.expand_khop(csr, *k) == g.khop(*k)
+    csr.close()
+    g.close()
+
+
+@pytest.mark.parametrize("V,E,seed,max_hops", [(30, 60, 1, 5), (100, 300, 2, 3), (100, 300, 2, 0), (64, 2000, 3, 2), (3000, 40000, 4, -1), (40, 30, 4, 6)])
+def test_bfs64_equals_recursive_cte(gg, orc, V, E, seed, max_hops):
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=3)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = np.concatenate([datagen.pick_sources(vid, 61, seed), np.array([999], np.int64), vid[:2]])
+    assert sources.size <= 64
+    dist, st = gg.bfs64(csr, sources, max_hops)
+    o_dist, o_st = g.bfs64(g.lookup(sources), max_hops)
+    assert np.array_equal(dist, o_dist)
+    assert st == o_st
+    if max_hops >= 0 and E <= 2000:
+        ref = orc.cte_shortest(vid, src, dst, sources, max_hops)  # the reference's relation
+        got = {(int(sources[i]), int(vid[v]), int(dist[i, v])) for i in range(sources.size) for v in np.nonzero(dist[i] >= 0)[0]}
+        assert got == {tuple(r) for r in ref.tolist()}
+    # explicit target list, including ids that are not vertices
+    targets = np.concatenate([vid[::7], np.array([-12345], np.int64)])
+    d2, _ = gg.bfs64(csr, sources, max_hops, targets=targets)
+    assert np.array_equal(d2[:, :-1], dist[:, ::7]) and np.all(d2[:, -1] == -1)
+    csr.close()
+    g.close()
+
+
+def test_medium_ldbc_shape_end_to_end(gg, orc):
+    """LDBC SF1-sized synthetic graph: CSR bit-exact, 2-hop count/digest, 64-source BFS."""
+    vid, src, dst = datagen.ldbc("sf1")
+    csr, g = build_both(gg, orc, vid, src, dst, chunk_rows=122_880)  # one row group per append
+    assert_csr_equal(csr, g)
+    assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
+    sources = datagen.pick_sources(vid, 64, 1)
+    dist, st = gg.bfs64(csr, sources, -1)
+    o_dist, o_st = g.bfs64(g.lookup(sources), -1)
+    assert np.array_equal(dist, o_dist) and st == o_st
+    csr.close()
+    g.close()

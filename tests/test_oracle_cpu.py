@@ -1,0 +1,102 @@
+"""CPU tests of the oracle itself: the join/CTE restatement of the reference operators against the
+reference's own golden rows, and against the direct CSR formulation used for full-size inputs."""
+import numpy as np
+import pytest
+
+from duckdb_pgq_amd import datagen
+from tests import trainbenchmark as tb
+from tests.oracle_lib import sort_rows
+
+
+def test_jht_chain_prepend_order(orc):
+    # duplicates of one key chain newest-first (join_hashtable.cpp:251-259); within a probe chunk all
+    # first matches are emitted before second matches (ScanStructure::NextInnerJoin)
+    build = np.array([5, 7, 5, 5, 9], np.int64)
+    probe = np.array([5, 9, 4, 5], np.int64)
+    m = orc.hash_join(build, probe)
+    assert m.tolist() == [[0, 3], [1, 4], [3, 3], [0, 2], [3, 2], [0, 0], [3, 0]]
+
+
+def test_jht_long_chain(orc):
+    # test/sql/join/inner/test_join_duplicates.test:14-24 — a 10 240-long duplicate chain
+    build = np.full(10240, 1, np.int64)
+    probe = np.array([1, 2, 1], np.int64)
+    m = orc.hash_join(build, probe)
+    assert m.shape[0] == 2 * 10240
+    assert set(m[:, 0].tolist()) == {0, 2}
+    assert sorted(m[m[:, 0] == 0, 1].tolist()) == list(range(10240))
+
+
+def test_connectedsegments_golden(orc):
+    # the only golden vector on graph data in the reference:
+    # benchmark/trainbenchmark/connectedsegments.benchmark:34-38
+    rows = tb.connectedsegments_via_joins(orc, tb.tables())
+    assert sort_rows(rows).tolist() == sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN).tolist()
+
+
+@pytest.mark.parametrize("V,E,seed,dangling,dup", [(1, 0, 1, 0, 0), (10, 40, 2, 0, 0), (50, 400, 3, 6, 20), (200, 1500, 4, 10, 0), (7, 60, 5, 0, 30)])
+@pytest.mark.parametrize("k", [(1, 1), (1, 2), (2, 2), (1, 3), (3, 3)])
+def test_khop_join_equals_csr(orc, V, E, seed, dangling, dup, k):
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    kmin, kmax = k
+    j = orc.khop_join(vid, src, dst, kmin, kmax)
+    c = g.khop_rows(kmin, kmax)
+    st = g.khop(kmin, kmax, threads=2)
+    for h in range(kmin, kmax + 1):
+        jr = vid[j[h]] if j[h].size else j[h]
+        assert sort_rows(jr).tolist() == sort_rows(c[h]).tolist()
+        assert st["rows"][h] == j[h].shape[0]
+        assert st["digest"][h] == orc.digest_rows(j[h])
+    g.close()
+
+
+def test_khop_sources_subset_and_missing(orc):
+    vid, src, dst = datagen.small_graph(60, 500, 11, dangling=4)
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    sources = np.concatenate([vid[[3, 3, 17, 59]], np.array([123456789, -5], np.int64)])
+    j = orc.khop_join(vid, src, dst, 1, 2, sources=sources)
+    dense = g.lookup(sources)
+    dense = dense[dense >= 0].astype(np.uint32)
+    st = g.khop(1, 2, sources_dense=dense)
+    for h in (1, 2):
+        assert st["rows"][h] == j[h].shape[0]
+        assert st["digest"][h] == orc.digest_rows(j[h])
+    g.close()
+
+
+def test_duplicate_vertex_rejected(orc):
+    rc, g = orc.csr_build(np.array([1, 2, 1], np.int64), np.array([1], np.int64), np.array([2], np.int64))
+    assert rc == -4
+    g.close()
+
+
+@pytest.mark.parametrize("V,E,seed,max_hops", [(30, 60, 1, 5), (100, 300, 2, 3), (100, 300, 2, 0), (64, 2000, 3, 2), (40, 30, 4, 6)])
+def test_cte_shortest_equals_bfs(orc, V, E, seed, max_hops):
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=3)
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    sources = np.concatenate([datagen.pick_sources(vid, 10, seed), np.array([999], np.int64), vid[:1]])
+    ref = orc.cte_shortest(vid, src, dst, sources, max_hops)
+    dense = g.lookup(sources)
+    dist, st = g.bfs64(dense, max_hops)
+    got = set()
+    for i, s in enumerate(sources):
+        for v in np.nonzero(dist[i] >= 0)[0]:
+            got.add((int(s), int(vid[v]), int(dist[i, v])))
+    assert got == {tuple(r) for r in ref.tolist()}
+    g.close()
+
+
+def test_datagen_deterministic():
+    a = datagen.ldbc_knows(500, 6000, 42)
+    b = datagen.ldbc_knows(500, 6000, 42)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    vid, src, dst = a
+    assert np.unique(vid).size == vid.size
+    half = src.size // 2
+    assert np.array_equal(src[:half], dst[half:]) and np.array_equal(dst[:half], src[half:])
+    assert not np.any(src == dst)
