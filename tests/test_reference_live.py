@@ -1,0 +1,74 @@
+"""Where the compiled reference is present (oracle/_ref, built from /root/reference by
+`make -C oracle ref`), run it live against the C oracle on a fresh seeded graph.  Skipped on boxes
+that only carry the committed fixtures."""
+import numpy as np
+import pytest
+
+from duckdb_pgq_amd import datagen
+from oracle import ref_duckdb as R
+from tests.oracle_lib import sort_rows
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+
+
+@pytest.fixture(scope="module")
+def refdb():
+    vid, src, dst = datagen.ldbc_knows(1200, 30_000, 0xABCD)
+    db = R.RefDuckDB(threads=4)
+    db.load_ldbc(vid, src, dst)
+    yield db, vid, src, dst
+    db.close()
+
+
+def test_khop_counts_and_rows(orc, refdb):
+    db, vid, src, dst = refdb
+    rc, c = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    st = c.khop(1, 3)
+    for h in (1, 2, 3):
+        assert int(db.execute(R.sql_khop(h))[0, 0]) == st["rows"][h]
+    rows = c.khop_rows(1, 2)
+    for h in (1, 2):
+        assert np.array_equal(sort_rows(db.execute(R.sql_khop_rows(h))), sort_rows(rows[h]))
+    # a source sample by rowid, as bench.py's cpu_baseline leg uses
+    lim = 100
+    got = int(db.execute(R.sql_khop(2, where_extra=f"p0.rowid < {lim}"))[0, 0])
+    assert got == c.khop(2, 2, lo=0, hi=lim)["rows"][2]
+    c.close()
+
+
+def test_shortest_path_relation(orc, refdb):
+    db, vid, src, dst = refdb
+    sources = datagen.pick_sources(vid, 64, 9)
+    for max_hops in (0, 1, 4):
+        ref = sort_rows(db.execute(R.sql_shortest(sources, max_hops)))
+        assert np.array_equal(sort_rows(orc.cte_shortest(vid, src, dst, sources, max_hops)), ref)
+
+
+def test_connectedsegments_sql_on_reference():
+    """The reference itself reproduces its golden rows through our driver (sanity of the driver)."""
+    from tests import trainbenchmark as tb
+
+    db = R.RefDuckDB(threads=1)
+    t = tb.tables()
+    db.load_table("Segment", {"id": t["Segment"][:, 0], "length": t["Segment"][:, 1]})
+    db.load_table("connectsTo", {"TrackElement1_id": t["connectsTo"][:, 0], "TrackElement2_id": t["connectsTo"][:, 1]})
+    db.load_table("monitoredBy", {"TrackElement_id": t["monitoredBy"][:, 0], "Sensor_id": t["monitoredBy"][:, 1]})
+    sql = """SELECT mb1.Sensor_id, ct1.TrackElement1_id, ct2.TrackElement1_id, ct3.TrackElement1_id,
+      ct4.TrackElement1_id, ct5.TrackElement1_id, ct5.TrackElement2_id
+    FROM Segment
+    INNER JOIN connectsTo as ct1 ON Segment.id = ct1.TrackElement1_id
+    INNER JOIN connectsTo as ct2 ON ct1.TrackElement2_id = ct2.TrackElement1_id
+    INNER JOIN connectsTo as ct3 ON ct2.TrackElement2_id = ct3.TrackElement1_id
+    INNER JOIN connectsTo as ct4 ON ct3.TrackElement2_id = ct4.TrackElement1_id
+    INNER JOIN connectsTo as ct5 ON ct4.TrackElement2_id = ct5.TrackElement1_id
+    INNER JOIN monitoredBy as mb1 ON mb1.TrackElement_id = ct1.TrackElement1_id
+    INNER JOIN monitoredBy as mb2 ON mb2.TrackElement_id = ct2.TrackElement1_id
+    INNER JOIN monitoredBy as mb3 ON mb3.TrackElement_id = ct3.TrackElement1_id
+    INNER JOIN monitoredBy as mb4 ON mb4.TrackElement_id = ct4.TrackElement1_id
+    INNER JOIN monitoredBy as mb5 ON mb5.TrackElement_id = ct5.TrackElement1_id
+    INNER JOIN monitoredBy as mb6 ON mb6.TrackElement_id = ct5.TrackElement2_id
+    WHERE mb1.Sensor_id = mb2.Sensor_id AND mb1.Sensor_id = mb3.Sensor_id AND mb1.Sensor_id = mb4.Sensor_id
+      AND mb1.Sensor_id = mb5.Sensor_id AND mb1.Sensor_id = mb6.Sensor_id"""
+    assert np.array_equal(sort_rows(db.execute(sql)), sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN))
+    db.close()
