@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py — traversed edges/sec on LDBC SNB 2-hop MATCH (Person-KNOWS*1..2-Person), MI355X.
+
+One "step" = one pass of the hot path over the synthetic LDBC-shaped tables already resident in HBM:
+    gg_csr_build (densify ids, histogram, scan, stable radix scatter)  +  gg_expand_khop_range(1..2)
+i.e. what the reference does per query as hash-join build + probe chain.  With N > 1 ranks the
+SOURCE vertices are range-partitioned on 2-hop work (gg_khop_partition); every rank builds its own
+CSR replica and expands its range; there is no data-path collective, only one 40-byte all-reduce of
+(rows, digest, TE) per step, so `value` = total traversed edges of the whole query / max-over-ranks
+time ("strong" scaling: the query is fixed, ranks split it).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sf100|sf10|sf1] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (expand_fused2; algorithmic bytes = 8*TE + 16*frontier entries, SURVEY.md §8d, divided by
+the kernel's average duration measured with HIP events on the library's own stream) and
+`cpu_baseline` (the compiled reference — oracle/_ref/libduckdb.so — or, if absent, the C oracle,
+timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+MASK64 = (1 << 64) - 1
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(vid, src, dst, gg, csr, V, total_te, want_seconds=15.0):
+    """Timed CPU path on a bounded sample (sources = first S vertices in table order).
+
+    kind "reference": the compiled reference runs the 1-hop and 2-hop join chains (count(*)) with all
+    host threads; its counts are also checked against the GPU's counts for the same source range.
+    kind "port": the C oracle's CSR formulation (OpenMP), when oracle/_ref is not present."""
+    from oracle import ref_duckdb as R
+    from tests import oracle_lib
+
+    cores = os.cpu_count() or 1
+    orc = oracle_lib.load()
+    out = {}
+    # -- C oracle over the FULL workload: parity check of the GPU result + "port" baseline
+    t = time.perf_counter()
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    t_build = time.perf_counter() - t
+    t = time.perf_counter()
+    ost = g.khop(1, 2)
+    t_khop = time.perf_counter() - t
+    port = {"value": ost["traversed_edges"] / (t_build + t_khop), "unit": "traversed edges/s",
+            "cores": orc.num_threads(), "kind": "port",
+            "sample": f"full workload: CSR build {t_build:.2f}s (1 thread) + 1..2-hop count/digest {t_khop:.2f}s (OpenMP)"}
+    out["oracle_stats"] = ost
+    g.close()
+    if not R.available():
+        out["cpu_baseline"] = port
+        return out
+    # -- the compiled reference on a bounded sample of sources
+    db = R.RefDuckDB(threads=cores)
+    t = time.perf_counter()
+    db.load_ldbc(vid, src, dst)
+    t_load = time.perf_counter() - t
+    # choose S so that the sample's TE is ~ want_seconds of reference work; calibrate on a small probe
+    probe = max(1, V // 512)
+    st_probe = gg.expand_khop_range(csr, 0, probe, 1, 2)
+    _, dt1 = db.timed(R.sql_khop(1, where_extra=f"p0.rowid < {probe}"))
+    _, dt2 = db.timed(R.sql_khop(2, where_extra=f"p0.rowid < {probe}"))
+    rate = st_probe["traversed_edges"] / max(dt1 + dt2, 1e-6)
+    frac = min(1.0, rate * want_seconds / max(total_te, 1))
+    S = max(probe, min(V, int(V * frac)))
+    gst = gg.expand_khop_range(csr, 0, S, 1, 2)
+    c1, t1 = db.timed(R.sql_khop(1, where_extra=f"p0.rowid < {S}"))
+    c2, t2 = db.timed(R.sql_khop(2, where_extra=f"p0.rowid < {S}"))
+    ok = int(c1[0, 0]) == gst["rows"][1] and int(c2[0, 0]) == gst["rows"][2]
+    db.close()
+    out["cpu_baseline"] = {
+        "value": gst["traversed_edges"] / (t1 + t2), "unit": "traversed edges/s", "cores": cores, "kind": "reference",
+        "sample": (f"reference DuckDB count(*) of the 1-hop and 2-hop join chains for the first {S} of {V} persons "
+                   f"(TE={gst['traversed_edges']}, {t1 + t2:.2f}s, hash-table builds included, table load {t_load:.1f}s excluded)"),
+        "counts_match_gpu": bool(ok),
+    }
+    out["cpu_port"] = port
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sf100", choices=["sf0.1", "sf1", "sf10", "sf100"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus={args.gpus}; using WORLD_SIZE")
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the gg hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import duckdb_pgq_amd as pkg
+
+    # ---- synthetic LDBC-shaped tables (identical on every rank), staged to HBM before timing -------
+    t0 = time.perf_counter()
+    vid, src, dst = pkg.datagen.ldbc(args.workload)
+    t_gen = time.perf_counter() - t0
+    V, R = vid.size, src.size
+    gg = pkg.GG(local_rank)
+    t0 = time.perf_counter()
+    gg.chunk_rows = 122_880  # one DuckDB row group per append (storage/table/row_group.hpp:38-39)
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    gg.staging_sync()
+    t_stage = time.perf_counter() - t0
+    if rank == 0:
+        log(f"{args.workload}: V={V} knows rows={R}; datagen {t_gen:.1f}s, staging (PCIe) {t_stage*1e3:.1f} ms")
+
+    # ---- source partition (setup, not timed) ----------------------------------------------------------
+    csr = gg.build_csr()
+    bounds = gg.khop_partition(csr, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    csr.close()
+
+    def step():
+        c = gg.build_csr()
+        st = gg.expand_khop_range(c, lo, hi, 1, 2)
+        c.close()
+        vec = [st["rows"][1], st["rows"][2], st["digest"][1], st["digest"][2], st["traversed_edges"], st["frontier_entries"]]
+        if dist is not None:
+            # counts: plain sum; digests are sums mod 2^64 -> split into 32-bit halves so int64 adds never wrap
+            parts = []
+            for x in vec:
+                parts += [x & 0xFFFFFFFF, x >> 32]
+            tns = torch.tensor(parts, dtype=torch.int64, device="cuda")
+            dist.all_reduce(tns)
+            p = tns.tolist()
+            vec = [(p[2 * i] + (p[2 * i + 1] << 32)) & MASK64 for i in range(len(vec))]
+        return vec, st
+
+    for _ in range(args.warmup):
+        step()
+    gg.profile_reset()
+    gg.profile(True)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tot, st_local = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gg.profile(False)
+    prof = gg.profile_get()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    rows1, rows2, dig1, dig2, te_total, fr_total = tot
+    ms_per_step = elapsed / args.steps * 1e3
+    value = te_total * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel on this rank ---------------------------------------------------
+    dom = "expand_fused2"
+    launches, total_ms = prof.get(dom, (0, 0.0))
+    roof = None
+    if launches:
+        avg_s = total_ms / launches * 1e-3
+        alg_bytes = 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"]
+        achieved = alg_bytes / avg_s
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}/{dom}/n{world}")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
+                "algorithmic_bytes_per_launch": alg_bytes}
+    kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0)} for k, v in prof.items()}
+
+    if rank == 0:
+        extra = {}
+        if not args.no_cpu:
+            c = gg.build_csr()
+            extra = cpu_baseline(vid, src, dst, gg, c, V, te_total, args.cpu_seconds)
+            c.close()
+            ost = extra.pop("oracle_stats")
+            parity = (ost["rows"][1] == rows1 and ost["rows"][2] == rows2 and ost["digest"][1] == dig1
+                      and ost["digest"][2] == dig2 and ost["traversed_edges"] == te_total)
+            extra["parity_vs_oracle"] = bool(parity)
+            if not parity:
+                log("PARITY FAILURE", ost, tot)
+        line = {
+            "metric": "traversed edges/sec on LDBC SNB 2-hop MATCH",
+            "value": value,
+            "unit": "traversed edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int64 ids / u32 dense indices",
+            "data": "synthetic (seeded LDBC-shaped person/knows, duckdb_pgq_amd/datagen.py)",
+            "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build + 2-hop expansion (count + digest)",
+                       "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
+                       "traversed_edges": int(te_total), "parallelism": f"source-range x{world}, CSR replicated"},
+            "roofline": roof,
+            "kernels": kernels,
+            "staging_ms_pcie": t_stage * 1e3,
+        }
+        line.update(extra)
+        if "cpu_baseline" not in line:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    gg.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
