@@ -144,13 +144,14 @@ def main():
 
     # ---- source partition (setup, not timed) ----------------------------------------------------------
     csr = gg.build_csr()
-    bounds = gg.khop_partition(csr, world)
+    bounds = gg.khop_partition_mid(csr, world)  # middle-vertex ranges of equal product work
     lo, hi = bounds[rank], bounds[rank + 1]
     csr.close()
 
     def step():
         c = gg.build_csr()
-        st = gg.expand_khop_range(c, lo, hi, 1, 2)
+        # all persons are sources; this rank owns the walks whose middle vertex is in [lo, hi)
+        st = gg.expand_khop_mid(c, lo, hi, 1, 2) if world > 1 else gg.expand_khop(c, 1, 2)
         c.close()
         vec = [st["rows"][1], st["rows"][2], st["digest"][1], st["digest"][2], st["traversed_edges"], st["frontier_entries"]]
         if dist is not None:
@@ -188,12 +189,20 @@ def main():
     value = te_total * args.steps / elapsed
 
     # ---- roofline of the dominant kernel on this rank ---------------------------------------------------
-    dom = "expand_fused2"
-    launches, total_ms = prof.get(dom, (0, 0.0))
+    # dominant kernel = largest total time in the timed region; algorithmic bytes per launch
+    E_kept = rows1 if world == 1 else R
+    alg = {
+        "expand_mid2": 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"],
+        "expand_fused2": 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"],
+        "densify_hist": 32 * R + 8 * V,          # id densification, SURVEY.md §8d
+        "radix_scatter": 32 * R,                  # per launch: read (key, payload) 16E + write 16E at int64 width
+    }
+    dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
+    launches, total_ms = prof.get(dom, (0, 0.0)) if dom else (0, 0.0)
     roof = None
     if launches:
         avg_s = total_ms / launches * 1e-3
-        alg_bytes = 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"]
+        alg_bytes = alg[dom]
         achieved = alg_bytes / avg_s
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -205,7 +214,8 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
                 "algorithmic_bytes_per_launch": alg_bytes}
-    kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0)} for k, v in prof.items()}
+    kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
+                   "us_per_step": v[1] * 1e3 / args.steps} for k, v in prof.items()}
 
     if rank == 0:
         extra = {}
@@ -234,7 +244,7 @@ def main():
             "data": "synthetic (seeded LDBC-shaped person/knows, duckdb_pgq_amd/datagen.py)",
             "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build + 2-hop expansion (count + digest)",
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
-                       "traversed_edges": int(te_total), "parallelism": f"source-range x{world}, CSR replicated"},
+                       "traversed_edges": int(te_total), "parallelism": f"middle-vertex range x{world}, CSR replicated"},
             "roofline": roof,
             "kernels": kernels,
             "staging_ms_pcie": t_stage * 1e3,

@@ -4,15 +4,20 @@
 //   PhysicalHashJoin::Finalize -> JoinHashTable::Finalize/InsertHashes
 //   (src/execution/operator/join/physical_hash_join.cpp:165-185, src/execution/join_hashtable.cpp:240-302),
 // which inserts every build row single-threaded into a chained pointer table.  Here:
-//   1. k_ht_insert      vertex ids -> open-addressing id hash table (dense index = table position)
-//   2. k_edge_densify   (src,dst) ids -> dense (u,v); drops edges with a non-vertex endpoint;
-//                       degree histogram by atomics on the (L2-resident) degree array
-//   3. scan             degree -> row offsets
-//   4. LSD radix passes stable radix-bucket scatter of (u, v, rowid) by u: per-wave digit
-//                       histograms in LDS, one global prefix scan over (digit, wave) counters, then
-//                       a wave-ordered scatter whose in-wave ranks come from __ballot match masks.
-//      Stable => inside a CSR row neighbours keep ascending edge-rowid order; the build is
-//      bit-reproducible run to run (no atomics decide a position).
+//   1. k_ht_insert       vertex ids -> open-addressing id hash table (16-byte slots, one cache line
+//                        per probe; dense index = vertex-table position)
+//   2. k_densify_hist    (src,dst) ids -> dense (u,v); edges with a non-vertex endpoint get an invalid
+//                        key; fused with the first radix pass's per-wave digit histogram (LDS)
+//   3. LSD radix passes  stable radix-bucket scatter of (u, v, edge position) by u: global prefix scan
+//                        over (digit, wave) counters, then a wave-ordered scatter whose in-wave ranks
+//                        come from __ballot match masks.  Stable => inside a CSR row neighbours keep
+//                        ascending edge-rowid (append) order; no atomic ever decides a position, so the
+//                        build is bit-reproducible.
+//   4. k_row_offsets     row offsets from the sorted source column (run boundaries) — no degree
+//                        histogram, hence no global atomics at all on the per-edge path.
+// No host synchronisation happens between the first launch and the final status read-back.
+// The reverse CSR (in-neighbour lists, needed by the 2-hop product kernel and by pull-style BFS) is
+// derived from the forward CSR's COO view by the same radix machinery (ensure_reverse).
 // All integer work, HBM-bound: algorithmic bytes 40E + 16V (with rowid).
 #include "gg_internal.h"
 
@@ -20,20 +25,27 @@ using namespace gg;
 
 namespace gg {
 
-struct BuildStatus {  // device-side status word block, copied back once per build
+struct BuildStatus {  // device-side status block, copied back once per build
   unsigned long long dup_vertex;   // !=0: duplicate vertex id seen
   long long min_idx;               // dense index of the vertex with id == HT_EMPTY, or -1
   unsigned long long kept;         // edges kept (both endpoints are vertices)
 };
 
-__global__ __launch_bounds__(256) void k_ht_init(int64_t *__restrict__ keys, uint64_t cap) {
+__global__ __launch_bounds__(256) void k_ht_init(HtSlot *__restrict__ ht, uint64_t cap) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cap) keys[i] = HT_EMPTY;
+  if (i < cap) {
+    uint4 e;
+    e.x = 0u;
+    e.y = 0x80000000u;  // key = INT64_MIN
+    e.z = INVALID_U32;
+    e.w = 0u;
+    *reinterpret_cast<uint4 *>(&ht[i]) = e;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ vid, uint64_t V,
-                                                   int64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                   uint32_t shift, uint64_t mask, BuildStatus *__restrict__ st) {
+                                                   HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
+                                                   BuildStatus *__restrict__ st) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= V) return;
   int64_t key = vid[i];
@@ -46,9 +58,9 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
   uint64_t slot = ((uint64_t)key * DIG_GOLD) >> shift;
   while (true) {
     unsigned long long prev =
-        atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+        atomicCAS((unsigned long long *)&ht[slot].key, (unsigned long long)HT_EMPTY, (unsigned long long)key);
     if (prev == (unsigned long long)HT_EMPTY) {
-      vals[slot] = (uint32_t)i;
+      ht[slot].val = (uint32_t)i;
       return;
     }
     if (prev == (unsigned long long)key) {
@@ -59,116 +71,229 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
   }
 }
 
-// One thread per edge row: two id lookups (hash table is V-sized, L2/MALL resident), degree count.
-__global__ __launch_bounds__(256) void k_edge_densify(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                      uint64_t E, const int64_t *__restrict__ keys,
-                                                      const uint32_t *__restrict__ vals, uint32_t shift, uint64_t mask,
-                                                      const BuildStatus *__restrict__ st, uint32_t *__restrict__ su,
-                                                      uint32_t *__restrict__ dv, uint32_t *__restrict__ deg) {
-  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+// ---- stable LSD radix machinery -----------------------------------------------------------------
+// One workgroup owns a tile of RB_TILE consecutive elements.  Inside the tile, wave w owns the
+// contiguous quarter [w*1024, (w+1)*1024) and walks it in order, 64 elements per step, so element
+// order is fully determined (stable).  Elements are first ranked INSIDE the tile and staged in LDS in
+// digit order, then written out: consecutive LDS slots of one digit go to consecutive global
+// addresses, so the global stores are coalesced runs instead of 4-byte scatters.
+constexpr int RB_THREADS = 256;
+constexpr int RB_WAVES = RB_THREADS / 64;
+constexpr int RB_ITEMS = 16;                       // elements per lane
+constexpr int RB_TILE = RB_THREADS * RB_ITEMS;     // 4096 elements per workgroup
+constexpr int RB_WTILE = RB_TILE / RB_WAVES;       // 1024 per wave
+constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
+
+// Densify + pass-0 histogram.  One lane per edge row: two id lookups (hash table is V-sized, L2 /
+// Infinity-Cache resident), dense endpoints written coalesced, digit counted in the tile's LDS histogram.
+// counts[digit * nblocks + block] = number of valid elements of that tile with that digit
+__global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__restrict__ src,
+                                                             const int64_t *__restrict__ dst, uint64_t E,
+                                                             const HtSlot *__restrict__ ht, uint32_t shift,
+                                                             uint64_t mask, const BuildStatus *__restrict__ st,
+                                                             uint32_t *__restrict__ su, uint32_t *__restrict__ dv,
+                                                             uint32_t bits, uint64_t nblocks,
+                                                             uint32_t *__restrict__ counts) {
+  __shared__ uint32_t hist[1 << RB_MAX_BITS];
+  const uint32_t ndig = 1u << bits;
+  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) hist[i] = 0;
+  __syncthreads();
   const int64_t min_idx = st->min_idx;
-  uint32_t u = ht_lookup(keys, vals, shift, mask, min_idx, src[e]);
-  uint32_t v = ht_lookup(keys, vals, shift, mask, min_idx, dst[e]);
-  if (u == INVALID_U32 || v == INVALID_U32) {
-    su[e] = INVALID_U32;
-    dv[e] = INVALID_U32;
-    return;
+  const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
+#pragma unroll 4
+  for (int it = 0; it < RB_ITEMS; it++) {
+    const uint64_t e = base + (uint64_t)it * RB_THREADS + threadIdx.x;
+    if (e < E) {
+      uint32_t u = ht_lookup(ht, shift, mask, min_idx, src[e]);
+      uint32_t v = ht_lookup(ht, shift, mask, min_idx, dst[e]);
+      if (u == INVALID_U32 || v == INVALID_U32) {
+        u = INVALID_U32;
+        v = INVALID_U32;
+      } else {
+        atomicAdd(&hist[u & (ndig - 1)], 1u);
+      }
+      su[e] = u;
+      dv[e] = v;
+    }
   }
-  su[e] = u;
-  dv[e] = v;
-  atomicAdd(&deg[u], 1u);
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
 }
 
-// ---- stable LSD radix pass -------------------------------------------------------------------
-// A wave owns a contiguous sub-tile of RS_WTILE elements and walks it in order, 64 at a time.
-constexpr int RS_THREADS = 256;
-constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_WTILE = 4096;          // elements per wave
-constexpr int RS_MAX_BITS = 11;         // digits <= 2048 -> 4 x 2048 x 4 B = 32 KiB LDS per block
-
-// counts[digit * nwaves + wave_global] = number of valid elements of that wave with that digit
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t *__restrict__ key, uint64_t n,
-                                                           uint32_t lo_bit, uint32_t bits, uint64_t nwaves,
+// histogram of a later pass: n comes from device memory (edges kept is only known on the device)
+__global__ __launch_bounds__(RB_THREADS) void k_radix_hist(const uint32_t *__restrict__ key,
+                                                           const unsigned long long *__restrict__ n_dev,
+                                                           uint32_t lo_bit, uint32_t bits, uint64_t nblocks,
                                                            uint32_t *__restrict__ counts) {
-  extern __shared__ uint32_t lds_hist[];  // RS_WAVES << bits
+  __shared__ uint32_t hist[1 << RB_MAX_BITS];
   const uint32_t ndig = 1u << bits;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t i = threadIdx.x; i < RS_WAVES * ndig; i += RS_THREADS) lds_hist[i] = 0;
+  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) hist[i] = 0;
   __syncthreads();
-  const uint64_t wg = (uint64_t)blockIdx.x * RS_WAVES + wave;
-  uint32_t *h = lds_hist + wave * ndig;
-  if (wg < nwaves) {
-    const uint64_t base = wg * RS_WTILE;
+  const uint64_t n = *n_dev;
+  const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
 #pragma unroll 4
-    for (int it = 0; it < RS_WTILE / 64; it++) {
-      uint64_t idx = base + (uint64_t)it * 64 + lane;
-      if (idx < n) {
-        uint32_t k = key[idx];
-        if (k != INVALID_U32) atomicAdd(&h[(k >> lo_bit) & (ndig - 1)], 1u);
+  for (int it = 0; it < RB_ITEMS; it++) {
+    const uint64_t idx = base + (uint64_t)it * RB_THREADS + threadIdx.x;
+    if (idx < n) {
+      const uint32_t k = key[idx];
+      if (k != INVALID_U32) atomicAdd(&hist[(k >> lo_bit) & (ndig - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
+}
+
+// Scatter.  `bases` is the exclusive scan of `counts` (same layout).
+//   GEN_B : payload b is the element's own position (pass 0: the edge's append position)
+//   HAS_B : a second payload column exists
+template <bool HAS_B, bool GEN_B>
+__global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
+    const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ a_in, const uint32_t *__restrict__ b_in,
+    uint64_t n_host, const unsigned long long *__restrict__ n_dev, uint32_t lo_bit, uint32_t bits, uint64_t nblocks,
+    const uint32_t *__restrict__ bases, uint32_t *__restrict__ key_out, uint32_t *__restrict__ a_out,
+    uint32_t *__restrict__ b_out) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t ndig = 1u << bits;
+  uint32_t *xk = lds;                                  // staged keys, digit order
+  uint32_t *xa = xk + RB_TILE;
+  uint32_t *xb = xa + RB_TILE;                         // only if HAS_B
+  uint32_t *hw = HAS_B ? xb + RB_TILE : xb;            // [RB_WAVES][ndig] per-wave counts -> running cursors
+  uint32_t *dbase = hw + RB_WAVES * ndig;              // [ndig] first tile slot of each digit
+  uint32_t *gb = dbase + ndig;                         // [ndig] global position of tile slot 0 of the digit, minus dbase
+  uint32_t *misc = gb + ndig;                          // [8] block-scan scratch + valid count
+
+  const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
+  const uint64_t tile_base = (uint64_t)blockIdx.x * RB_TILE;
+  if (tile_base >= n) return;  // block-uniform
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < RB_WAVES * ndig; i += RB_THREADS) hw[i] = 0;
+  __syncthreads();
+
+  // load (coalesced: 64 consecutive elements per wave step) and count per wave
+  uint32_t k[RB_ITEMS], a[RB_ITEMS], b[RB_ITEMS];
+  uint32_t *myh = hw + wave * ndig;
+  const uint64_t wbase = tile_base + (uint64_t)wave * RB_WTILE;
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++) {
+    const uint64_t idx = wbase + (uint64_t)it * 64 + lane;
+    k[it] = INVALID_U32;
+    a[it] = 0;
+    b[it] = 0;
+    if (idx < n) {
+      k[it] = key_in[idx];
+      a[it] = a_in[idx];
+      if (HAS_B) b[it] = GEN_B ? (uint32_t)idx : b_in[idx];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++)
+    if (k[it] != INVALID_U32) atomicAdd(&myh[(k[it] >> lo_bit) & (ndig - 1)], 1u);
+  __syncthreads();
+
+  // per digit: wave counts -> exclusive offsets across waves; digit totals -> exclusive scan = dbase
+  {
+    uint32_t tot = 0;
+    const uint32_t d = threadIdx.x;
+    if (d < ndig) {
+#pragma unroll
+      for (int w = 0; w < RB_WAVES; w++) {
+        const uint32_t c = hw[w * ndig + d];
+        hw[w * ndig + d] = tot;
+        tot += c;
       }
     }
+    // block exclusive scan of tot over threads (ndig <= 256 = RB_THREADS)
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) misc[wave] = incl;
+    __syncthreads();
+    uint32_t wb = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < RB_WAVES; w++) {
+      const uint32_t sv = misc[w];
+      if (w < wave) wb += sv;
+      all += sv;
+    }
+    const uint32_t ex = wb + incl - tot;
+    if (d < ndig) {
+      dbase[d] = ex;
+      gb[d] = bases[(uint64_t)d * nblocks + blockIdx.x] - ex;
+    }
+    if (threadIdx.x == 0) misc[4] = all;  // valid elements in this tile
   }
   __syncthreads();
-  if (wg < nwaves)
-    for (uint32_t d = lane; d < ndig; d += 64) counts[(uint64_t)d * nwaves + wg] = h[d];
-}
 
-// Scatter.  `bases` is the exclusive scan of `counts` (same layout).  LAST pass writes only the
-// payload (neighbour + rowid) to the CSR arrays; earlier passes also carry the key.
-template <bool LAST>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
-    const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ val_in, const int64_t *__restrict__ eid_in,
-    uint64_t n, uint32_t lo_bit, uint32_t bits, uint64_t nwaves, const uint32_t *__restrict__ bases,
-    uint32_t *__restrict__ key_out, uint32_t *__restrict__ val_out, int64_t *__restrict__ eid_out) {
-  extern __shared__ uint32_t lds_cur[];  // RS_WAVES << bits : per-wave running cursor per digit
-  const uint32_t ndig = 1u << bits;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t wg = (uint64_t)blockIdx.x * RS_WAVES + wave;
-  if (wg >= nwaves) return;  // no block-level barrier below: waves are independent
-  volatile uint32_t *cur = lds_cur + wave * ndig;
-  for (uint32_t d = lane; d < ndig; d += 64) cur[d] = bases[(uint64_t)d * nwaves + wg];
-  __builtin_amdgcn_wave_barrier();
-  const uint64_t base = wg * RS_WTILE;
+  // rank inside the tile (stable) and stage in LDS in digit order
   const uint64_t lane_lt = (1ULL << lane) - 1ULL;
-  for (int it = 0; it < RS_WTILE / 64; it++) {
-    const uint64_t idx = base + (uint64_t)it * 64 + lane;
-    if (base + (uint64_t)it * 64 >= n) break;  // wave-uniform
-    uint32_t k = INVALID_U32, v = 0;
-    int64_t r = 0;
-    if (idx < n) {
-      k = key_in[idx];
-      v = val_in[idx];
-      r = eid_in[idx];
-    }
-    const bool valid = (k != INVALID_U32);
-    const uint32_t d = (k >> lo_bit) & (ndig - 1);
-    // match mask: lanes of this wave holding the same digit (ballot per digit bit)
+  volatile uint32_t *cur = myh;
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++) {
+    const bool valid = (k[it] != INVALID_U32);
+    const uint32_t d = (k[it] >> lo_bit) & (ndig - 1);
     uint64_t m = __ballot(valid);
-    for (uint32_t b = 0; b < bits; b++) {
-      uint64_t bb = __ballot((d >> b) & 1u);
-      m &= ((d >> b) & 1u) ? bb : ~bb;
+    for (uint32_t bit = 0; bit < bits; bit++) {  // match mask: same digit within the wave
+      const uint64_t bb = __ballot((d >> bit) & 1u);
+      m &= ((d >> bit) & 1u) ? bb : ~bb;
     }
     if (valid) {
-      const uint32_t rank = __popcll(m & lane_lt);
-      const uint32_t pos = cur[d] + rank;  // all peers read the cursor before the leader bumps it
-      if (!LAST) key_out[pos] = k;
-      val_out[pos] = v;
-      eid_out[pos] = r;
+      const uint32_t pos = dbase[d] + cur[d] + __popcll(m & lane_lt);
+      xk[pos] = k[it];
+      xa[pos] = a[it];
+      if (HAS_B) xb[pos] = b[it];
     }
     __builtin_amdgcn_wave_barrier();
     if (valid && (m & lane_lt) == 0) cur[d] += __popcll(m);  // lowest lane of each digit group
     __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();
+
+  // write out: consecutive staged slots of one digit -> consecutive global positions
+  const uint32_t nvalid = misc[4];
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++) {
+    const uint32_t idx = (uint32_t)it * RB_THREADS + threadIdx.x;
+    if (idx < nvalid) {
+      const uint32_t kk = xk[idx];
+      const uint32_t pos = gb[(kk >> lo_bit) & (ndig - 1)] + idx;
+      key_out[pos] = kk;
+      a_out[pos] = xa[idx];
+      if (HAS_B) b_out[pos] = xb[idx];
+    }
+  }
 }
 
-__global__ __launch_bounds__(256) void k_set_last_offset(uint32_t *__restrict__ off, uint64_t V,
-                                                         const uint64_t *__restrict__ total,
-                                                         BuildStatus *__restrict__ st) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    off[V] = (uint32_t)*total;
-    st->kept = *total;
+// Row offsets from the sorted key column: off[u] = first position whose key >= u.
+__global__ __launch_bounds__(256) void k_row_offsets(const uint32_t *__restrict__ key, uint64_t n_host,
+                                                     const unsigned long long *__restrict__ n_dev, uint64_t V,
+                                                     uint32_t *__restrict__ off) {
+  const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) {
+    for (uint64_t u = i; u <= V; u += (uint64_t)gridDim.x * blockDim.x) off[u] = 0;
+    return;
   }
+  if (i >= n) return;
+  const uint32_t k = key[i];
+  const int64_t kp = i ? (int64_t)key[i - 1] : -1;
+  for (int64_t u = kp + 1; u <= (int64_t)k; u++) off[u] = (uint32_t)i;  // runs of empty rows are short
+  if (i == n - 1)
+    for (uint64_t u = (uint64_t)k + 1; u <= V; u++) off[u] = (uint32_t)n;
+}
+
+__global__ __launch_bounds__(64) void k_publish_kept(const uint64_t *__restrict__ total, BuildStatus *__restrict__ st) {
+  if (threadIdx.x == 0) st->kept = *total;
+}
+
+__global__ __launch_bounds__(256) void k_gather_rowid(const uint32_t *__restrict__ epos,
+                                                      const int64_t *__restrict__ rowid,
+                                                      const unsigned long long *__restrict__ n_dev,
+                                                      int64_t *__restrict__ eid) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < *n_dev) eid[i] = rowid[epos[i]];
 }
 
 }  // namespace gg
@@ -179,6 +304,90 @@ static int ceil_log2_u64(uint64_t v) {
   return b;
 }
 
+namespace {
+
+// Stable sort of (key, a[, b]) by key < 2^key_bits.  Pass 0 input is (key0, a0, b generated from the
+// position when gen_b); counts of pass 0 may already be available (fused producer) in counts0.
+// Outputs land in (key_out, a_out, b_out).  n: host bound (grid sizing); n_dev: actual count for
+// passes >= 1 (null: n is exact everywhere).  *total_dev receives the number of valid elements.
+struct RadixIO {
+  const uint32_t *key0, *a0, *b0;
+  uint32_t *key_out, *a_out, *b_out;
+};
+
+int radix_sort_stable(gg_ctx *ctx, const RadixIO &io, uint64_t n, bool has_b, bool gen_b, int key_bits,
+                      uint32_t *counts0 /* nullable: pass-0 histogram already computed */, int bits0,
+                      unsigned long long *total_dev /* nullable: where pass 0's valid count goes / comes from */,
+                      bool n_exact) {
+  if (n == 0) return GG_OK;
+  int passes = (key_bits + RB_MAX_BITS - 1) / RB_MAX_BITS;
+  if (passes < 1) passes = 1;
+  int bits_per = counts0 ? bits0 : (key_bits + passes - 1) / passes;
+  if (bits_per < 1) bits_per = 1;
+  uint32_t *kbuf[2] = {nullptr, nullptr}, *abuf[2] = {nullptr, nullptr}, *bbuf[2] = {nullptr, nullptr};
+  const int nbuf = passes > 2 ? 2 : (passes > 1 ? 1 : 0);
+  for (int i = 0; i < nbuf; i++) {
+    GG_TRY(ctx->dev_alloc((void **)&kbuf[i], n * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&abuf[i], n * sizeof(uint32_t)));
+    if (has_b) GG_TRY(ctx->dev_alloc((void **)&bbuf[i], n * sizeof(uint32_t)));
+  }
+  unsigned long long *own_total = nullptr;
+  if (!total_dev) {
+    GG_TRY(ctx->dev_alloc((void **)&own_total, sizeof(unsigned long long)));
+    total_dev = own_total;
+  }
+  const uint32_t *kin = io.key0, *ain = io.a0, *bin = io.b0;
+  const uint64_t nblocks64 = (n + RB_TILE - 1) / RB_TILE;
+  const unsigned nblocks = (unsigned)nblocks64;
+  for (int p = 0; p < passes; p++) {
+    const bool last = (p == passes - 1);
+    const uint32_t lo_bit = (uint32_t)(p * bits_per);
+    int rem = key_bits - (int)lo_bit;
+    const uint32_t bits = (uint32_t)(rem < bits_per ? (rem < 1 ? 1 : rem) : bits_per);
+    const uint32_t ndig = 1u << bits;
+    const size_t lds = ((size_t)RB_TILE * (has_b ? 3 : 2) + (size_t)(RB_WAVES + 2) * ndig + 8) * sizeof(uint32_t);
+    const uint64_t ncount = (uint64_t)ndig * nblocks64;
+    uint32_t *counts = nullptr;
+    if (p == 0 && counts0) {
+      counts = counts0;
+    } else {
+      GG_TRY(ctx->dev_alloc((void **)&counts, ncount * sizeof(uint32_t)));
+      // passes >= 1 see only the valid elements; pass 0 without a fused producer sees n (exact)
+      GG_LAUNCH(ctx, "radix_hist", k_radix_hist, dim3(nblocks), dim3(RB_THREADS), 0, kin,
+                (const unsigned long long *)total_dev, lo_bit, bits, nblocks64, counts);
+    }
+    // pass 0's scan total is the number of valid elements = n for every later pass
+    GG_TRY(scan_exclusive_u32(ctx, counts, counts, ncount, p == 0 ? (uint64_t *)total_dev : nullptr));
+    uint32_t *kout = last ? io.key_out : kbuf[p & 1];
+    uint32_t *aout = last ? io.a_out : abuf[p & 1];
+    uint32_t *bout = last ? io.b_out : bbuf[p & 1];
+    const unsigned long long *nd = (p == 0) ? nullptr : total_dev;
+    if (has_b && gen_b && p == 0)
+      GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true, true>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
+                bin, n, nd, lo_bit, bits, nblocks64, counts, kout, aout, bout);
+    else if (has_b)
+      GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true, false>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
+                bin, n, nd, lo_bit, bits, nblocks64, counts, kout, aout, bout);
+    else
+      GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<false, false>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
+                bin, n, nd, lo_bit, bits, nblocks64, counts, kout, aout, bout);
+    if (!(p == 0 && counts0)) ctx->dev_free(counts);
+    kin = kout;
+    ain = aout;
+    bin = bout;
+  }
+  (void)n_exact;
+  for (int i = 0; i < 2; i++) {
+    ctx->dev_free(kbuf[i]);
+    ctx->dev_free(abuf[i]);
+    ctx->dev_free(bbuf[i]);
+  }
+  if (own_total) ctx->dev_free(own_total);
+  return GG_OK;
+}
+
+}  // namespace
+
 extern "C" void gg_csr_destroy(gg_csr *csr) {
   if (!csr) return;
   gg_ctx *ctx = csr->ctx;
@@ -187,10 +396,13 @@ extern "C" void gg_csr_destroy(gg_csr *csr) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->dev_free(csr->off);
     ctx->dev_free(csr->nbr);
+    ctx->dev_free(csr->row);
+    ctx->dev_free(csr->epos);
     ctx->dev_free(csr->eid);
     ctx->dev_free(csr->vid);
-    ctx->dev_free(csr->ht_keys);
-    ctx->dev_free(csr->ht_vals);
+    ctx->dev_free(csr->ht);
+    ctx->dev_free(csr->roff);
+    ctx->dev_free(csr->rnbr);
   }
   delete csr;
 }
@@ -206,6 +418,7 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
   gg_csr *csr = new gg_csr();
   csr->ctx = ctx;
   csr->V = V;
+  csr->E_cap = E;
   struct Guard {  // frees the half-built CSR on any early return
     gg_csr *c;
     bool armed = true;
@@ -218,117 +431,106 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
   int lg = ceil_log2_u64(V * 2 < 1024 ? 1024 : V * 2);
   csr->ht_cap = 1ULL << lg;
   csr->ht_shift = 64 - lg;
-  GG_TRY(ctx->dev_alloc((void **)&csr->ht_keys, csr->ht_cap * sizeof(int64_t)));
-  GG_TRY(ctx->dev_alloc((void **)&csr->ht_vals, csr->ht_cap * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->ht, csr->ht_cap * sizeof(HtSlot)));
   GG_TRY(ctx->dev_alloc((void **)&csr->vid, (V ? V : 1) * sizeof(int64_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->off, (V + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->nbr, (E ? E : 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->row, (E ? E : 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->epos, (E ? E : 1) * sizeof(uint32_t)));
   BuildStatus *st = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&st, sizeof(BuildStatus)));
   BuildStatus init{0ULL, -1LL, 0ULL};
   memcpy(ctx->pin_scratch, &init, sizeof(init));
   GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch, sizeof(init), hipMemcpyHostToDevice, s));
   if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-  GG_LAUNCH(ctx, "ht_init", k_ht_init, dim3((unsigned)((csr->ht_cap + 255) / 256)), dim3(256), 0, csr->ht_keys,
+  GG_LAUNCH(ctx, "ht_init", k_ht_init, dim3((unsigned)((csr->ht_cap + 255) / 256)), dim3(256), 0, csr->ht,
             csr->ht_cap);
   if (V)
-    GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V,
-              csr->ht_keys, csr->ht_vals, csr->ht_shift, csr->ht_cap - 1, st);
+    GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
+              csr->ht_shift, csr->ht_cap - 1, st);
 
-  // ---- densify + degree histogram ----------------------------------------------------------
-  uint32_t *su = nullptr, *dv = nullptr, *deg = nullptr;
-  uint64_t *total = nullptr;
-  GG_TRY(ctx->dev_alloc((void **)&su, (E ? E : 1) * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&dv, (E ? E : 1) * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&deg, (V + 1) * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&total, sizeof(uint64_t)));
-  GG_HIP(hipMemsetAsync(deg, 0, (V + 1) * sizeof(uint32_t), s));
-  if (E)
-    GG_LAUNCH(ctx, "edge_densify", k_edge_densify, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, csr->ht_keys, csr->ht_vals, csr->ht_shift, csr->ht_cap - 1, st, su, dv, deg);
+  unsigned long long *kept_dev = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
+  GG_HIP(hipMemsetAsync(kept_dev, 0, sizeof(unsigned long long), s));
+  if (E) {
+    // ---- densify + fused pass-0 histogram --------------------------------------------------------
+    const int key_bits = ceil_log2_u64(V < 2 ? 2 : V);
+    const int passes = (key_bits + RB_MAX_BITS - 1) / RB_MAX_BITS;
+    const int bits0 = (key_bits + passes - 1) / passes;
+    const uint64_t nblocks64 = (E + RB_TILE - 1) / RB_TILE;
+    const unsigned nblocks = (unsigned)nblocks64;
+    uint32_t *su = nullptr, *dv = nullptr, *counts0 = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&su, E * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&dv, E * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&counts0, (uint64_t)(1u << bits0) * nblocks64 * sizeof(uint32_t)));
+    GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
+              ctx->c_dst.dev, E, csr->ht, csr->ht_shift, csr->ht_cap - 1, st, su, dv, (uint32_t)bits0, nblocks64,
+              counts0);
+    // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
+    RadixIO io{su, dv, nullptr, csr->row, csr->nbr, csr->epos};
+    GG_TRY(radix_sort_stable(ctx, io, E, true, true, key_bits, counts0, bits0, kept_dev, false));
+    ctx->dev_free(counts0);
+    ctx->dev_free(su);
+    ctx->dev_free(dv);
+  }
+  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, csr->row,
+            (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
+  GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev, st);
+  if (ctx->rowid_explicit && E) {
+    GG_TRY(ctx->dev_alloc((void **)&csr->eid, E * sizeof(int64_t)));
+    GG_LAUNCH(ctx, "gather_rowid", k_gather_rowid, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, csr->epos,
+              ctx->c_rowid.dev, (const unsigned long long *)kept_dev, csr->eid);
+  }
 
-  // ---- offsets ------------------------------------------------------------------------------
-  GG_TRY(scan_exclusive_u32(ctx, deg, csr->off, V, total));
-  GG_LAUNCH(ctx, "set_last_offset", k_set_last_offset, dim3(1), dim3(64), 0, csr->off, V, total, st);
-
-  // status back to the host: duplicate check, sentinel vertex, kept-edge count
+  // status back to the host (the only synchronisation of the build): duplicate check, sentinel
+  // vertex, kept-edge count
   GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, s));
   GG_HIP(hipStreamSynchronize(s));
   BuildStatus hs;
   memcpy(&hs, ctx->pin_scratch, sizeof(hs));
   ctx->dev_free(st);
-  ctx->dev_free(deg);
-  ctx->dev_free(total);
+  ctx->dev_free(kept_dev);
   if (hs.dup_vertex) {
-    ctx->dev_free(su);
-    ctx->dev_free(dv);
     set_error("vertex key column is not unique (duplicate vertex id)");
     return GG_ERR_DUPLICATE_VERTEX;
   }
   csr->ht_min_idx = hs.min_idx;
   csr->E = hs.kept;
   csr->dropped = E - hs.kept;
-
-  GG_TRY(ctx->dev_alloc((void **)&csr->nbr, (csr->E ? csr->E : 1) * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&csr->eid, (csr->E ? csr->E : 1) * sizeof(int64_t)));
-
-  // ---- stable LSD radix scatter by source ------------------------------------------------------
-  if (E && csr->E) {
-    int key_bits = ceil_log2_u64(V < 2 ? 2 : V);
-    int passes = (key_bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
-    int bits_per = (key_bits + passes - 1) / passes;
-    uint32_t *kbuf[2] = {nullptr, nullptr}, *vbuf[2] = {nullptr, nullptr};
-    int64_t *ebuf[2] = {nullptr, nullptr};
-    if (passes > 1) {
-      for (int i = 0; i < (passes > 2 ? 2 : 1); i++) {
-        GG_TRY(ctx->dev_alloc((void **)&kbuf[i], csr->E * sizeof(uint32_t)));
-        GG_TRY(ctx->dev_alloc((void **)&vbuf[i], csr->E * sizeof(uint32_t)));
-        GG_TRY(ctx->dev_alloc((void **)&ebuf[i], csr->E * sizeof(int64_t)));
-      }
-    }
-    const uint32_t *kin = su, *vin = dv;
-    const int64_t *ein = ctx->c_rowid.dev;
-    uint64_t n_in = E;  // pass 0 reads all staged rows (and drops invalid ones); later passes read E_kept
-    for (int p = 0; p < passes; p++) {
-      const bool last = (p == passes - 1);
-      const uint32_t lo_bit = (uint32_t)(p * bits_per);
-      const uint32_t bits = (uint32_t)((key_bits - (int)lo_bit) < bits_per ? (key_bits - (int)lo_bit) : bits_per);
-      const uint64_t nwaves = (n_in + RS_WTILE - 1) / RS_WTILE;
-      const unsigned nblocks = (unsigned)((nwaves + RS_WAVES - 1) / RS_WAVES);
-      const size_t lds = (size_t)RS_WAVES * (1u << bits) * sizeof(uint32_t);
-      const uint64_t ncount = (uint64_t)(1u << bits) * nwaves;
-      uint32_t *counts = nullptr;
-      GG_TRY(ctx->dev_alloc((void **)&counts, ncount * sizeof(uint32_t)));
-      GG_LAUNCH(ctx, "radix_hist", k_radix_hist, dim3(nblocks), dim3(RS_THREADS), lds, kin, n_in, lo_bit, bits,
-                nwaves, counts);
-      GG_TRY(scan_exclusive_u32(ctx, counts, counts, ncount, nullptr));
-      uint32_t *kout = last ? nullptr : kbuf[p & 1];
-      uint32_t *vout = last ? csr->nbr : vbuf[p & 1];
-      int64_t *eout = last ? csr->eid : ebuf[p & 1];
-      if (last)
-        GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true>), dim3(nblocks), dim3(RS_THREADS), lds, kin, vin, ein,
-                  n_in, lo_bit, bits, nwaves, counts, kout, vout, eout);
-      else
-        GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<false>), dim3(nblocks), dim3(RS_THREADS), lds, kin, vin, ein,
-                  n_in, lo_bit, bits, nwaves, counts, kout, vout, eout);
-      ctx->dev_free(counts);
-      kin = kout;
-      vin = vout;
-      ein = eout;
-      n_in = csr->E;
-    }
-    for (int i = 0; i < 2; i++) {
-      ctx->dev_free(kbuf[i]);
-      ctx->dev_free(vbuf[i]);
-      ctx->dev_free(ebuf[i]);
-    }
-  }
-  ctx->dev_free(su);
-  ctx->dev_free(dv);
-  GG_HIP(hipStreamSynchronize(s));
   guard.armed = false;
   *out = csr;
   return GG_OK;
 }
+
+namespace gg {
+
+// Reverse CSR from the forward COO view (row, nbr), which is sorted by (source, rowid): a stable sort
+// by destination leaves every in-neighbour list in ascending (source, rowid) order.
+int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
+  if (csr->roff) return GG_OK;
+  const uint64_t V = csr->V, E = csr->E;
+  uint32_t *rkey = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&csr->roff, (V + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->rnbr, (E ? E : 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&rkey, (E ? E : 1) * sizeof(uint32_t)));
+  if (E) {
+    const int key_bits = ceil_log2_u64(V < 2 ? 2 : V);
+    RadixIO io{csr->nbr, csr->row, nullptr, rkey, csr->rnbr, nullptr};
+    // pass 0 needs a device-side n for its histogram: reuse total slot seeded with E
+    unsigned long long *tot = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(unsigned long long)));
+    const unsigned long long e_host = E;  // pageable source: staged by the runtime before the call returns
+    GG_HIP(hipMemcpyAsync(tot, &e_host, sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    GG_TRY(radix_sort_stable(ctx, io, E, false, false, key_bits, nullptr, 0, tot, true));
+    ctx->dev_free(tot);
+  }
+  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, rkey, E,
+            (const unsigned long long *)nullptr, V, csr->roff);
+  ctx->dev_free(rkey);
+  return GG_OK;
+}
+
+}  // namespace gg
 
 extern "C" int gg_csr_info(const gg_csr *csr, uint64_t *n_vertices, uint64_t *n_edges_kept,
                            uint64_t *n_edges_dropped) {
@@ -354,7 +556,15 @@ extern "C" int gg_csr_export(const gg_csr *csr, int64_t *off, int64_t *nbr, int6
     GG_HIP(hipMemcpy(h.data(), csr->nbr, csr->E * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < csr->E; i++) nbr[i] = (int64_t)h[i];
   }
-  if (eid && csr->E) GG_HIP(hipMemcpy(eid, csr->eid, csr->E * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (eid && csr->E) {
+    if (csr->eid) {
+      GG_HIP(hipMemcpy(eid, csr->eid, csr->E * sizeof(int64_t), hipMemcpyDeviceToHost));
+    } else {  // implicit rowids: the edge's append position
+      std::vector<uint32_t> h(csr->E);
+      GG_HIP(hipMemcpy(h.data(), csr->epos, csr->E * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      for (uint64_t i = 0; i < csr->E; i++) eid[i] = (int64_t)h[i];
+    }
+  }
   if (vid && csr->V) GG_HIP(hipMemcpy(vid, csr->vid, csr->V * sizeof(int64_t), hipMemcpyDeviceToHost));
   return GG_OK;
 }

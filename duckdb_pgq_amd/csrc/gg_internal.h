@@ -49,6 +49,12 @@ struct ProfRec {
   hipEvent_t start, stop;
 };
 
+struct alignas(16) HtSlot {
+  int64_t key;
+  uint32_t val;
+  uint32_t pad;
+};
+
 struct Column {
   int64_t *dev = nullptr;
   size_t cap = 0;  // rows
@@ -65,6 +71,7 @@ struct gg_ctx {
   std::mutex mu;
   gg::Column c_vid, c_src, c_dst, c_rowid;
   uint64_t n_vertices = 0, n_edges = 0;          // rows resident or in flight to the device
+  bool rowid_explicit = false;                   // some append passed explicit rowids
   static constexpr size_t STAGE_ROWS = 1u << 20; // rows per pinned staging block
   int64_t *pin_v[2] = {nullptr, nullptr};        // vertex ids
   int64_t *pin_e[2] = {nullptr, nullptr};        // edge block: [src | dst | rowid] each STAGE_ROWS
@@ -77,6 +84,7 @@ struct gg_ctx {
   size_t bytes_allocated = 0;
 
   // ---- profiling ----
+  bool force_frontier = false;  // gg_debug_force_frontier
   bool profiling = false;
   std::vector<std::string> prof_names;
   std::vector<uint64_t> prof_launches;
@@ -96,15 +104,21 @@ struct gg_ctx {
 struct gg_csr {
   gg_ctx *ctx = nullptr;
   uint64_t V = 0, E = 0, dropped = 0;
-  uint32_t *off = nullptr;   // V+1
-  uint32_t *nbr = nullptr;   // E dense neighbour indices
-  int64_t *eid = nullptr;    // E edge rowids
-  int64_t *vid = nullptr;    // V vertex ids by dense index
-  int64_t *ht_keys = nullptr;  // id hash table (open addressing)
-  uint32_t *ht_vals = nullptr;
-  uint32_t ht_shift = 0;     // slot = (key * GOLD) >> ht_shift
+  uint64_t E_cap = 0;          // allocation size of the per-edge arrays (= staged edge rows)
+  uint32_t *off = nullptr;     // V+1 row offsets
+  uint32_t *nbr = nullptr;     // E   dense neighbour (destination) per entry
+  uint32_t *row = nullptr;     // E   dense source per entry (COO view, sorted by source)
+  uint32_t *epos = nullptr;    // E   append position of the edge row (implicit rowid)
+  int64_t *eid = nullptr;      // E   explicit edge rowids (only if the Sink passed rowids), else null
+  int64_t *vid = nullptr;      // V   vertex ids by dense index
+  gg::HtSlot *ht = nullptr;    // id hash table (open addressing, 16-byte slots: one line per probe)
+  uint32_t ht_shift = 0;       // slot = (key * GOLD) >> ht_shift
   uint64_t ht_cap = 0;
-  int64_t ht_min_idx = -1;   // dense index of the vertex whose id == HT_EMPTY, if any
+  int64_t ht_min_idx = -1;     // dense index of the vertex whose id == HT_EMPTY, if any
+  // reverse CSR (in-neighbours), built lazily by ensure_reverse(): row x lists the sources u of
+  // every edge u->x in ascending (u, rowid) order
+  uint32_t *roff = nullptr;    // V+1
+  uint32_t *rnbr = nullptr;    // E
 };
 
 struct gg_result {
@@ -133,6 +147,8 @@ int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t 
 
 // id -> dense lookup of n host ids; writes dense (uint32, INVALID_U32 if absent) to out_dev
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev);
+// build csr->roff / csr->rnbr if absent (gg_csr.hip)
+int ensure_reverse(gg_ctx *ctx, gg_csr *csr);
 
 __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   x ^= x >> 33;
@@ -147,13 +163,15 @@ __device__ __forceinline__ uint64_t dig_leaf(uint64_t q, uint32_t d) {
   return q ^ ((uint64_t)d * (uint64_t)DIG_K32);  // one v_mad_u64_u32
 }
 
-__device__ __forceinline__ uint32_t ht_lookup(const int64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                              uint32_t shift, uint64_t mask, int64_t min_idx, int64_t key) {
+__device__ __forceinline__ uint32_t ht_lookup(const HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
+                                              int64_t min_idx, int64_t key) {
   if (key == HT_EMPTY) return min_idx >= 0 ? (uint32_t)min_idx : INVALID_U32;
   uint64_t slot = ((uint64_t)key * DIG_GOLD) >> shift;
   while (true) {
-    int64_t k = keys[slot];
-    if (k == key) return vals[slot];
+    // one 16-byte load per probe: key and value share a cache line
+    const uint4 raw = *reinterpret_cast<const uint4 *>(&ht[slot]);
+    const int64_t k = (int64_t)(((uint64_t)raw.y << 32) | raw.x);
+    if (k == key) return raw.z;
     if (k == HT_EMPTY) return INVALID_U32;
     slot = (slot + 1) & mask;
   }

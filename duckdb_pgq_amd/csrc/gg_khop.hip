@@ -236,6 +236,136 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
   block_store_partials(0, sum, 0, s_red, partial);
 }
 
+
+// ---- 2-hop as a join product around the middle vertex ---------------------------------------------
+// Every 2-hop walk u -> x -> w is one pair (in-edge of x, out-edge of x): the walks through x are the
+// cartesian product in(x) x out(x) — exactly what the reference's second hash join emits when a probe
+// key matches a chain of build rows (join_hashtable.cpp:442-476).  Reading CSR row x once per walk (the
+// frontier formulation above) therefore re-reads it |in(x)| times.  Here a tile of 256 consecutive
+// REVERSE-CSR entries (= 1-hop rows u->x, grouped by x) is staged in LDS as hash states; for each run
+// of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced) and every
+// staged state of the run is folded against it (LDS broadcast read + 4 VALU ops per walk).  The kernel
+// is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
+constexpr int MID_R = 4;  // out-row values per lane per J-block: a J-block covers 64*MID_R = 256 leaves
+
+template <int NREG, bool FULL>
+__device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int ib, const uint64_t (&t)[MID_R],
+                                               const bool (&ok)[MID_R], uint64_t (&acc)[MID_R]) {
+#pragma unroll 4
+  for (int i = ia; i < ib; i++) {
+    const uint64_t q = s_q[i];  // wave-uniform address: LDS broadcast
+#pragma unroll
+    for (int r = 0; r < NREG; r++) {
+      if (FULL || ok[r]) acc[r] += q ^ t[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                    const uint32_t *__restrict__ roff /* + mid_lo */,
+                                                    const uint32_t *__restrict__ rnbr, uint64_t n_mid, uint32_t mid_lo,
+                                                    uint64_t M, const uint32_t *__restrict__ tile_entry,
+                                                    int emit_mid, unsigned long long *__restrict__ partial) {
+  __shared__ uint64_t s_foff[XT + 1];
+  __shared__ uint64_t s_q[XT];
+  __shared__ uint32_t s_x[XT];
+  __shared__ uint32_t s_run[XT + 1];  // tile position where each run of equal x starts (+ end sentinel)
+  __shared__ uint32_t s_wcnt[XT / 64];
+  __shared__ uint64_t s_red[12];
+
+  const uint64_t fbase = (uint64_t)roff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, roff, n_mid, i0);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool valid = p < fbase + M;
+  uint64_t mid_sum = 0, rows_last = 0;
+  uint32_t x = INVALID_U32;
+  if (valid) {
+    uint64_t k;
+    const uint64_t i = locate_entry(s_foff, roff, n_mid, i0, p, &k);
+    x = mid_lo + (uint32_t)i;
+    const uint32_t u = rnbr[p];
+    const uint64_t P = dig_leaf(dig_q((uint64_t)u, 0), x);
+    if (emit_mid) mid_sum = P;
+    s_q[threadIdx.x] = dig_q(P, 1);
+    rows_last = (uint64_t)(off[x + 1] - off[x]);
+  }
+  s_x[threadIdx.x] = x;
+  __syncthreads();
+
+  // run heads -> compact list of run start positions (ballot + popcount, wave bases through LDS)
+  const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
+  const uint64_t hm = __ballot(head);
+  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
+  __syncthreads();
+  uint32_t hbase = 0, nruns = 0;
+#pragma unroll
+  for (int w = 0; w < XT / 64; w++) {
+    if (w < wave) hbase += s_wcnt[w];
+    nruns += s_wcnt[w];
+  }
+  if (head) s_run[hbase + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
+  const uint64_t remaining = fbase + M - (fbase + (uint64_t)blockIdx.x * XT);
+  const uint32_t n_valid = remaining < XT ? (uint32_t)remaining : XT;
+  if (threadIdx.x == 0) s_run[nruns] = n_valid;
+  __syncthreads();
+
+  uint64_t acc[MID_R];
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) acc[r] = 0;
+
+  for (uint32_t rr = 0; rr < nruns; rr++) {
+    const int a = (int)s_run[rr], b = (int)s_run[rr + 1];
+    const uint32_t xr = s_x[a];
+    const uint32_t st = off[xr];
+    const uint32_t dout = off[xr + 1] - st;
+    if (dout == 0) continue;
+    const uint32_t *__restrict__ row = nbr + st;
+    const int len = b - a;
+    const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
+    // long runs: every wave takes a slice of the run (i-split) and walks all J-blocks;
+    // short runs: whole run per wave, J-blocks dealt round-robin (rotated by run so waves share load)
+    const bool isplit = len >= 16;
+    const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
+    const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : b;
+    for (uint32_t jb = 0; jb < nJ; jb++) {
+      if (!isplit && ((jb + rr) & (XT / 64 - 1)) != (uint32_t)wave) continue;
+      const uint32_t base = jb * 64 * MID_R;
+      const uint32_t rem = dout - base;
+      uint64_t t[MID_R];
+      bool ok[MID_R];
+#pragma unroll
+      for (int r = 0; r < MID_R; r++) {
+        const uint32_t j = base + r * 64 + lane;
+        ok[r] = j < dout;
+        t[r] = ok[r] ? (uint64_t)row[j] * (uint64_t)DIG_K32 : 0ULL;
+      }
+      if (rem >= 64 * MID_R)
+        mid_accumulate<MID_R, true>(s_q, ia, ib, t, ok, acc);
+      else if (rem > 128)
+        mid_accumulate<MID_R, false>(s_q, ia, ib, t, ok, acc);
+      else if (rem > 64)
+        mid_accumulate<2, false>(s_q, ia, ib, t, ok, acc);
+      else
+        mid_accumulate<1, false>(s_q, ia, ib, t, ok, acc);
+    }
+  }
+  uint64_t total = 0;
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) total += acc[r];
+  block_store_partials(mid_sum, total, rows_last, s_red, partial);
+}
+
+// per-vertex work of the product kernel: in-degree x (1 + out-degree)
+__global__ __launch_bounds__(256) void k_mid_work(const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
+                                                  uint64_t V, uint64_t *__restrict__ work) {
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < V) work[x] = 1 + (uint64_t)(roff[x + 1] - roff[x]) * (1 + (uint64_t)(off[x + 1] - off[x]));
+}
+
 // sum partial[b*4 + c] over b -> out[c]  (c < 3)
 __global__ __launch_bounds__(256) void k_reduce_partials(const unsigned long long *__restrict__ partial,
                                                          uint64_t nblocks, unsigned long long *__restrict__ out) {
@@ -546,6 +676,54 @@ int khop_count(gg_ctx *ctx, const gg_csr *csr, bool ident, uint32_t lo, uint64_t
   return GG_OK;
 }
 
+
+// 2-hop count + digest through the product kernel for middle vertices [mid_lo, mid_hi)
+int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, gg_khop_stats *st) {
+  memset(st, 0, sizeof(*st));
+  GG_TRY(ensure_reverse(ctx, csr));
+  const uint64_t n_mid = mid_hi - mid_lo;
+  uint64_t M = csr->E;
+  if (!(mid_lo == 0 && mid_hi == csr->V)) {
+    uint32_t ends[2] = {0, 0};
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, csr->roff + mid_lo, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch + 1, csr->roff + mid_hi, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(&ends[0], ctx->pin_scratch, sizeof(uint32_t));
+    memcpy(&ends[1], ctx->pin_scratch + 1, sizeof(uint32_t));
+    M = (uint64_t)ends[1] - ends[0];
+  }
+  uint64_t rows2 = 0, dig1 = 0, dig2 = 0;
+  if (M) {
+    uint32_t *tile_entry = nullptr;
+    uint64_t n_tiles = 0;
+    unsigned long long *partial = nullptr, *tmp = nullptr;
+    GG_TRY(make_tiles<uint32_t>(ctx, csr->roff + mid_lo, n_mid, M, &tile_entry, &n_tiles));
+    GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+    GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
+    GG_LAUNCH(ctx, "expand_mid2", k_expand_mid2, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
+              csr->roff + mid_lo, csr->rnbr, n_mid, (uint32_t)mid_lo, M, tile_entry, (int)(k_min <= 1), partial);
+    GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    dig1 = ctx->pin_scratch[0];
+    dig2 = ctx->pin_scratch[1];
+    rows2 = ctx->pin_scratch[2];
+    ctx->dev_free(tmp);
+    ctx->dev_free(partial);
+    ctx->dev_free(tile_entry);
+  }
+  if (k_min <= 1) {
+    st->rows[1] = M;
+    st->digest[1] = dig1;
+  }
+  st->rows[2] = rows2;
+  st->digest[2] = dig2;
+  st->traversed_edges = M + rows2;
+  st->frontier_entries = n_mid + M;
+  return GG_OK;
+}
+
 // materialise walks as int64 id columns (correctness config; level-by-level)
 int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64_t n0, int k_min, int k_max,
                      gg_result *res) {
@@ -663,7 +841,12 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
     memcpy(&ends[1], ctx->pin_scratch + 1, sizeof(uint32_t));
     M1 = (uint64_t)ends[1] - ends[0];
   }
-  GG_TRY(khop_count(ctx, csr, true, (uint32_t)src_lo, n0, M1, DevFrontier(), k_min, k_max, stats));
+  if (k_max == 2 && src_lo == 0 && src_hi == csr->V && !ctx->force_frontier) {
+    // every vertex is a source: the 2-hop walks are the per-vertex products in(x) x out(x)
+    GG_TRY(khop_count_mid(ctx, const_cast<gg_csr *>(csr), 0, csr->V, k_min, stats));
+  } else {
+    GG_TRY(khop_count(ctx, csr, true, (uint32_t)src_lo, n0, M1, DevFrontier(), k_min, k_max, stats));
+  }
   if (materialise) {
     gg_result *res = new gg_result();
     res->ctx = ctx;
@@ -766,6 +949,55 @@ extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, ui
   for (int i = 1; i < n_parts; i++) {
     uint64_t target = (uint64_t)((__uint128_t)total * (unsigned)i / (unsigned)n_parts);
     uint64_t lo = 0, hi = V;  // first vertex whose exclusive prefix >= target
+    while (lo < hi) {
+      uint64_t mid = (lo + hi) >> 1;
+      if (h[mid] < target)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    bounds[i] = lo;
+  }
+  return GG_OK;
+}
+
+
+extern "C" int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, int k_max,
+                                  gg_khop_stats *stats) {
+  GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
+  if (k_max != 2) {
+    set_error("gg_expand_khop_mid: only k_max == 2 is supported (got %d)", k_max);
+    return GG_ERR_INVALID_ARG;
+  }
+  if (mid_hi > csr->V) mid_hi = csr->V;
+  if (mid_lo > mid_hi) mid_lo = mid_hi;
+  GG_HIP(hipSetDevice(ctx->device));
+  return khop_count_mid(ctx, csr, mid_lo, mid_hi, k_min, stats);
+}
+
+extern "C" int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds) {
+  if (!ctx || !csr || n_parts < 1 || !bounds) return GG_ERR_INVALID_ARG;
+  GG_HIP(hipSetDevice(ctx->device));
+  const uint64_t V = csr->V;
+  bounds[0] = 0;
+  bounds[n_parts] = V;
+  if (V == 0 || n_parts == 1) {
+    for (int i = 1; i < n_parts; i++) bounds[i] = V;
+    return GG_OK;
+  }
+  GG_TRY(ensure_reverse(ctx, csr));
+  uint64_t *work = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&work, (V + 1) * sizeof(uint64_t)));
+  GG_LAUNCH(ctx, "mid_work", k_mid_work, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->off, csr->roff, V,
+            work);
+  uint64_t total = 0;
+  GG_TRY(offsets_from_deg(ctx, work, V, &total));
+  std::vector<uint64_t> h(V + 1);
+  GG_HIP(hipMemcpy(h.data(), work, (V + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  ctx->dev_free(work);
+  for (int i = 1; i < n_parts; i++) {
+    uint64_t target = (uint64_t)((__uint128_t)total * (unsigned)i / (unsigned)n_parts);
+    uint64_t lo = 0, hi = V;
     while (lo < hi) {
       uint64_t mid = (lo + hi) >> 1;
       if (h[mid] < target)

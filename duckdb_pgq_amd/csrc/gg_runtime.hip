@@ -124,6 +124,12 @@ int gg_ctx::prof_flush() {
   return GG_OK;
 }
 
+extern "C" int gg_debug_force_frontier(gg_ctx *ctx, int on) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  ctx->force_frontier = on != 0;
+  return GG_OK;
+}
+
 extern "C" int gg_profile_enable(gg_ctx *ctx, int on) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   GG_TRY(ctx->prof_flush());
@@ -302,6 +308,7 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
     if (rowid) {
       memcpy(blk + 2 * S + ctx->fill_e, rowid, take * sizeof(int64_t));
       rowid += take;
+      ctx->rowid_explicit = true;
     } else {
       int64_t base = (int64_t)ctx->n_edges;
       int64_t *r = blk + 2 * S + ctx->fill_e;
@@ -342,6 +349,7 @@ extern "C" int gg_staging_clear(gg_ctx *ctx) {
   GG_HIP(hipStreamSynchronize(ctx->stream));
   ctx->n_vertices = ctx->n_edges = 0;
   ctx->fill_v = ctx->fill_e = 0;
+  ctx->rowid_explicit = false;
   return GG_OK;
 }
 
@@ -468,17 +476,16 @@ int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t 
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lookup_ids(const int64_t *__restrict__ ids, uint64_t n,
-                                                    const int64_t *__restrict__ keys,
-                                                    const uint32_t *__restrict__ vals, uint32_t shift, uint64_t mask,
+                                                    const HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
                                                     int64_t min_idx, uint32_t *__restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = ht_lookup(keys, vals, shift, mask, min_idx, ids[i]);
+  if (i < n) out[i] = ht_lookup(ht, shift, mask, min_idx, ids[i]);
 }
 
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev) {
   if (n == 0) return GG_OK;
   GG_LAUNCH(ctx, "lookup_ids", k_lookup_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids_dev, n,
-            csr->ht_keys, csr->ht_vals, csr->ht_shift, csr->ht_cap - 1, csr->ht_min_idx, out_dev);
+            csr->ht, csr->ht_shift, csr->ht_cap - 1, csr->ht_min_idx, out_dev);
   return GG_OK;
 }
 

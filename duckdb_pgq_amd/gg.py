@@ -17,7 +17,8 @@ SYMBOLS = [
     "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
     "gg_csr_build", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
-    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition",
+    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
+    "gg_debug_force_frontier",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy",
     "gg_bfs64",
     "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
@@ -83,6 +84,9 @@ def load_library(path: str | None = None):
     lib.gg_expand_khop.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_expand_khop_range.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_khop_partition.argtypes = [P, P, C.c_int, C.POINTER(u64)]
+    lib.gg_expand_khop_mid.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.POINTER(KhopStats)]
+    lib.gg_khop_partition_mid.argtypes = [P, P, C.c_int, C.POINTER(u64)]
+    lib.gg_debug_force_frontier.argtypes = [P, C.c_int]
     lib.gg_result_rows.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_fetch.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
     lib.gg_result_destroy.argtypes = [P]
@@ -237,6 +241,19 @@ class GG:
         if materialise:
             d["tables"] = self._collect(res, k_min, k_max)
         return d
+
+    def expand_khop_mid(self, csr: Csr, lo: int, hi: int, k_min: int = 1, k_max: int = 2):
+        st = KhopStats()
+        self._chk(self.lib.gg_expand_khop_mid(self.ctx, csr.handle, lo, hi, k_min, k_max, C.byref(st)))
+        return self._stats_dict(st)
+
+    def khop_partition_mid(self, csr: Csr, n_parts: int):
+        b = (C.c_uint64 * (n_parts + 1))()
+        self._chk(self.lib.gg_khop_partition_mid(self.ctx, csr.handle, n_parts, b))
+        return list(b)
+
+    def force_frontier(self, on: bool):
+        self._chk(self.lib.gg_debug_force_frontier(self.ctx, int(on)))
 
     def khop_partition(self, csr: Csr, n_parts: int):
         b = (C.c_uint64 * (n_parts + 1))()

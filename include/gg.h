@@ -122,6 +122,15 @@ int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src_lo, uint64
  * sum over v in adj(u) of (1+deg(v))).  bounds: n_parts+1 entries. */
 int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds);
 
+/* 2-hop walks (and, if k_min == 1, the 1-hop rows) of ALL sources whose MIDDLE vertex (1-hop rows:
+ * destination) has dense index in [mid_lo, mid_hi).  k_max must be 2.  Disjoint ranges partition the
+ * result of gg_expand_khop(all sources, k_min..2): counts add, digests add mod 2^64.  This is the
+ * multi-GPU sharding entry point of the 2-hop product kernel (reads each CSR row once per shard). */
+int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, int k_max,
+                       gg_khop_stats *stats);
+/* Split [0,V) into n_parts contiguous middle-vertex ranges of near-equal product work. */
+int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds);
+
 int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows);
 /* Copy rows [offset, offset+max_rows) of the h-hop table into cols[0..h] (host arrays of >= max_rows). */
 int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *cols,
@@ -147,6 +156,10 @@ int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, 
              uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats);
 
 /* ---- in-library kernel timing (HIP events on the library's own stream) ---------------------- */
+/* Testing knob: force gg_expand_khop to use the frontier kernels even where the product kernel
+ * applies (both must give identical results). */
+int gg_debug_force_frontier(gg_ctx *ctx, int on);
+
 int gg_profile_enable(gg_ctx *ctx, int on);
 int gg_profile_reset(gg_ctx *ctx);
 /* Number of distinct kernels seen; then per index: name, launches, total milliseconds. */

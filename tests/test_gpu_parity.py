@@ -248,3 +248,49 @@ def test_medium_ldbc_shape_end_to_end(gg, orc):
     assert np.array_equal(dist, o_dist) and st == o_st
     csr.close()
     g.close()
+
+
+@pytest.mark.parametrize("V,E,seed,dangling,dup", CASES[3:] + [(64, 6000, 41, 0, 200), (1000, 300000, 42, 0, 0)])
+def test_khop_product_kernel_equals_frontier_kernel(gg, orc, V, E, seed, dangling, dup):
+    """All-sources 2-hop runs through the middle-vertex product kernel; it must agree bit-for-bit with
+    the frontier kernels and with the oracle (k_min 1 and 2)."""
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    for kmin in (1, 2):
+        ref = g.khop(kmin, 2)
+        assert gg.expand_khop(csr, kmin, 2) == ref
+        gg.force_frontier(True)
+        try:
+            assert gg.expand_khop(csr, kmin, 2) == ref
+        finally:
+            gg.force_frontier(False)
+    csr.close()
+    g.close()
+
+
+def test_khop_mid_ranges_partition_the_result(gg, orc):
+    """Middle-vertex sharding (multi-GPU entry point of the product kernel): shards add up."""
+    vid, src, dst = datagen.ldbc_knows(6000, 250_000, 23)
+    # make it properly directed: drop a third of the rows so in- and out-lists differ
+    keep = (np.arange(src.size) % 3) != 0
+    src, dst = src[keep], dst[keep]
+    csr, g = build_both(gg, orc, vid, src, dst)
+    whole = g.khop(1, 2)
+    assert gg.expand_khop(csr, 1, 2) == whole
+    for parts in (1, 2, 5, 8):
+        b = gg.khop_partition_mid(csr, parts)
+        assert b[0] == 0 and b[-1] == csr.V and all(x <= y for x, y in zip(b, b[1:]))
+        rows = [0, 0, 0]
+        dig = [0, 0, 0]
+        te = fr = 0
+        for lo, hi in zip(b, b[1:]):
+            st = gg.expand_khop_mid(csr, lo, hi)
+            for h in (1, 2):
+                rows[h] += st["rows"][h]
+                dig[h] = (dig[h] + st["digest"][h]) & 0xFFFFFFFFFFFFFFFF
+            te += st["traversed_edges"]
+            fr += st["frontier_entries"]
+        assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3]
+        assert te == whole["traversed_edges"] and fr == whole["frontier_entries"]
+    csr.close()
+    g.close()
