@@ -155,14 +155,16 @@ def main():
         c.close()
         vec = [st["rows"][1], st["rows"][2], st["digest"][1], st["digest"][2], st["traversed_edges"], st["frontier_entries"]]
         if dist is not None:
-            # counts: plain sum; digests are sums mod 2^64 -> split into 32-bit halves so int64 adds never wrap
+            # 32-bit halves in int64 slots so the all-reduce never wraps; counts recombine with carry,
+            # digests are lane-wise sums (each half mod 2^32, no carry: DESIGN.md "Row digest")
             parts = []
             for x in vec:
                 parts += [x & 0xFFFFFFFF, x >> 32]
             tns = torch.tensor(parts, dtype=torch.int64, device="cuda")
             dist.all_reduce(tns)
             p = tns.tolist()
-            vec = [(p[2 * i] + (p[2 * i + 1] << 32)) & MASK64 for i in range(len(vec))]
+            vec = [((p[2 * i] & 0xFFFFFFFF) | ((p[2 * i + 1] & 0xFFFFFFFF) << 32)) if i in (2, 3)
+                   else (p[2 * i] + (p[2 * i + 1] << 32)) & MASK64 for i in range(len(vec))]
         return vec, st
 
     for _ in range(args.warmup):

@@ -99,11 +99,11 @@ __device__ __forceinline__ void entry_vertex_q(const Frontier &f, uint64_t i, ui
   *q = f.fq ? f.fq[i] : dig_q((uint64_t)vv, 0);
 }
 
-// block reduce of three u64 values -> partial[blockIdx.x*4 + 0..2]
+// block reduce -> partial[blockIdx.x*4 + 0..2]; a, b are digest sums (lane-wise 2 x u32), c a plain count
 __device__ __forceinline__ void block_store_partials(uint64_t a, uint64_t b, uint64_t c, uint64_t *s_red /*12*/,
                                                      unsigned long long *__restrict__ partial) {
-  a = wave_reduce_add_u64(a);
-  b = wave_reduce_add_u64(b);
+  a = wave_reduce_dsum(a);
+  b = wave_reduce_dsum(b);
   c = wave_reduce_add_u64(c);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
@@ -113,7 +113,9 @@ __device__ __forceinline__ void block_store_partials(uint64_t a, uint64_t b, uin
   }
   __syncthreads();
   if (threadIdx.x < 3) {
-    uint64_t s = s_red[threadIdx.x] + s_red[3 + threadIdx.x] + s_red[6 + threadIdx.x] + s_red[9 + threadIdx.x];
+    const uint64_t v0 = s_red[threadIdx.x], v1 = s_red[3 + threadIdx.x], v2 = s_red[6 + threadIdx.x],
+                   v3 = s_red[9 + threadIdx.x];
+    const uint64_t s = threadIdx.x < 2 ? dsum_add(dsum_add(v0, v1), dsum_add(v2, v3)) : v0 + v1 + v2 + v3;
     partial[(uint64_t)blockIdx.x * 4 + threadIdx.x] = s;
   }
 }
@@ -168,12 +170,12 @@ __global__ __launch_bounds__(XT) void k_expand_fused2(const uint32_t *__restrict
     uint32_t jj = lane;
     for (; jj + 192 < len; jj += 256) {
       uint32_t w0 = row[jj], w1 = row[jj + 64], w2 = row[jj + 128], w3 = row[jj + 192];
-      acc += dig_leaf(q2, w0);
-      acc += dig_leaf(q2, w1);
-      acc += dig_leaf(q2, w2);
-      acc += dig_leaf(q2, w3);
+      acc = dsum_add(acc, dig_leaf(q2, w0));
+      acc = dsum_add(acc, dig_leaf(q2, w1));
+      acc = dsum_add(acc, dig_leaf(q2, w2));
+      acc = dsum_add(acc, dig_leaf(q2, w3));
     }
-    for (; jj < len; jj += 64) acc += dig_leaf(q2, row[jj]);
+    for (; jj < len; jj += 64) acc = dsum_add(acc, dig_leaf(q2, row[jj]));
   }
   block_store_partials(mid_sum, acc, rows_last, s_red, partial);
 }
@@ -248,17 +250,34 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
 constexpr int MID_R = 4;  // out-row values per lane per J-block: a J-block covers 64*MID_R = 256 leaves
 
-template <int NREG, bool FULL>
-__device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int ib, const uint64_t (&t)[MID_R],
-                                               const bool (&ok)[MID_R], uint64_t (&acc)[MID_R]) {
-#pragma unroll 4
-  for (int i = ia; i < ib; i++) {
-    const uint64_t q = s_q[i];  // wave-uniform address: LDS broadcast
+#define GG_XAD(acc, q, t) asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(q), "v"(t))
+
+// acc = (q ^ t) + acc in ONE instruction per 32-bit half; spelled out because the compiler otherwise
+// splits the unrolled loop into v_xor_b32 + v_add3_u32 (12 instead of 8 VALU per state at NREG = 4).
+template <int NREG>
+__device__ __forceinline__ void mid_fold(uint64_t q, const uint32_t (&tlo)[MID_R], const uint32_t (&thi)[MID_R],
+                                         uint32_t (&alo)[MID_R], uint32_t (&ahi)[MID_R]) {
+  const uint32_t qlo = (uint32_t)q, qhi = (uint32_t)(q >> 32);
 #pragma unroll
-    for (int r = 0; r < NREG; r++) {
-      if (FULL || ok[r]) acc[r] += q ^ t[r];
-    }
+  for (int r = 0; r < NREG; r++) {
+    GG_XAD(alo[r], qlo, tlo[r]);
+    GG_XAD(ahi[r], qhi, thi[r]);
   }
+}
+
+template <int NREG>
+__device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int ib, const uint32_t (&tlo)[MID_R],
+                                               const uint32_t (&thi)[MID_R], uint32_t (&alo)[MID_R],
+                                               uint32_t (&ahi)[MID_R]) {
+  int i = ia;
+  for (; i + 4 <= ib; i += 4) {  // 4 states per trip: their LDS broadcast reads issue back to back
+    const uint64_t q0 = s_q[i], q1 = s_q[i + 1], q2 = s_q[i + 2], q3 = s_q[i + 3];
+    mid_fold<NREG>(q0, tlo, thi, alo, ahi);
+    mid_fold<NREG>(q1, tlo, thi, alo, ahi);
+    mid_fold<NREG>(q2, tlo, thi, alo, ahi);
+    mid_fold<NREG>(q3, tlo, thi, alo, ahi);
+  }
+  for (; i < ib; i++) mid_fold<NREG>(s_q[i], tlo, thi, alo, ahi);
 }
 
 __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
@@ -268,9 +287,11 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
                                                     int emit_mid, unsigned long long *__restrict__ partial) {
   __shared__ uint64_t s_foff[XT + 1];
   __shared__ uint64_t s_q[XT];
+  __shared__ uint64_t s_pq[XT + 1];   // lane-wise prefix sums of s_q: s_pq[i] = sum of s_q[0..i)
   __shared__ uint32_t s_x[XT];
   __shared__ uint32_t s_run[XT + 1];  // tile position where each run of equal x starts (+ end sentinel)
   __shared__ uint32_t s_wcnt[XT / 64];
+  __shared__ uint64_t s_wsum[XT / 64];
   __shared__ uint64_t s_red[12];
 
   const uint64_t fbase = (uint64_t)roff[0];
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool valid = p < fbase + M;
-  uint64_t mid_sum = 0, rows_last = 0;
+  uint64_t mid_sum = 0, rows_last = 0, myq = 0;
   uint32_t x = INVALID_U32;
   if (valid) {
     uint64_t k;
@@ -290,16 +311,37 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
     const uint32_t u = rnbr[p];
     const uint64_t P = dig_leaf(dig_q((uint64_t)u, 0), x);
     if (emit_mid) mid_sum = P;
-    s_q[threadIdx.x] = dig_q(P, 1);
+    myq = dig_q(P, 1);
     rows_last = (uint64_t)(off[x + 1] - off[x]);
   }
+  s_q[threadIdx.x] = myq;
   s_x[threadIdx.x] = x;
+  // lane-wise inclusive scan of q inside the wave, wave totals through LDS
+  uint32_t plo = (uint32_t)myq, phi = (uint32_t)(myq >> 32);
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t a = __shfl_up(plo, o, 64), b = __shfl_up(phi, o, 64);
+    if (lane >= o) {
+      plo += a;
+      phi += b;
+    }
+  }
+  if (lane == 63) s_wsum[wave] = ((uint64_t)phi << 32) | plo;
   __syncthreads();
 
   // run heads -> compact list of run start positions (ballot + popcount, wave bases through LDS)
   const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
   const uint64_t hm = __ballot(head);
   if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
+  {
+    uint64_t wbase = 0;
+#pragma unroll
+    for (int w = 0; w < XT / 64; w++)
+      if (w < wave) wbase = dsum_add(wbase, s_wsum[w]);
+    const uint64_t incl = dsum_add(wbase, ((uint64_t)phi << 32) | plo);
+    s_pq[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) s_pq[0] = 0;
+  }
   __syncthreads();
   uint32_t hbase = 0, nruns = 0;
 #pragma unroll
@@ -308,14 +350,15 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
     nruns += s_wcnt[w];
   }
   if (head) s_run[hbase + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
-  const uint64_t remaining = fbase + M - (fbase + (uint64_t)blockIdx.x * XT);
+  const uint64_t remaining = M - (uint64_t)blockIdx.x * XT;
   const uint32_t n_valid = remaining < XT ? (uint32_t)remaining : XT;
   if (threadIdx.x == 0) s_run[nruns] = n_valid;
   __syncthreads();
 
-  uint64_t acc[MID_R];
+  uint32_t alo[MID_R], ahi[MID_R];
 #pragma unroll
-  for (int r = 0; r < MID_R; r++) acc[r] = 0;
+  for (int r = 0; r < MID_R; r++) alo[r] = ahi[r] = 0;
+  uint64_t corr = 0;  // what lanes holding no leaf accumulated (q ^ 0), removed at the end
 
   for (uint32_t rr = 0; rr < nruns; rr++) {
     const int a = (int)s_run[rr], b = (int)s_run[rr + 1];
@@ -331,31 +374,40 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
     const bool isplit = len >= 16;
     const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
     const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : b;
+    if (ia >= ib) continue;
+    const uint64_t sq = dsum_sub(s_pq[ib], s_pq[ia]);  // sum of the slice's hash states
     for (uint32_t jb = 0; jb < nJ; jb++) {
       if (!isplit && ((jb + rr) & (XT / 64 - 1)) != (uint32_t)wave) continue;
       const uint32_t base = jb * 64 * MID_R;
       const uint32_t rem = dout - base;
-      uint64_t t[MID_R];
-      bool ok[MID_R];
+      uint32_t tlo[MID_R], thi[MID_R];
+      const int nreg = rem >= 64 * MID_R ? MID_R : (int)((rem + 63) / 64);
+      uint32_t ninv = 0;  // registers (among the nreg used) in which this lane holds no leaf
 #pragma unroll
       for (int r = 0; r < MID_R; r++) {
         const uint32_t j = base + r * 64 + lane;
-        ok[r] = j < dout;
-        t[r] = ok[r] ? (uint64_t)row[j] * (uint64_t)DIG_K32 : 0ULL;
+        const bool ok = j < dout;
+        const uint64_t t = ok ? (uint64_t)row[j] * (uint64_t)DIG_K32 : 0ULL;
+        tlo[r] = (uint32_t)t;
+        thi[r] = (uint32_t)(t >> 32);
+        if (!ok && r < nreg) ninv++;
       }
-      if (rem >= 64 * MID_R)
-        mid_accumulate<MID_R, true>(s_q, ia, ib, t, ok, acc);
-      else if (rem > 128)
-        mid_accumulate<MID_R, false>(s_q, ia, ib, t, ok, acc);
-      else if (rem > 64)
-        mid_accumulate<2, false>(s_q, ia, ib, t, ok, acc);
+      if (nreg == MID_R)
+        mid_accumulate<MID_R>(s_q, ia, ib, tlo, thi, alo, ahi);
+      else if (nreg == 3)
+        mid_accumulate<3>(s_q, ia, ib, tlo, thi, alo, ahi);
+      else if (nreg == 2)
+        mid_accumulate<2>(s_q, ia, ib, tlo, thi, alo, ahi);
       else
-        mid_accumulate<1, false>(s_q, ia, ib, t, ok, acc);
+        mid_accumulate<1>(s_q, ia, ib, tlo, thi, alo, ahi);
+      // a lane without a leaf added q ^ 0 = q for every state of the slice
+      for (uint32_t c = 0; c < ninv; c++) corr = dsum_add(corr, sq);
     }
   }
   uint64_t total = 0;
 #pragma unroll
-  for (int r = 0; r < MID_R; r++) total += acc[r];
+  for (int r = 0; r < MID_R; r++) total = dsum_add(total, ((uint64_t)ahi[r] << 32) | alo[r]);
+  total = dsum_sub(total, corr);
   block_store_partials(mid_sum, total, rows_last, s_red, partial);
 }
 
@@ -366,18 +418,18 @@ __global__ __launch_bounds__(256) void k_mid_work(const uint32_t *__restrict__ o
   if (x < V) work[x] = 1 + (uint64_t)(roff[x + 1] - roff[x]) * (1 + (uint64_t)(off[x + 1] - off[x]));
 }
 
-// sum partial[b*4 + c] over b -> out[c]  (c < 3)
+// sum partial[b*4 + c] over b -> out[c]  (c < 3); c = 0,1 are digest sums (lane-wise), c = 2 a count
 __global__ __launch_bounds__(256) void k_reduce_partials(const unsigned long long *__restrict__ partial,
                                                          uint64_t nblocks, unsigned long long *__restrict__ out) {
   __shared__ uint64_t s_red[12];
   uint64_t a = 0, b = 0, c = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblocks; i += (uint64_t)gridDim.x * blockDim.x) {
-    a += partial[i * 4];
-    b += partial[i * 4 + 1];
+    a = dsum_add(a, partial[i * 4]);
+    b = dsum_add(b, partial[i * 4 + 1]);
     c += partial[i * 4 + 2];
   }
-  a = wave_reduce_add_u64(a);
-  b = wave_reduce_add_u64(b);
+  a = wave_reduce_dsum(a);
+  b = wave_reduce_dsum(b);
   c = wave_reduce_add_u64(c);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
@@ -386,9 +438,18 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const unsigned long lon
     s_red[wave * 3 + 2] = c;
   }
   __syncthreads();
-  if (threadIdx.x < 3)
-    atomicAdd(&out[threadIdx.x],
-              s_red[threadIdx.x] + s_red[3 + threadIdx.x] + s_red[6 + threadIdx.x] + s_red[9 + threadIdx.x]);
+  if (threadIdx.x < 3) {
+    const uint64_t v0 = s_red[threadIdx.x], v1 = s_red[3 + threadIdx.x], v2 = s_red[6 + threadIdx.x],
+                   v3 = s_red[9 + threadIdx.x];
+    if (threadIdx.x < 2) {  // the two halves are independent u32 sums: two 32-bit atomics, no carry
+      const uint64_t sv = dsum_add(dsum_add(v0, v1), dsum_add(v2, v3));
+      unsigned int *o32 = reinterpret_cast<unsigned int *>(&out[threadIdx.x]);
+      atomicAdd(&o32[0], (unsigned int)sv);
+      atomicAdd(&o32[1], (unsigned int)(sv >> 32));
+    } else {
+      atomicAdd(&out[2], v0 + v1 + v2 + v3);
+    }
+  }
 }
 
 // ---- source list -> frontier 0 -------------------------------------------------------------------

@@ -31,6 +31,12 @@ uint64_t orc_fmix64(uint64_t x) {
 static inline uint64_t orc_q(uint64_t p, int j) { return orc_fmix64(p + ORC_GOLD * (uint64_t)(j + 1)); }
 static inline uint64_t orc_leaf(uint64_t q, uint32_t d) { return q ^ ((uint64_t)d * (uint64_t)ORC_K32); }
 
+/* digest sums are lane-wise: two independent u32 sums (low/high half), no carry between them */
+uint64_t orc_dsum_add(uint64_t a, uint64_t b) {
+  uint32_t lo = (uint32_t)a + (uint32_t)b, hi = (uint32_t)(a >> 32) + (uint32_t)(b >> 32);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 uint64_t orc_row_hash(const uint32_t *d, int h) {
   uint64_t p = d[0]; /* P_0 := d0 */
   for (int j = 0; j < h; j++) p = orc_leaf(orc_q(p, j), d[j + 1]);
@@ -531,16 +537,20 @@ static void khop_rec(const orc_csr *g, uint32_t v, uint64_t q, int j, int k_min,
   st->frontier_entries += 1;
   if (h >= k_min) st->rows[h] += (uint64_t)(e - b);
   if (h == k_max) {
-    uint64_t s = 0;
+    uint32_t slo = 0, shi = 0;
     const uint32_t *nb = g->nbr;
-    for (int64_t i = b; i < e; i++) s += orc_leaf(q, nb[i]);
-    st->digest[h] += s;
+    for (int64_t i = b; i < e; i++) {
+      uint64_t r = orc_leaf(q, nb[i]);
+      slo += (uint32_t)r;
+      shi += (uint32_t)(r >> 32);
+    }
+    st->digest[h] = orc_dsum_add(st->digest[h], ((uint64_t)shi << 32) | slo);
     return;
   }
   for (int64_t i = b; i < e; i++) {
     uint32_t w = g->nbr[i];
     uint64_t p = orc_leaf(q, w);
-    if (h >= k_min) st->digest[h] += p;
+    if (h >= k_min) st->digest[h] = orc_dsum_add(st->digest[h], p);
     khop_rec(g, w, orc_q(p, h), h, k_min, k_max, st);
   }
 }
@@ -580,7 +590,7 @@ int orc_khop_csr(const orc_csr *g, const uint32_t *src_dense, uint64_t n_src, ui
   for (int t = 0; t < nt; t++) {
     for (int h = 0; h <= ORC_MAX_HOPS; h++) {
       st->rows[h] += part[t].rows[h];
-      st->digest[h] += part[t].digest[h];
+      st->digest[h] = orc_dsum_add(st->digest[h], part[t].digest[h]);
     }
     st->traversed_edges += part[t].traversed_edges;
     st->frontier_entries += part[t].frontier_entries;

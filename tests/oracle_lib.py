@@ -87,10 +87,12 @@ class Oracle:
         return int(self.lib.orc_row_hash(a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size - 1))
 
     def digest_rows(self, dense_rows: np.ndarray) -> int:
-        s = 0
+        lo = hi = 0  # lane-wise digest: low and high halves of the row hashes are summed independently
         for r in dense_rows:
-            s = (s + self.row_hash(r)) & 0xFFFFFFFFFFFFFFFF
-        return s
+            h = self.row_hash(r)
+            lo = (lo + (h & 0xFFFFFFFF)) & 0xFFFFFFFF
+            hi = (hi + (h >> 32)) & 0xFFFFFFFF
+        return (hi << 32) | lo
 
     # ---- join restatement
     def hash_join(self, build_keys, probe_keys) -> np.ndarray:

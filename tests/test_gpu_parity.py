@@ -9,6 +9,13 @@ from tests.oracle_lib import sort_rows
 pytestmark = pytest.mark.gpu
 
 
+def dsum(a, b):
+    """digest sums are lane-wise: low and high 32-bit halves add independently (Row digest)"""
+    lo = ((a & 0xFFFFFFFF) + (b & 0xFFFFFFFF)) & 0xFFFFFFFF
+    hi = ((a >> 32) + (b >> 32)) & 0xFFFFFFFF
+    return (hi << 32) | lo
+
+
 def build_both(gg, orc, vid, src, dst, rowid=None, chunk_rows=0):
     gg.staging_clear()
     old = gg.chunk_rows
@@ -188,7 +195,7 @@ def test_khop_ranges_partition_the_result(gg, orc):
             assert st == g.khop(1, 2, lo=lo, hi=hi)
             for h in (1, 2):
                 rows[h] += st["rows"][h]
-                dig[h] = (dig[h] + st["digest"][h]) & 0xFFFFFFFFFFFFFFFF
+                dig[h] = dsum(dig[h], st["digest"][h])
             te += st["traversed_edges"]
         assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3] and te == whole["traversed_edges"]
     csr.close()
@@ -287,7 +294,7 @@ def test_khop_mid_ranges_partition_the_result(gg, orc):
             st = gg.expand_khop_mid(csr, lo, hi)
             for h in (1, 2):
                 rows[h] += st["rows"][h]
-                dig[h] = (dig[h] + st["digest"][h]) & 0xFFFFFFFFFFFFFFFF
+                dig[h] = dsum(dig[h], st["digest"][h])
             te += st["traversed_edges"]
             fr += st["frontier_entries"]
         assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3]
