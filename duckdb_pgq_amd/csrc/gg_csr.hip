@@ -77,9 +77,9 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
 // order is fully determined (stable).  Elements are first ranked INSIDE the tile and staged in LDS in
 // digit order, then written out: consecutive LDS slots of one digit go to consecutive global
 // addresses, so the global stores are coalesced runs instead of 4-byte scatters.
-constexpr int RB_THREADS = 256;
+constexpr int RB_THREADS = 512;                    // 8 waves share one 4096-element tile (LDS-bound occupancy)
 constexpr int RB_WAVES = RB_THREADS / 64;
-constexpr int RB_ITEMS = 16;                       // elements per lane
+constexpr int RB_ITEMS = 8;                        // elements per lane
 constexpr int RB_TILE = RB_THREADS * RB_ITEMS;     // 4096 elements per workgroup
 constexpr int RB_WTILE = RB_TILE / RB_WAVES;       // 1024 per wave
 constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
@@ -100,12 +100,30 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__re
   __syncthreads();
   const int64_t min_idx = st->min_idx;
   const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
-#pragma unroll 4
-  for (int it = 0; it < RB_ITEMS; it++) {
-    const uint64_t e = base + (uint64_t)it * RB_THREADS + threadIdx.x;
-    if (e < E) {
-      uint32_t u = ht_lookup(ht, shift, mask, min_idx, src[e]);
-      uint32_t v = ht_lookup(ht, shift, mask, min_idx, dst[e]);
+  constexpr int B = 4;  // edges per batch: 2*B independent first-probe loads in flight per lane
+  for (int it0 = 0; it0 < RB_ITEMS; it0 += B) {
+    int64_t ks[B], kd[B];
+    uint64_t ss[B], sd[B];
+    uint4 rs[B], rd[B];
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
+      ks[j] = e < E ? src[e] : HT_EMPTY;
+      kd[j] = e < E ? dst[e] : HT_EMPTY;
+    }
+#pragma unroll
+    for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
+      ss[j] = ((uint64_t)ks[j] * DIG_GOLD) >> shift;
+      sd[j] = ((uint64_t)kd[j] * DIG_GOLD) >> shift;
+      rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
+      rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
+    }
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
+      if (e >= E) continue;
+      uint32_t u = ht_resolve(ht, mask, min_idx, ks[j], ss[j], rs[j]);
+      uint32_t v = ht_resolve(ht, mask, min_idx, kd[j], sd[j], rd[j]);
       if (u == INVALID_U32 || v == INVALID_U32) {
         u = INVALID_U32;
         v = INVALID_U32;
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
   uint32_t *hw = HAS_B ? xb + RB_TILE : xb;            // [RB_WAVES][ndig] per-wave counts -> running cursors
   uint32_t *dbase = hw + RB_WAVES * ndig;              // [ndig] first tile slot of each digit
   uint32_t *gb = dbase + ndig;                         // [ndig] global position of tile slot 0 of the digit, minus dbase
-  uint32_t *misc = gb + ndig;                          // [8] block-scan scratch + valid count
+  uint32_t *misc = gb + ndig;                          // [RB_WAVES + 1] block-scan scratch + valid count
 
   const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
   const uint64_t tile_base = (uint64_t)blockIdx.x * RB_TILE;
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
         tot += c;
       }
     }
-    // block exclusive scan of tot over threads (ndig <= 256 = RB_THREADS)
+    // block exclusive scan of tot over threads (ndig <= 256 <= RB_THREADS)
     uint32_t incl = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
       dbase[d] = ex;
       gb[d] = bases[(uint64_t)d * nblocks + blockIdx.x] - ex;
     }
-    if (threadIdx.x == 0) misc[4] = all;  // valid elements in this tile
+    if (threadIdx.x == 0) misc[RB_WAVES] = all;  // valid elements in this tile
   }
   __syncthreads();
 
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
   __syncthreads();
 
   // write out: consecutive staged slots of one digit -> consecutive global positions
-  const uint32_t nvalid = misc[4];
+  const uint32_t nvalid = misc[RB_WAVES];
 #pragma unroll
   for (int it = 0; it < RB_ITEMS; it++) {
     const uint32_t idx = (uint32_t)it * RB_THREADS + threadIdx.x;
@@ -345,7 +363,7 @@ int radix_sort_stable(gg_ctx *ctx, const RadixIO &io, uint64_t n, bool has_b, bo
     int rem = key_bits - (int)lo_bit;
     const uint32_t bits = (uint32_t)(rem < bits_per ? (rem < 1 ? 1 : rem) : bits_per);
     const uint32_t ndig = 1u << bits;
-    const size_t lds = ((size_t)RB_TILE * (has_b ? 3 : 2) + (size_t)(RB_WAVES + 2) * ndig + 8) * sizeof(uint32_t);
+    const size_t lds = ((size_t)RB_TILE * (has_b ? 3 : 2) + (size_t)(RB_WAVES + 2) * ndig + RB_WAVES + 8) * sizeof(uint32_t);
     const uint64_t ncount = (uint64_t)ndig * nblocks64;
     uint32_t *counts = nullptr;
     if (p == 0 && counts0) {

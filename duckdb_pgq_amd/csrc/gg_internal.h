@@ -177,6 +177,19 @@ __device__ __forceinline__ uint32_t ht_lookup(const HtSlot *__restrict__ ht, uin
   }
 }
 
+// finish a lookup whose first probe (slot, raw) is already loaded; continues linear probing on a miss
+__device__ __forceinline__ uint32_t ht_resolve(const HtSlot *__restrict__ ht, uint64_t mask, int64_t min_idx,
+                                               int64_t key, uint64_t slot, uint4 raw) {
+  if (key == HT_EMPTY) return min_idx >= 0 ? (uint32_t)min_idx : INVALID_U32;
+  while (true) {
+    const int64_t k = (int64_t)(((uint64_t)raw.y << 32) | raw.x);
+    if (k == key) return raw.z;
+    if (k == HT_EMPTY) return INVALID_U32;
+    slot = (slot + 1) & mask;
+    raw = *reinterpret_cast<const uint4 *>(&ht[slot]);
+  }
+}
+
 // Digest sums are LANE-WISE: two independent u32 sums (low / high half of the row hash), no carry
 // between the halves.  One v_xad_u32 (xor + add) per half per walk on gfx950.
 __host__ __device__ __forceinline__ uint64_t dsum_add(uint64_t a, uint64_t b) {
