@@ -4,8 +4,9 @@
 One "step" = one pass of the hot path over the synthetic LDBC-shaped tables already resident in HBM:
     gg_csr_build (densify ids, histogram, scan, stable radix scatter)  +  gg_expand_khop_range(1..2)
 i.e. what the reference does per query as hash-join build + probe chain.  With N > 1 ranks the
-SOURCE vertices are range-partitioned on 2-hop work (gg_khop_partition); every rank builds its own
-CSR replica and expands its range; there is no data-path collective, only one 40-byte all-reduce of
+vertices are hash-partitioned (owner = hash(person id) mod N); every rank holds the same staged base
+tables, builds only the CSR rows of the vertices it owns (gg_csr_build_shard) and produces the walks
+whose middle vertex it owns; there is no data-path collective, only one small all-reduce of
 (rows, digest, TE) per step, so `value` = total traversed edges of the whole query / max-over-ranks
 time ("strong" scaling: the query is fixed, ranks split it).
 
@@ -102,6 +103,8 @@ def main():
     ap.add_argument("--workload", default="sf100", choices=["sf0.1", "sf1", "sf10", "sf100"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="diagnostic: time rank 0's share of an N-rank run on one GPU (output is not a bench line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,16 +145,14 @@ def main():
     if rank == 0:
         log(f"{args.workload}: V={V} knows rows={R}; datagen {t_gen:.1f}s, staging (PCIe) {t_stage*1e3:.1f} ms")
 
-    # ---- source partition (setup, not timed) ----------------------------------------------------------
-    csr = gg.build_csr()
-    bounds = gg.khop_partition_mid(csr, world)  # middle-vertex ranges of equal product work
-    lo, hi = bounds[rank], bounds[rank + 1]
-    csr.close()
-
     def step():
-        c = gg.build_csr()
-        # all persons are sources; this rank owns the walks whose middle vertex is in [lo, hi)
-        st = gg.expand_khop_mid(c, lo, hi, 1, 2) if world > 1 else gg.expand_khop(c, 1, 2)
+        # all persons are sources; with N ranks this rank builds only the CSR rows of the vertices it
+        # owns (owner = hash(id) mod N) and produces the walks whose middle vertex it owns
+        if args.shard_of > 1:
+            c = gg.build_csr_shard(0, args.shard_of)
+        else:
+            c = gg.build_csr_shard(rank, world) if world > 1 else gg.build_csr()
+        st = gg.expand_khop(c, 1, 2)
         c.close()
         vec = [st["rows"][1], st["rows"][2], st["digest"][1], st["digest"][2], st["traversed_edges"], st["frontier_entries"]]
         if dist is not None:
@@ -219,6 +220,11 @@ def main():
     kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
                    "us_per_step": v[1] * 1e3 / args.steps} for k, v in prof.items()}
 
+    if args.shard_of > 1:
+        log(f"shard 0 of {args.shard_of}: {ms_per_step:.3f} ms/step; kernels us/step:",
+            {k: round(v["us_per_step"]) for k, v in kernels.items()})
+        gg.close()
+        return
     if rank == 0:
         extra = {}
         if not args.no_cpu:
@@ -246,7 +252,7 @@ def main():
             "data": "synthetic (seeded LDBC-shaped person/knows, duckdb_pgq_amd/datagen.py)",
             "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build + 2-hop expansion (count + digest)",
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
-                       "traversed_edges": int(te_total), "parallelism": f"middle-vertex range x{world}, CSR replicated"},
+                       "traversed_edges": int(te_total), "parallelism": f"vertex-ownership shards x{world} (base tables replicated, CSR + expansion sharded, no data-path collective)"},
             "roofline": roof,
             "kernels": kernels,
             "staging_ms_pcie": t_stage * 1e3,

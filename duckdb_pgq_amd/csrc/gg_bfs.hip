@@ -120,6 +120,10 @@ extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, 
     set_error("gg_bfs64: bad argument (n_src must be 0..%d)", GG_BFS_LANES);
     return GG_ERR_INVALID_ARG;
   }
+  if (csr->n_parts > 1) {
+    set_error("gg_bfs64 needs a whole CSR, not a shard");
+    return GG_ERR_STATE;
+  }
   GG_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const uint64_t V = csr->V;

@@ -28,8 +28,15 @@ namespace gg {
 struct BuildStatus {  // device-side status block, copied back once per build
   unsigned long long dup_vertex;   // !=0: duplicate vertex id seen
   long long min_idx;               // dense index of the vertex with id == HT_EMPTY, or -1
-  unsigned long long kept;         // edges kept (both endpoints are vertices)
+  unsigned long long kept;         // edges kept in the forward CSR (both endpoints are vertices, source owned)
+  unsigned long long kept_rev;     // edges kept in the reverse CSR (shard builds; destination owned)
+  unsigned long long owned;        // vertices owned by this shard
 };
+
+// shard ownership of a vertex id: independent of table order, so every rank decides it alone
+__device__ __forceinline__ bool owns(int64_t id, uint32_t part, uint32_t n_parts) {
+  return n_parts <= 1 || (uint32_t)((((uint64_t)id * DIG_GOLD) >> 32) % n_parts) == part;
+}
 
 __global__ __launch_bounds__(256) void k_ht_init(HtSlot *__restrict__ ht, uint64_t cap) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,8 +52,11 @@ __global__ __launch_bounds__(256) void k_ht_init(HtSlot *__restrict__ ht, uint64
 
 __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ vid, uint64_t V,
                                                    HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
-                                                   BuildStatus *__restrict__ st) {
+                                                   BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool mine = i < V && owns(vid[i < V ? i : 0], part, n_parts);
+  const uint64_t om = __ballot(mine);
+  if ((threadIdx.x & 63) == 0 && om) atomicAdd(&st->owned, (unsigned long long)__popcll(om));
   if (i >= V) return;
   int64_t key = vid[i];
   if (key == HT_EMPTY) {  // the sentinel value itself is a legal id: keep it outside the table
@@ -87,16 +97,19 @@ constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
 // Densify + pass-0 histogram.  One lane per edge row: two id lookups (hash table is V-sized, L2 /
 // Infinity-Cache resident), dense endpoints written coalesced, digit counted in the tile's LDS histogram.
 // counts[digit * nblocks + block] = number of valid elements of that tile with that digit
-__global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__restrict__ src,
-                                                             const int64_t *__restrict__ dst, uint64_t E,
-                                                             const HtSlot *__restrict__ ht, uint32_t shift,
-                                                             uint64_t mask, const BuildStatus *__restrict__ st,
-                                                             uint32_t *__restrict__ su, uint32_t *__restrict__ dv,
-                                                             uint32_t bits, uint64_t nblocks,
-                                                             uint32_t *__restrict__ counts) {
+__global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
+    const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
+    uint32_t shift, uint64_t mask, const BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts,
+    uint32_t *__restrict__ fk, uint32_t *__restrict__ fv, uint32_t *__restrict__ rk /* nullable */,
+    uint32_t *__restrict__ rv /* nullable */, uint32_t bits, uint64_t nblocks, uint32_t *__restrict__ counts,
+    uint32_t *__restrict__ counts_r /* nullable */) {
   __shared__ uint32_t hist[1 << RB_MAX_BITS];
+  __shared__ uint32_t hist_r[1 << RB_MAX_BITS];
   const uint32_t ndig = 1u << bits;
-  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) hist[i] = 0;
+  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) {
+    hist[i] = 0;
+    hist_r[i] = 0;
+  }
   __syncthreads();
   const int64_t min_idx = st->min_idx;
   const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
@@ -105,37 +118,50 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__re
     int64_t ks[B], kd[B];
     uint64_t ss[B], sd[B];
     uint4 rs[B], rd[B];
+    bool of[B], orv[B];
 #pragma unroll
     for (int j = 0; j < B; j++) {
       const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
       ks[j] = e < E ? src[e] : HT_EMPTY;
       kd[j] = e < E ? dst[e] : HT_EMPTY;
+      of[j] = e < E && owns(ks[j], part, n_parts);   // edge belongs to this shard's forward CSR
+      orv[j] = e < E && owns(kd[j], part, n_parts);  // ... reverse CSR
     }
 #pragma unroll
     for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
       ss[j] = ((uint64_t)ks[j] * DIG_GOLD) >> shift;
       sd[j] = ((uint64_t)kd[j] * DIG_GOLD) >> shift;
-      rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
-      rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
+      if (of[j] || orv[j]) {
+        rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
+        rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B; j++) {
       const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
       if (e >= E) continue;
-      uint32_t u = ht_resolve(ht, mask, min_idx, ks[j], ss[j], rs[j]);
-      uint32_t v = ht_resolve(ht, mask, min_idx, kd[j], sd[j], rd[j]);
-      if (u == INVALID_U32 || v == INVALID_U32) {
-        u = INVALID_U32;
-        v = INVALID_U32;
-      } else {
-        atomicAdd(&hist[u & (ndig - 1)], 1u);
+      uint32_t u = INVALID_U32, v = INVALID_U32;
+      if (of[j] || orv[j]) {
+        u = ht_resolve(ht, mask, min_idx, ks[j], ss[j], rs[j]);
+        v = ht_resolve(ht, mask, min_idx, kd[j], sd[j], rd[j]);
       }
-      su[e] = u;
-      dv[e] = v;
+      const bool ok = u != INVALID_U32 && v != INVALID_U32;
+      const bool f = ok && of[j], r = ok && orv[j];
+      if (f) atomicAdd(&hist[u & (ndig - 1)], 1u);
+      fk[e] = f ? u : INVALID_U32;
+      fv[e] = v;
+      if (rk) {
+        if (r) atomicAdd(&hist_r[v & (ndig - 1)], 1u);
+        rk[e] = r ? v : INVALID_U32;
+        rv[e] = u;
+      }
     }
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) {
+    counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
+    if (counts_r) counts_r[(uint64_t)d * nblocks + blockIdx.x] = hist_r[d];
+  }
 }
 
 // histogram of a later pass: n comes from device memory (edges kept is only known on the device)
@@ -302,8 +328,13 @@ __global__ __launch_bounds__(256) void k_row_offsets(const uint32_t *__restrict_
     for (uint64_t u = (uint64_t)k + 1; u <= V; u++) off[u] = (uint32_t)n;
 }
 
-__global__ __launch_bounds__(64) void k_publish_kept(const uint64_t *__restrict__ total, BuildStatus *__restrict__ st) {
-  if (threadIdx.x == 0) st->kept = *total;
+__global__ __launch_bounds__(64) void k_publish_kept(const uint64_t *__restrict__ total,
+                                                     const uint64_t *__restrict__ total_rev,
+                                                     BuildStatus *__restrict__ st) {
+  if (threadIdx.x == 0) {
+    st->kept = *total;
+    st->kept_rev = total_rev ? *total_rev : *total;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_gather_rowid(const uint32_t *__restrict__ epos,
@@ -425,9 +456,10 @@ extern "C" void gg_csr_destroy(gg_csr *csr) {
   delete csr;
 }
 
-extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
-  if (!ctx || !out) return GG_ERR_INVALID_ARG;
+static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
+  if (!ctx || !out || n_parts < 1 || part < 0 || part >= n_parts) return GG_ERR_INVALID_ARG;
   *out = nullptr;
+  const bool shard = n_parts > 1;
   GG_TRY(gg_staging_sync(ctx));
   GG_HIP(hipSetDevice(ctx->device));
   const uint64_t V = ctx->n_vertices, E = ctx->n_edges;
@@ -437,6 +469,8 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
   csr->ctx = ctx;
   csr->V = V;
   csr->E_cap = E;
+  csr->part = part;
+  csr->n_parts = n_parts;
   struct Guard {  // frees the half-built CSR on any early return
     gg_csr *c;
     bool armed = true;
@@ -457,7 +491,7 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
   GG_TRY(ctx->dev_alloc((void **)&csr->epos, (E ? E : 1) * sizeof(uint32_t)));
   BuildStatus *st = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&st, sizeof(BuildStatus)));
-  BuildStatus init{0ULL, -1LL, 0ULL};
+  BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL};
   memcpy(ctx->pin_scratch, &init, sizeof(init));
   GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch, sizeof(init), hipMemcpyHostToDevice, s));
   if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -465,11 +499,19 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
             csr->ht_cap);
   if (V)
     GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_shift, csr->ht_cap - 1, st);
+              csr->ht_shift, csr->ht_cap - 1, st, (uint32_t)part, (uint32_t)n_parts);
 
-  unsigned long long *kept_dev = nullptr;
+  unsigned long long *kept_dev = nullptr, *kept_rev_dev = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
   GG_HIP(hipMemsetAsync(kept_dev, 0, sizeof(unsigned long long), s));
+  uint32_t *rkey_sorted = nullptr;
+  if (shard) {
+    GG_TRY(ctx->dev_alloc((void **)&kept_rev_dev, sizeof(unsigned long long)));
+    GG_HIP(hipMemsetAsync(kept_rev_dev, 0, sizeof(unsigned long long), s));
+    GG_TRY(ctx->dev_alloc((void **)&csr->roff, (V + 1) * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&csr->rnbr, (E ? E : 1) * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&rkey_sorted, (E ? E : 1) * sizeof(uint32_t)));
+  }
   if (E) {
     // ---- densify + fused pass-0 histogram --------------------------------------------------------
     const int key_bits = ceil_log2_u64(V < 2 ? 2 : V);
@@ -477,23 +519,40 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
     const int bits0 = (key_bits + passes - 1) / passes;
     const uint64_t nblocks64 = (E + RB_TILE - 1) / RB_TILE;
     const unsigned nblocks = (unsigned)nblocks64;
-    uint32_t *su = nullptr, *dv = nullptr, *counts0 = nullptr;
+    uint32_t *su = nullptr, *dv = nullptr, *counts0 = nullptr, *rk = nullptr, *rv = nullptr, *counts0r = nullptr;
     GG_TRY(ctx->dev_alloc((void **)&su, E * sizeof(uint32_t)));
     GG_TRY(ctx->dev_alloc((void **)&dv, E * sizeof(uint32_t)));
     GG_TRY(ctx->dev_alloc((void **)&counts0, (uint64_t)(1u << bits0) * nblocks64 * sizeof(uint32_t)));
+    if (shard) {
+      GG_TRY(ctx->dev_alloc((void **)&rk, E * sizeof(uint32_t)));
+      GG_TRY(ctx->dev_alloc((void **)&rv, E * sizeof(uint32_t)));
+      GG_TRY(ctx->dev_alloc((void **)&counts0r, (uint64_t)(1u << bits0) * nblocks64 * sizeof(uint32_t)));
+    }
     GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, csr->ht, csr->ht_shift, csr->ht_cap - 1, st, su, dv, (uint32_t)bits0, nblocks64,
-              counts0);
+              ctx->c_dst.dev, E, csr->ht, csr->ht_shift, csr->ht_cap - 1, st, (uint32_t)part, (uint32_t)n_parts, su,
+              dv, rk, rv, (uint32_t)bits0, nblocks64, counts0, counts0r);
     // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
     RadixIO io{su, dv, nullptr, csr->row, csr->nbr, csr->epos};
     GG_TRY(radix_sort_stable(ctx, io, E, true, true, key_bits, counts0, bits0, kept_dev, false));
+    if (shard) {  // reverse CSR of the edges whose DESTINATION this shard owns (rowid order inside a row)
+      RadixIO ior{rk, rv, nullptr, rkey_sorted, csr->rnbr, nullptr};
+      GG_TRY(radix_sort_stable(ctx, ior, E, false, false, key_bits, counts0r, bits0, kept_rev_dev, false));
+    }
     ctx->dev_free(counts0);
+    ctx->dev_free(counts0r);
     ctx->dev_free(su);
     ctx->dev_free(dv);
+    ctx->dev_free(rk);
+    ctx->dev_free(rv);
+  }
+  if (shard) {
+    GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0,
+              rkey_sorted, (uint64_t)0, (const unsigned long long *)kept_rev_dev, V, csr->roff);
   }
   GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, csr->row,
             (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
-  GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev, st);
+  GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
+            (const uint64_t *)kept_rev_dev, st);
   if (ctx->rowid_explicit && E) {
     GG_TRY(ctx->dev_alloc((void **)&csr->eid, E * sizeof(int64_t)));
     GG_LAUNCH(ctx, "gather_rowid", k_gather_rowid, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, csr->epos,
@@ -508,16 +567,26 @@ extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) {
   memcpy(&hs, ctx->pin_scratch, sizeof(hs));
   ctx->dev_free(st);
   ctx->dev_free(kept_dev);
+  ctx->dev_free(kept_rev_dev);
+  ctx->dev_free(rkey_sorted);
   if (hs.dup_vertex) {
     set_error("vertex key column is not unique (duplicate vertex id)");
     return GG_ERR_DUPLICATE_VERTEX;
   }
   csr->ht_min_idx = hs.min_idx;
   csr->E = hs.kept;
-  csr->dropped = E - hs.kept;
+  csr->E_rev = hs.kept_rev;
+  csr->owned_vertices = hs.owned;
+  csr->dropped = shard ? 0 : E - hs.kept;  // a shard cannot tell dropped edges from other shards' edges
   guard.armed = false;
   *out = csr;
   return GG_OK;
+}
+
+extern "C" int gg_csr_build(gg_ctx *ctx, gg_csr **out) { return csr_build_impl(ctx, 0, 1, out); }
+
+extern "C" int gg_csr_build_shard(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
+  return csr_build_impl(ctx, part, n_parts, out);
 }
 
 namespace gg {

@@ -105,6 +105,9 @@ struct gg_csr {
   gg_ctx *ctx = nullptr;
   uint64_t V = 0, E = 0, dropped = 0;
   uint64_t E_cap = 0;          // allocation size of the per-edge arrays (= staged edge rows)
+  uint64_t E_rev = 0;          // entries of the reverse CSR (== E unless this is a shard)
+  uint64_t owned_vertices = 0; // vertices owned by this shard (== V unless this is a shard)
+  int part = 0, n_parts = 1;   // shard identity (gg_csr_build_shard)
   uint32_t *off = nullptr;     // V+1 row offsets
   uint32_t *nbr = nullptr;     // E   dense neighbour (destination) per entry
   uint32_t *row = nullptr;     // E   dense source per entry (COO view, sorted by source)

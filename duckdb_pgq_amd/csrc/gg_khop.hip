@@ -743,7 +743,7 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
   memset(st, 0, sizeof(*st));
   GG_TRY(ensure_reverse(ctx, csr));
   const uint64_t n_mid = mid_hi - mid_lo;
-  uint64_t M = csr->E;
+  uint64_t M = csr->E_rev;
   if (!(mid_lo == 0 && mid_hi == csr->V)) {
     uint32_t ends[2] = {0, 0};
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, csr->roff + mid_lo, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -781,7 +781,7 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
   st->rows[2] = rows2;
   st->digest[2] = dig2;
   st->traversed_edges = M + rows2;
-  st->frontier_entries = n_mid + M;
+  st->frontier_entries = (csr->n_parts > 1 ? csr->owned_vertices : n_mid) + M;
   return GG_OK;
 }
 
@@ -873,6 +873,10 @@ int check_args(gg_ctx *ctx, const gg_csr *csr, int k_min, int k_max, gg_khop_sta
     set_error("gg_expand_khop: bad context/csr/stats argument");
     return GG_ERR_INVALID_ARG;
   }
+  if (csr->n_parts > 1 && k_max != 2) {
+    set_error("a CSR shard (gg_csr_build_shard) only supports all-source 2-hop count expansion");
+    return GG_ERR_STATE;
+  }
   if (k_min < 1 || k_max < k_min || k_max > GG_MAX_HOPS) {
     set_error("gg_expand_khop: need 1 <= k_min <= k_max <= %d (got %d..%d)", GG_MAX_HOPS, k_min, k_max);
     return GG_ERR_INVALID_ARG;
@@ -902,7 +906,11 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
     memcpy(&ends[1], ctx->pin_scratch + 1, sizeof(uint32_t));
     M1 = (uint64_t)ends[1] - ends[0];
   }
-  if (k_max == 2 && src_lo == 0 && src_hi == csr->V && !ctx->force_frontier) {
+  if (csr->n_parts > 1 && (materialise || !(src_lo == 0 && src_hi == csr->V))) {
+    set_error("a CSR shard (gg_csr_build_shard) only supports all-source 2-hop count expansion");
+    return GG_ERR_STATE;
+  }
+  if (k_max == 2 && src_lo == 0 && src_hi == csr->V && (!ctx->force_frontier || csr->n_parts > 1)) {
     // every vertex is a source: the 2-hop walks are the per-vertex products in(x) x out(x)
     GG_TRY(khop_count_mid(ctx, const_cast<gg_csr *>(csr), 0, csr->V, k_min, stats));
   } else {
@@ -938,6 +946,10 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
   if (!src_ids)
     return gg_expand_khop_range(ctx, csr, 0, csr ? csr->V : 0, k_min, k_max, materialise, stats, out_result);
   GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
+  if (csr->n_parts > 1) {
+    set_error("a CSR shard (gg_csr_build_shard) only supports all-source 2-hop count expansion");
+    return GG_ERR_STATE;
+  }
   if (out_result) *out_result = nullptr;
   if (materialise && !out_result) return GG_ERR_INVALID_ARG;
   GG_HIP(hipSetDevice(ctx->device));
@@ -989,7 +1001,7 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
 }
 
 extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds) {
-  if (!ctx || !csr || n_parts < 1 || !bounds) return GG_ERR_INVALID_ARG;
+  if (!ctx || !csr || n_parts < 1 || !bounds || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
   GG_HIP(hipSetDevice(ctx->device));
   const uint64_t V = csr->V;
   bounds[0] = 0;
@@ -1037,7 +1049,7 @@ extern "C" int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uin
 }
 
 extern "C" int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds) {
-  if (!ctx || !csr || n_parts < 1 || !bounds) return GG_ERR_INVALID_ARG;
+  if (!ctx || !csr || n_parts < 1 || !bounds || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
   GG_HIP(hipSetDevice(ctx->device));
   const uint64_t V = csr->V;
   bounds[0] = 0;

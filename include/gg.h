@@ -92,6 +92,13 @@ int gg_staging_clear(gg_ctx *ctx);
  * deterministic.  Staged columns stay resident, so the build can be repeated.
  * Fails with GG_ERR_DUPLICATE_VERTEX if the vertex key column is not unique. */
 int gg_csr_build(gg_ctx *ctx, gg_csr **out);
+/* Multi-GPU sharding of the whole hot path with NO data-path collective: every rank holds the same
+ * staged base tables and builds only the CSR rows of the vertices it owns (owner = hash(vertex id)
+ * mod n_parts): forward rows of owned sources, reverse rows of owned destinations.  Non-owned edge
+ * rows are skipped before the id lookups.  gg_expand_khop(all sources, k_min..2, count) on a shard
+ * returns the walks whose MIDDLE vertex (1-hop rows: destination) is owned; over all parts the
+ * counts add and the digests add lane-wise.  Other operations reject a shard (GG_ERR_STATE). */
+int gg_csr_build_shard(gg_ctx *ctx, int part, int n_parts, gg_csr **out);
 void gg_csr_destroy(gg_csr *csr);
 int gg_csr_info(const gg_csr *csr, uint64_t *n_vertices, uint64_t *n_edges_kept, uint64_t *n_edges_dropped);
 /* Parity export.  off: V+1 entries; nbr: E_kept dense neighbour indices; eid: E_kept edge rowids

@@ -301,3 +301,42 @@ def test_khop_mid_ranges_partition_the_result(gg, orc):
         assert te == whole["traversed_edges"] and fr == whole["frontier_entries"]
     csr.close()
     g.close()
+
+
+def test_sharded_build_and_expand_add_up(gg, orc):
+    """Multi-GPU path on one GPU: every 'rank' builds only the CSR rows of the vertices it owns
+    (gg_csr_build_shard) and expands them; the shards' counts/digests add up to the whole query."""
+    from duckdb_pgq_amd import GGError
+
+    vid, src, dst = datagen.ldbc_knows(7000, 300_000, 29)
+    keep = (np.arange(src.size) % 4) != 0  # directed: in- and out-lists differ
+    src, dst = src[keep], dst[keep]
+    src = np.concatenate([src, np.array([-99, vid[0]], np.int64)])  # two dangling rows
+    dst = np.concatenate([dst, np.array([vid[1], -98], np.int64)])
+    csr, g = build_both(gg, orc, vid, src, dst)
+    whole = g.khop(1, 2)
+    assert gg.expand_khop(csr, 1, 2) == whole
+    csr.close()
+    for parts in (2, 3, 8):
+        rows = [0, 0, 0]
+        dig = [0, 0, 0]
+        te = fr = 0
+        for part in range(parts):
+            sh = gg.build_csr_shard(part, parts)
+            st = gg.expand_khop(sh, 1, 2)
+            for h in (1, 2):
+                rows[h] += st["rows"][h]
+                dig[h] = dsum(dig[h], st["digest"][h])
+            te += st["traversed_edges"]
+            fr += st["frontier_entries"]
+            if part == 0:
+                with pytest.raises(GGError):
+                    gg.bfs64(sh, vid[:2], 3)
+                with pytest.raises(GGError):
+                    gg.expand_khop(sh, 1, 3)
+                with pytest.raises(GGError):
+                    gg.expand_khop(sh, 1, 2, materialise=True)
+            sh.close()
+        assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3]
+        assert te == whole["traversed_edges"] and fr == whole["frontier_entries"]
+    g.close()
