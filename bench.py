@@ -129,6 +129,7 @@ def main():
             dist.barrier()
 
     import duckdb_pgq_amd as pkg
+    from duckdb_pgq_amd import sharding
 
     # ---- synthetic LDBC-shaped tables (identical on every rank), staged to HBM before timing -------
     t0 = time.perf_counter()
@@ -154,18 +155,7 @@ def main():
             c = gg.build_csr_shard(rank, world) if world > 1 else gg.build_csr()
         st = gg.expand_khop(c, 1, 2)
         c.close()
-        vec = [st["rows"][1], st["rows"][2], st["digest"][1], st["digest"][2], st["traversed_edges"], st["frontier_entries"]]
-        if dist is not None:
-            # 32-bit halves in int64 slots so the all-reduce never wraps; counts recombine with carry,
-            # digests are lane-wise sums (each half mod 2^32, no carry: DESIGN.md "Row digest")
-            parts = []
-            for x in vec:
-                parts += [x & 0xFFFFFFFF, x >> 32]
-            tns = torch.tensor(parts, dtype=torch.int64, device="cuda")
-            dist.all_reduce(tns)
-            p = tns.tolist()
-            vec = [((p[2 * i] & 0xFFFFFFFF) | ((p[2 * i + 1] & 0xFFFFFFFF) << 32)) if i in (2, 3)
-                   else (p[2 * i] + (p[2 * i + 1] << 32)) & MASK64 for i in range(len(vec))]
+        vec = sharding.combine(sharding.stats_to_vec(st), dist, device="cuda")
         return vec, st
 
     for _ in range(args.warmup):

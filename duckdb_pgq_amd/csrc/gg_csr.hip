@@ -54,9 +54,16 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
                                                    HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
                                                    BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool mine = i < V && owns(vid[i < V ? i : 0], part, n_parts);
-  const uint64_t om = __ballot(mine);
-  if ((threadIdx.x & 63) == 0 && om) atomicAdd(&st->owned, (unsigned long long)__popcll(om));
+  if (n_parts > 1) {  // owned-vertex count (whole builds own everything: set on the host)
+    __shared__ uint32_t s_owned;
+    if (threadIdx.x == 0) s_owned = 0;
+    __syncthreads();
+    const bool mine = i < V && owns(vid[i < V ? i : 0], part, n_parts);
+    const uint64_t om = __ballot(mine);
+    if ((threadIdx.x & 63) == 0 && om) atomicAdd(&s_owned, (uint32_t)__popcll(om));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_owned) atomicAdd(&st->owned, (unsigned long long)s_owned);
+  }
   if (i >= V) return;
   int64_t key = vid[i];
   if (key == HT_EMPTY) {  // the sentinel value itself is a legal id: keep it outside the table
@@ -576,7 +583,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   csr->ht_min_idx = hs.min_idx;
   csr->E = hs.kept;
   csr->E_rev = hs.kept_rev;
-  csr->owned_vertices = hs.owned;
+  csr->owned_vertices = shard ? hs.owned : V;
   csr->dropped = shard ? 0 : E - hs.kept;  // a shard cannot tell dropped edges from other shards' edges
   guard.armed = false;
   *out = csr;

@@ -1,0 +1,66 @@
+"""Host-side logic of the multi-GPU path (one process per GPU, torch.distributed).
+
+The data path needs no collective: every rank holds the same staged base tables and builds/expands
+only the vertices it owns (gg_csr_build_shard: owner = hash(vertex id) mod N).  What is left on the
+host is (a) the ownership function, mirrored here so tests can shard the oracle the same way, and
+(b) combining the per-rank results of one query with ONE small all-reduce.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GOLD = np.uint64(0x9E3779B97F4A7C15)
+MASK64 = (1 << 64) - 1
+MASK32 = 0xFFFFFFFF
+
+# order of the per-query result vector that ranks exchange
+FIELDS = ("rows1", "rows2", "digest1", "digest2", "traversed_edges", "frontier_entries")
+LANEWISE = (2, 3)  # digests: low and high 32-bit halves are independent sums (DESIGN.md "Row digest")
+
+
+def owner_of(ids: np.ndarray, n_parts: int) -> np.ndarray:
+    """Shard that owns each vertex id — bit-identical to `owns()` in csrc/gg_csr.hip."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64).view(np.uint64)
+    if n_parts <= 1:
+        return np.zeros(ids.shape, np.int64)
+    with np.errstate(over="ignore"):
+        h = (ids * GOLD) >> np.uint64(32)
+    return (h % np.uint64(n_parts)).astype(np.int64)
+
+
+def stats_to_vec(st: dict) -> list:
+    return [st["rows"][1], st["rows"][2], st["digest"][1], st["digest"][2], st["traversed_edges"], st["frontier_entries"]]
+
+
+def split_halves(vec) -> list:
+    """u64 values -> 32-bit halves in int64 slots, so an int64 SUM all-reduce can never wrap."""
+    out = []
+    for x in vec:
+        out += [int(x) & MASK32, int(x) >> 32]
+    return out
+
+
+def join_halves(parts) -> list:
+    vec = []
+    for i in range(len(parts) // 2):
+        lo, hi = int(parts[2 * i]), int(parts[2 * i + 1])
+        if i in LANEWISE:
+            vec.append((lo & MASK32) | ((hi & MASK32) << 32))  # no carry between the halves
+        else:
+            vec.append((lo + (hi << 32)) & MASK64)
+    return vec
+
+
+def combine(vec, dist=None, device=None) -> list:
+    """All-reduce one query's per-rank result vector (SUM over ranks)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(x) for x in vec]
+    import torch
+
+    t = torch.tensor(split_halves(vec), dtype=torch.int64, device=device or "cpu")
+    dist.all_reduce(t)
+    return join_halves(t.tolist())
+
+
+def dsum(a: int, b: int) -> int:
+    return (((a & MASK32) + (b & MASK32)) & MASK32) | ((((a >> 32) + (b >> 32)) & MASK32) << 32)

@@ -340,3 +340,19 @@ def test_sharded_build_and_expand_add_up(gg, orc):
         assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3]
         assert te == whole["traversed_edges"] and fr == whole["frontier_entries"]
     g.close()
+
+
+def test_each_shard_matches_oracle_sharded_the_same_way(gg, orc):
+    """Per-shard results (not only their sum) equal the oracle restricted by the mirrored ownership
+    function (duckdb_pgq_amd/sharding.py:owner_of == owns() in csrc/gg_csr.hip)."""
+    from tests.test_multirank_cpu import shard_stats
+
+    vid, src, dst = datagen.small_graph(120, 1500, 91, dangling=5, dup_edges=30)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    csr.close()
+    for parts in (2, 5):
+        for part in range(parts):
+            sh = gg.build_csr_shard(part, parts)
+            assert gg.expand_khop(sh, 1, 2) == shard_stats(orc, g, vid, part, parts)
+            sh.close()
+    g.close()

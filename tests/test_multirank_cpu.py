@@ -1,0 +1,99 @@
+"""world_size-2 (and 3) `gloo` tests of the N>1 path's host logic on CPU: vertex-ownership sharding +
+the single all-reduce that combines per-rank results.  The per-rank compute is the ORACLE restricted to
+the walks whose middle vertex the rank owns — the same contract gg_csr_build_shard + gg_expand_khop
+fulfil on a GPU (tests/test_gpu_parity.py::test_sharded_build_and_expand_add_up)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from duckdb_pgq_amd import datagen, sharding
+from tests import oracle_lib
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def shard_stats(orc, g, vid, part, n_parts):
+    """1..2-hop stats of the walks whose middle vertex (1-hop rows: destination) is owned by `part`."""
+    off, nbr, _, _ = g.arrays()
+    V = vid.size
+    own = sharding.owner_of(vid, n_parts) == part
+    rows = [0, 0, 0]
+    dig = [0, 0, 0]
+    for u in range(V):
+        for i in range(off[u], off[u + 1]):
+            x = int(nbr[i])
+            if not own[x]:
+                continue
+            rows[1] += 1
+            dig[1] = sharding.dsum(dig[1], orc.row_hash([u, x]))
+            for j in range(off[x], off[x + 1]):
+                rows[2] += 1
+                dig[2] = sharding.dsum(dig[2], orc.row_hash([u, x, int(nbr[j])]))
+    return {"rows": rows, "digest": dig, "traversed_edges": rows[1] + rows[2],
+            "frontier_entries": int(own.sum()) + rows[1]}
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.load()
+        vid, src, dst = datagen.small_graph(90, 700, 77, dangling=4, dup_edges=9)
+        rc, g = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        local = shard_stats(orc, g, vid, rank, world)
+        total = sharding.combine(sharding.stats_to_vec(local), dist)
+        whole = g.khop(1, 2)
+        assert total == sharding.stats_to_vec(whole), (rank, total, whole)
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == float(world)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_query_combines_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_owner_partition_and_halves():
+    vid = datagen.person_ids(10_000, 5)
+    for n in (1, 2, 8):
+        o = sharding.owner_of(vid, n)
+        assert o.min() >= 0 and o.max() < n
+        if n > 1:
+            counts = np.bincount(o, minlength=n)
+            assert counts.min() > 0.8 * vid.size / n  # hash ownership is balanced
+    vec = [2**40 + 5, 3, (2**64 - 1), 2**63 + 7, 2**35, 9]
+    assert sharding.join_halves(sharding.split_halves(vec)) == vec
+    # lane-wise digest fields never carry between halves
+    a, b = 0xFFFFFFFF_FFFFFFFF, 0x00000001_00000001
+    parts = [x + y for x, y in zip(sharding.split_halves([0, 0, a, a, 0, 0]), sharding.split_halves([0, 0, b, b, 0, 0]))]
+    assert sharding.join_halves(parts)[2] == 0
