@@ -1,0 +1,370 @@
+// gg_operators.cpp — see gg_operators.hpp.
+#include "gg_operators.hpp"
+
+#include "duckdb/common/exception.hpp"
+#include "duckdb/common/types/data_chunk.hpp"
+#include "duckdb/common/types/vector.hpp"
+#include "duckdb/main/client_context.hpp"
+
+namespace duckdb {
+
+//===--------------------------------------------------------------------===//
+// GGGraph
+//===--------------------------------------------------------------------===//
+void GGGraph::Check(int rc, const char *what) {
+	if (rc != GG_OK) {
+		throw IOException(string(what) + ": " + gg_last_error());
+	}
+}
+
+GGGraph::GGGraph(int device) {
+	Check(gg_ctx_create(device, &ctx), "gg_ctx_create");
+}
+
+GGGraph::~GGGraph() {
+	if (csr) {
+		gg_csr_destroy(csr);
+	}
+	if (ctx) {
+		gg_ctx_destroy(ctx);
+	}
+}
+
+template <class T>
+static void CopyColumn(VectorData &vdata, idx_t count, const vector<bool> &keep, vector<int64_t> &out) {
+	auto data = (const T *)vdata.data;
+	for (idx_t i = 0; i < count; i++) {
+		if (keep[i]) {
+			out.push_back((int64_t)data[vdata.sel->get_index(i)]);
+		}
+	}
+}
+
+idx_t GGExtractKeys(DataChunk &input, const vector<idx_t> &cols, vector<vector<int64_t>> &out) {
+	const idx_t count = input.size();
+	vector<VectorData> vdata(cols.size());
+	vector<bool> keep(count, true);
+	for (idx_t c = 0; c < cols.size(); c++) {
+		// inputs may be flat, constant, dictionary or sequence vectors (e.g. rowid): Orrify gives a
+		// uniform (selection, data, validity) view  (src/include/duckdb/common/types/vector.hpp:119)
+		input.data[cols[c]].Orrify(count, vdata[c]);
+		if (!vdata[c].validity.AllValid()) {
+			for (idx_t i = 0; i < count; i++) {
+				if (!vdata[c].validity.RowIsValid(vdata[c].sel->get_index(i))) {
+					keep[i] = false;
+				}
+			}
+		}
+	}
+	out.resize(cols.size());
+	idx_t kept = 0;
+	for (idx_t i = 0; i < count; i++) {
+		kept += keep[i];
+	}
+	for (idx_t c = 0; c < cols.size(); c++) {
+		out[c].clear();
+		out[c].reserve(kept);
+		switch (input.data[cols[c]].GetType().InternalType()) {
+		case PhysicalType::INT64:
+			CopyColumn<int64_t>(vdata[c], count, keep, out[c]);
+			break;
+		case PhysicalType::INT32:
+			CopyColumn<int32_t>(vdata[c], count, keep, out[c]);
+			break;
+		case PhysicalType::UINT32:
+			CopyColumn<uint32_t>(vdata[c], count, keep, out[c]);
+			break;
+		case PhysicalType::INT16:
+			CopyColumn<int16_t>(vdata[c], count, keep, out[c]);
+			break;
+		default:
+			throw NotImplementedException("GG graph operators need integer key columns");
+		}
+	}
+	return kept;
+}
+
+//===--------------------------------------------------------------------===//
+// Sinks
+//===--------------------------------------------------------------------===//
+class GGSinkGlobalState : public GlobalSinkState {
+public:
+	std::atomic<idx_t> rows {0};
+};
+
+class GGSinkLocalState : public LocalSinkState {
+public:
+	vector<vector<int64_t>> columns; // per-thread conversion buffers, reused across chunks
+};
+
+PhysicalGGVertexSink::PhysicalGGVertexSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
+                                           idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), graph(move(graph_p)) {
+}
+
+unique_ptr<GlobalSinkState> PhysicalGGVertexSink::GetGlobalSinkState(ClientContext &context) const {
+	GGGraph::Check(gg_staging_clear(graph->ctx), "gg_staging_clear");
+	return make_unique<GGSinkGlobalState>();
+}
+
+unique_ptr<LocalSinkState> PhysicalGGVertexSink::GetLocalSinkState(ExecutionContext &context) const {
+	return make_unique<GGSinkLocalState>();
+}
+
+SinkResultType PhysicalGGVertexSink::Sink(ExecutionContext &context, GlobalSinkState &gstate_p,
+                                          LocalSinkState &lstate_p, DataChunk &input) const {
+	auto &gstate = (GGSinkGlobalState &)gstate_p;
+	auto &lstate = (GGSinkLocalState &)lstate_p;
+	idx_t n = GGExtractKeys(input, {0}, lstate.columns);
+	// thread-safe append (gg.h): one call per DataChunk, like JoinHashTable::Build per Sink call
+	GGGraph::Check(gg_vertices_append(graph->ctx, lstate.columns[0].data(), n), "gg_vertices_append");
+	gstate.rows += n;
+	return SinkResultType::NEED_MORE_INPUT;
+}
+
+void PhysicalGGVertexSink::Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const {
+}
+
+SinkFinalizeType PhysicalGGVertexSink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+                                                GlobalSinkState &gstate) const {
+	return SinkFinalizeType::READY;
+}
+
+PhysicalGGEdgeSink::PhysicalGGEdgeSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
+                                       idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), graph(move(graph_p)) {
+}
+
+unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext &context) const {
+	return make_unique<GGSinkGlobalState>();
+}
+
+unique_ptr<LocalSinkState> PhysicalGGEdgeSink::GetLocalSinkState(ExecutionContext &context) const {
+	return make_unique<GGSinkLocalState>();
+}
+
+SinkResultType PhysicalGGEdgeSink::Sink(ExecutionContext &context, GlobalSinkState &gstate_p, LocalSinkState &lstate_p,
+                                        DataChunk &input) const {
+	auto &gstate = (GGSinkGlobalState &)gstate_p;
+	auto &lstate = (GGSinkLocalState &)lstate_p;
+	const bool has_rowid = input.ColumnCount() >= 3;
+	idx_t n = has_rowid ? GGExtractKeys(input, {0, 1, 2}, lstate.columns) : GGExtractKeys(input, {0, 1}, lstate.columns);
+	GGGraph::Check(gg_edges_append(graph->ctx, lstate.columns[0].data(), lstate.columns[1].data(),
+	                               has_rowid ? lstate.columns[2].data() : nullptr, n),
+	               "gg_edges_append");
+	gstate.rows += n;
+	return SinkResultType::NEED_MORE_INPUT;
+}
+
+void PhysicalGGEdgeSink::Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const {
+}
+
+SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+                                              GlobalSinkState &gstate) const {
+	// single-threaded, after every Sink/Combine (physical_operator.hpp:145-147): build the index
+	lock_guard<mutex> guard(graph->lock);
+	if (graph->csr) {
+		gg_csr_destroy(graph->csr);
+		graph->csr = nullptr;
+	}
+	GGGraph::Check(gg_csr_build(graph->ctx, &graph->csr), "gg_csr_build");
+	return SinkFinalizeType::READY;
+}
+
+//===--------------------------------------------------------------------===//
+// Path expansion source
+//===--------------------------------------------------------------------===//
+class GGExpandGlobalState : public GlobalSourceState {
+public:
+	~GGExpandGlobalState() override {
+		if (result) {
+			gg_result_destroy(result);
+		}
+	}
+	idx_t MaxThreads() override {
+		return max_threads;
+	}
+
+	gg_khop_stats stats;
+	gg_result *result = nullptr;
+	// scan position: (current hop length, row offset inside it); GetData claims slices under the lock
+	mutex lock;
+	int hop = 0;
+	idx_t offset = 0;
+	idx_t max_threads = 1;
+};
+
+vector<LogicalType> PhysicalGGPathExpand::OutputTypes(int k_max, bool count_only) {
+	vector<LogicalType> types;
+	types.push_back(LogicalType::INTEGER);
+	if (count_only) {
+		types.push_back(LogicalType::BIGINT);
+		types.push_back(LogicalType::BIGINT);
+		types.push_back(LogicalType::BIGINT);
+	} else {
+		for (int c = 0; c <= k_max; c++) {
+			types.push_back(LogicalType::BIGINT);
+		}
+	}
+	return types;
+}
+
+PhysicalGGPathExpand::PhysicalGGPathExpand(shared_ptr<GGGraph> graph_p, int k_min_p, int k_max_p, bool count_only_p,
+                                           vector<int64_t> sources_p, bool all_sources_p,
+                                           idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, OutputTypes(k_max_p, count_only_p), estimated_cardinality),
+      graph(move(graph_p)), k_min(k_min_p), k_max(k_max_p), count_only(count_only_p), sources(move(sources_p)),
+      all_sources(all_sources_p) {
+}
+
+unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientContext &context) const {
+	auto state = make_unique<GGExpandGlobalState>();
+	lock_guard<mutex> guard(graph->lock);
+	if (!graph->csr) {
+		throw InternalException("GG_PATH_EXPAND scheduled before the CSR was built");
+	}
+	GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(), k_min,
+	                              k_max, count_only ? 0 : 1, &state->stats, count_only ? nullptr : &state->result),
+	               "gg_expand_khop");
+	state->hop = k_min;
+	idx_t total = 0;
+	for (int h = k_min; h <= k_max; h++) {
+		total += state->stats.rows[h];
+	}
+	state->max_threads = count_only ? 1 : MaxValue<idx_t>(1, total / (STANDARD_VECTOR_SIZE * 64));
+	return move(state);
+}
+
+void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
+                                   LocalSourceState &lstate) const {
+	auto &gstate = (GGExpandGlobalState &)gstate_p;
+	if (count_only) {
+		lock_guard<mutex> guard(gstate.lock);
+		if (gstate.hop > k_max) {
+			return; // empty chunk: exhausted (pipeline_executor.cpp:55-58)
+		}
+		idx_t n = 0;
+		for (int h = gstate.hop; h <= k_max; h++, n++) {
+			FlatVector::GetData<int32_t>(chunk.data[0])[n] = h;
+			FlatVector::GetData<int64_t>(chunk.data[1])[n] = (int64_t)gstate.stats.rows[h];
+			FlatVector::GetData<int64_t>(chunk.data[2])[n] = (int64_t)gstate.stats.digest[h];
+			FlatVector::GetData<int64_t>(chunk.data[3])[n] = (int64_t)gstate.stats.traversed_edges;
+		}
+		gstate.hop = k_max + 1;
+		chunk.SetCardinality(n);
+		return;
+	}
+	// claim the next <=1024-row slice of the current hop-length table
+	int hop;
+	idx_t offset;
+	{
+		lock_guard<mutex> guard(gstate.lock);
+		while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
+			gstate.hop++;
+			gstate.offset = 0;
+		}
+		if (gstate.hop > k_max) {
+			return;
+		}
+		hop = gstate.hop;
+		offset = gstate.offset;
+		gstate.offset += STANDARD_VECTOR_SIZE;
+	}
+	if (context.client.interrupted) { // cancellation is polled between device calls
+		throw InterruptException();
+	}
+	int64_t *cols[GG_MAX_HOPS + 1];
+	for (int c = 0; c <= hop; c++) {
+		cols[c] = FlatVector::GetData<int64_t>(chunk.data[1 + c]); // flat vectors, written in place
+	}
+	uint32_t n = 0;
+	{
+		lock_guard<mutex> guard(graph->lock);
+		GGGraph::Check(gg_result_fetch(gstate.result, hop, offset, STANDARD_VECTOR_SIZE, cols, &n), "gg_result_fetch");
+	}
+	auto hops = FlatVector::GetData<int32_t>(chunk.data[0]);
+	for (uint32_t i = 0; i < n; i++) {
+		hops[i] = hop;
+	}
+	for (int c = hop + 1; c <= k_max; c++) { // shorter walks: trailing vertices are NULL
+		chunk.data[1 + c].SetVectorType(VectorType::CONSTANT_VECTOR);
+		ConstantVector::SetNull(chunk.data[1 + c], true);
+	}
+	chunk.SetCardinality(n);
+}
+
+//===--------------------------------------------------------------------===//
+// Shortest path source
+//===--------------------------------------------------------------------===//
+class GGShortestGlobalState : public GlobalSourceState {
+public:
+	vector<int64_t> start, frnd;
+	vector<int32_t> hop;
+	idx_t offset = 0;
+};
+
+PhysicalGGShortestPath::PhysicalGGShortestPath(shared_ptr<GGGraph> graph_p, vector<int64_t> sources_p,
+                                               int max_hops_p, idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID,
+                       {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER}, estimated_cardinality),
+      graph(move(graph_p)), sources(move(sources_p)), max_hops(max_hops_p) {
+}
+
+unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(ClientContext &context) const {
+	auto state = make_unique<GGShortestGlobalState>();
+	lock_guard<mutex> guard(graph->lock);
+	if (!graph->csr) {
+		throw InternalException("GG_SHORTEST_PATH scheduled before the CSR was built");
+	}
+	uint64_t V = 0;
+	GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
+	vector<int64_t> vid(V);
+	GGGraph::Check(gg_csr_export(graph->csr, nullptr, nullptr, nullptr, vid.data()), "gg_csr_export");
+	// UNION semantics: a source listed twice yields its rows once
+	vector<int64_t> uniq;
+	{
+		unordered_set<int64_t> seen;
+		for (auto s : sources) {
+			if (seen.insert(s).second) {
+				uniq.push_back(s);
+			}
+		}
+	}
+	vector<int32_t> dist;
+	for (idx_t base = 0; base < uniq.size(); base += GG_BFS_LANES) { // 64 bit lanes per batch
+		if (context.interrupted) {
+			throw InterruptException();
+		}
+		int n = (int)MinValue<idx_t>(GG_BFS_LANES, uniq.size() - base);
+		dist.resize((size_t)n * V);
+		GGGraph::Check(gg_bfs64(graph->ctx, graph->csr, uniq.data() + base, n, max_hops, nullptr, 0, dist.data(), nullptr),
+		               "gg_bfs64");
+		for (int i = 0; i < n; i++) {
+			for (uint64_t v = 0; v < V; v++) {
+				int32_t d = dist[(size_t)i * V + v];
+				if (d >= 0) {
+					state->start.push_back(uniq[base + i]);
+					state->frnd.push_back(vid[v]);
+					state->hop.push_back(d);
+				}
+			}
+		}
+	}
+	return move(state);
+}
+
+void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
+                                     LocalSourceState &lstate) const {
+	auto &gstate = (GGShortestGlobalState &)gstate_p;
+	idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.start.size() - gstate.offset);
+	if (n == 0) {
+		return;
+	}
+	memcpy(FlatVector::GetData<int64_t>(chunk.data[0]), gstate.start.data() + gstate.offset, n * sizeof(int64_t));
+	memcpy(FlatVector::GetData<int64_t>(chunk.data[1]), gstate.frnd.data() + gstate.offset, n * sizeof(int64_t));
+	memcpy(FlatVector::GetData<int32_t>(chunk.data[2]), gstate.hop.data() + gstate.offset, n * sizeof(int32_t));
+	gstate.offset += n;
+	chunk.SetCardinality(n);
+}
+
+} // namespace duckdb

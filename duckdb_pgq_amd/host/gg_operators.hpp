@@ -1,0 +1,154 @@
+// gg_operators.hpp — DuckDB physical operators backed by the MI355X graph kernels (libgg.so).
+//
+// Host side of the drop-in: these classes implement the reference's own operator interface
+// (src/include/duckdb/execution/physical_operator.hpp:24-165 in cwida/duckdb-pgq.old) and call the
+// C-ABI of include/gg.h where the reference's operators call their CPU data structures:
+//
+//   PhysicalGGVertexSink / PhysicalGGEdgeSink   <->  PhysicalHashJoin::Sink/Combine/Finalize
+//        (src/execution/operator/join/physical_hash_join.cpp:128-185): the "build side" of the
+//        adjacency index; Sink is called concurrently from the pipeline's worker threads with
+//        <=1024-row DataChunks, Finalize once.
+//   PhysicalGGPathExpand                         <->  the chain of PhysicalHashJoin::Execute probes
+//        (physical_hash_join.cpp:217-254) of a k-hop pattern; a source that emits the walks.
+//   PhysicalGGShortestPath                       <->  PhysicalRecursiveCTE + min(hop) aggregate
+//        (src/execution/operator/set/physical_recursive_cte.cpp:48-139) for the bi-10 friends CTE.
+//
+// Compiled against the reference's headers; duckdb symbols are resolved by the hosting libduckdb at
+// load time (the library is loaded as an extension: gg_duckdb_extension.cpp).
+#pragma once
+
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "duckdb.hpp"
+#include "duckdb/execution/physical_operator.hpp"
+#include "gg.h"
+
+namespace duckdb {
+
+//! Device graph shared by the sinks that build it and the sources that query it.
+struct GGGraph {
+	explicit GGGraph(int device);
+	~GGGraph();
+	//! Turn a non-zero gg status into the exception the reference's operators would throw.
+	static void Check(int rc, const char *what);
+
+	gg_ctx *ctx = nullptr;
+	gg_csr *csr = nullptr;
+	std::mutex lock; // gg calls other than the appends are externally serialised (gg.h)
+};
+
+//! Copy one integer key column of a chunk into `out` (BIGINT or INTEGER physical type, any vector
+//! type via Orrify); rows whose key is NULL in ANY of the given columns are skipped, as
+//! JoinHashTable::PrepareKeys does for join keys (src/execution/join_hashtable.cpp:126-148).
+idx_t GGExtractKeys(DataChunk &input, const vector<idx_t> &cols, vector<vector<int64_t>> &out);
+
+class PhysicalGGVertexSink : public PhysicalOperator {
+public:
+	PhysicalGGVertexSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality);
+
+	shared_ptr<GGGraph> graph;
+
+public:
+	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
+	unique_ptr<LocalSinkState> GetLocalSinkState(ExecutionContext &context) const override;
+	SinkResultType Sink(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate,
+	                    DataChunk &input) const override;
+	void Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const override;
+	SinkFinalizeType Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+	                          GlobalSinkState &gstate) const override;
+	bool IsSink() const override {
+		return true;
+	}
+	bool ParallelSink() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_VERTEX_SINK";
+	}
+};
+
+//! Input columns: (source key, destination key[, edge rowid]).  Finalize builds the CSR.
+class PhysicalGGEdgeSink : public PhysicalOperator {
+public:
+	PhysicalGGEdgeSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality);
+
+	shared_ptr<GGGraph> graph;
+
+public:
+	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
+	unique_ptr<LocalSinkState> GetLocalSinkState(ExecutionContext &context) const override;
+	SinkResultType Sink(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate,
+	                    DataChunk &input) const override;
+	void Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const override;
+	SinkFinalizeType Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+	                          GlobalSinkState &gstate) const override;
+	bool IsSink() const override {
+		return true;
+	}
+	bool ParallelSink() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_EDGE_SINK";
+	}
+};
+
+//! Source: walks of length k_min..k_max.  Output: (hops INTEGER, v0 BIGINT, ..., v{k_max} BIGINT),
+//! trailing vertices NULL for shorter walks.  count_only: (hops INTEGER, rows BIGINT, digest BIGINT,
+//! traversed_edges BIGINT), one row per length.
+class PhysicalGGPathExpand : public PhysicalOperator {
+public:
+	PhysicalGGPathExpand(shared_ptr<GGGraph> graph, int k_min, int k_max, bool count_only, vector<int64_t> sources,
+	                     bool all_sources, idx_t estimated_cardinality);
+
+	static vector<LogicalType> OutputTypes(int k_max, bool count_only);
+
+	shared_ptr<GGGraph> graph;
+	int k_min, k_max;
+	bool count_only;
+	vector<int64_t> sources;
+	bool all_sources;
+
+public:
+	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
+	             LocalSourceState &lstate) const override;
+	bool IsSource() const override {
+		return true;
+	}
+	bool ParallelSource() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_PATH_EXPAND";
+	}
+};
+
+//! Source: (startPerson BIGINT, friend BIGINT, hopCount INTEGER) for every pair reached within
+//! max_hops — the friends_shortest relation of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31.
+//! Sources are processed in batches of 64 bit lanes.
+class PhysicalGGShortestPath : public PhysicalOperator {
+public:
+	PhysicalGGShortestPath(shared_ptr<GGGraph> graph, vector<int64_t> sources, int max_hops,
+	                       idx_t estimated_cardinality);
+
+	shared_ptr<GGGraph> graph;
+	vector<int64_t> sources;
+	int max_hops;
+
+public:
+	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
+	             LocalSourceState &lstate) const override;
+	bool IsSource() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_SHORTEST_PATH";
+	}
+};
+
+} // namespace duckdb

@@ -1,0 +1,67 @@
+"""Drop-in test: the compiled reference (oracle/_ref/libduckdb.so) LOADs our extension and runs the GPU
+operators next to its own CPU operators on the SAME tables in the SAME database; results must be equal
+as sorted relations.  Needs the prebuilt extension (built where /root/reference exists) and a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from duckdb_pgq_amd import datagen
+from oracle import ref_duckdb as R
+from tests.oracle_lib import sort_rows
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXT = os.path.join(ROOT, "duckdb_pgq_amd", "gg_duckdb.duckdb_extension")
+
+pytestmark = [
+    pytest.mark.gpu,
+    pytest.mark.skipif(not (R.available() and os.path.exists(EXT)), reason="reference build / extension not present"),
+]
+
+GRAPH = "'person', 'p_personid', 'knows', 'k_person1id', 'k_person2id'"
+
+
+@pytest.fixture(scope="module")
+def db():
+    vid, src, dst = datagen.ldbc_knows(1500, 40_000, 0xD0C)
+    # a few dangling edge rows and a NULL-free but non-person id
+    src = np.concatenate([src, np.array([-5, vid[3]], np.int64)])
+    dst = np.concatenate([dst, np.array([vid[2], -6], np.int64)])
+    d = R.RefDuckDB(threads=4)
+    d.load_ldbc(vid, src, dst)
+    d.execute(f"LOAD '{EXT}'")
+    yield d, vid
+    d.close()
+
+
+def test_khop_count_matches_reference_joins(db):
+    d, _ = db
+    got = d.execute(f"SELECT hops, rows FROM gg_khop_count({GRAPH}, 1, 3) ORDER BY hops")
+    for hops, rows in got.tolist():
+        assert rows == int(d.execute(R.sql_khop(hops))[0, 0])
+
+
+def test_khop_rows_match_reference_joins(db):
+    d, _ = db
+    got = d.execute(f"SELECT hops, v0, v1, v2 FROM gg_khop({GRAPH}, 1, 2)")
+    one = got[got[:, 0] == 1][:, 1:3]
+    two = got[got[:, 0] == 2][:, 1:4]
+    assert np.array_equal(sort_rows(one), sort_rows(d.execute(R.sql_khop_rows(1))))
+    assert np.array_equal(sort_rows(two), sort_rows(d.execute(R.sql_khop_rows(2))))
+    # the function composes with ordinary SQL (aggregation on top of the GPU source)
+    agg = d.execute(f"SELECT v0, count(*) FROM gg_khop({GRAPH}, 2, 2) GROUP BY v0 ORDER BY v0")
+    ref = d.execute("SELECT p0.p_personid, count(*) FROM (" + R.sql_khop_rows(2).replace("SELECT", "SELECT p0.p_personid AS pid,", 1)
+                    + ") t, person p0 WHERE t.pid = p0.p_personid GROUP BY p0.p_personid ORDER BY 1") if False else None
+    two_ref = d.execute(R.sql_khop_rows(2))
+    u, c = np.unique(two_ref[:, 0], return_counts=True)
+    assert np.array_equal(agg, np.stack([u, c], axis=1))
+
+
+def test_shortest_path_matches_recursive_cte(db):
+    d, vid = db
+    sources = datagen.pick_sources(vid, 70, 3)  # > 64: two bit-lane batches
+    src_sql = "SELECT p_personid FROM person WHERE p_personid IN (" + ", ".join(str(int(s)) for s in sources) + ")"
+    for max_hops in (1, 3):
+        got = d.execute(f"SELECT * FROM gg_shortest_path({GRAPH}, '{src_sql}', {max_hops})")
+        ref = d.execute(R.sql_shortest(sources, max_hops))
+        assert np.array_equal(sort_rows(got), sort_rows(ref))
