@@ -50,8 +50,6 @@ def test_khop_rows_match_reference_joins(db):
     assert np.array_equal(sort_rows(two), sort_rows(d.execute(R.sql_khop_rows(2))))
     # the function composes with ordinary SQL (aggregation on top of the GPU source)
     agg = d.execute(f"SELECT v0, count(*) FROM gg_khop({GRAPH}, 2, 2) GROUP BY v0 ORDER BY v0")
-    ref = d.execute("SELECT p0.p_personid, count(*) FROM (" + R.sql_khop_rows(2).replace("SELECT", "SELECT p0.p_personid AS pid,", 1)
-                    + ") t, person p0 WHERE t.pid = p0.p_personid GROUP BY p0.p_personid ORDER BY 1") if False else None
     two_ref = d.execute(R.sql_khop_rows(2))
     u, c = np.unique(two_ref[:, 0], return_counts=True)
     assert np.array_equal(agg, np.stack([u, c], axis=1))
