@@ -7,11 +7,19 @@
 //       table, probe it with the working table, dedupe whole tuples in a GroupedAggregateHashTable)
 //   GroupedAggregateHashTable::FindOrCreateGroups   src/execution/aggregate_hashtable.cpp:367-504
 //   PhysicalHashAggregate (min)                     src/execution/operator/aggregate/physical_hash_aggregate.cpp:152-266
-// Here each of up to 64 sources owns one bit lane of a uint64 per vertex; one level is
-//   k_bfs_compact  frontier words -> active-vertex list (__ballot + popcount compaction), level stats
-//   k_bfs_expand   wavefront per active vertex: coalesced CSR row read, 8-byte OR into next[w]
-//                  (skipped when the neighbour has already seen every lane in the word)
-//   k_bfs_update   new = next & ~seen; seen |= new; dist[lane][v] = level for each new bit
+// Here each of up to 64 sources owns one bit lane of a uint64 per vertex.  A level runs in one of two
+// directions, chosen from the frontier's edge count (both give identical bits):
+//   push (light frontier)  k_bfs_compact: frontier words -> active-vertex list (__ballot + popcount)
+//                          k_bfs_push:    wavefront per active vertex, coalesced CSR row read, 8-byte OR
+//                                         into next[w] only for lanes w has not seen
+//                          k_bfs_update:  new = next & ~seen; seen |= new; distances; next frontier + stats
+//   pull (heavy frontier)  k_bfs_pull:    wavefront per vertex w that still misses lanes: OR of
+//                                         frontier[v] over the in-neighbours (reverse CSR, coalesced row
+//                                         read + 8-byte gathers from the V-sized, L2-resident frontier),
+//                                         no atomics; writes the next frontier, seen, distances and the
+//                                         next level's stats in the same pass
+// Distances live as one byte per (vertex, lane) — 64 contiguous bytes per vertex — and are widened to the
+// API's int32 [lane][vertex] layout only when fetched.
 // The CSR is built once and reused by every level (the reference rebuilds its hash table per level,
 // SURVEY.md F4).  Algorithmic bytes per level: 8V + 16Va + 24*TE_level (+ 24V update) — SURVEY §8d.
 #include "gg_internal.h"
@@ -20,49 +28,107 @@ using namespace gg;
 
 namespace gg {
 
-struct BfsLevel {  // device counters for one level
+struct BfsLevel {  // device counters describing the NEXT frontier
   unsigned long long n_active;
   unsigned long long te;
   unsigned long long reached;
 };
 
-__global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ src_dense, int n_src, uint64_t V,
-                                                 uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
-                                                 int32_t *__restrict__ dist, BfsLevel *__restrict__ lv) {
-  const int i = threadIdx.x;
-  if (i >= n_src) return;
-  const uint32_t v = src_dense[i];
-  if (v == INVALID_U32) return;
-  atomicOr((unsigned long long *)&frontier[v], 1ULL << i);
-  atomicOr((unsigned long long *)&seen[v], 1ULL << i);
-  dist[(uint64_t)i * V + v] = 0;
-  atomicAdd(&lv->reached, 1ULL);
+// Distance cells are DistT (uint8_t, or uint16_t for BFS deeper than 254 levels), 64 per vertex,
+// contiguous.  A vertex's newly reached lanes are written by composing whole 8-byte words.
+template <typename DistT>
+__device__ __forceinline__ void write_dist(uint64_t *__restrict__ dist /* [V][64] DistT */, uint64_t v, uint64_t nw,
+                                           uint32_t level) {
+  constexpr int PER_WORD = 8 / (int)sizeof(DistT);     // lanes per 8-byte word
+  constexpr int WORDS = 64 / PER_WORD;
+  constexpr uint64_t CELL = sizeof(DistT) == 1 ? 0xFFULL : 0xFFFFULL;
+  uint64_t *d = dist + v * WORDS;
+#pragma unroll
+  for (int k = 0; k < WORDS; k++) {
+    const uint32_t b = (uint32_t)(nw >> (PER_WORD * k)) & ((1u << PER_WORD) - 1u);
+    if (b) {
+      uint64_t m = 0, val = 0;
+#pragma unroll
+      for (int i = 0; i < PER_WORD; i++) {
+        m |= ((b >> i) & 1u) ? (CELL << (8 * sizeof(DistT) * i)) : 0ULL;
+        val |= (uint64_t)level << (8 * sizeof(DistT) * i);
+      }
+      d[k] = (d[k] & ~m) | (val & m);  // cells are written at most once (first level that reaches them)
+    }
+  }
+}
+
+// block-aggregate (n_active, te, reached) and add to the level counters with three atomics per block
+__device__ __forceinline__ void add_level_stats(uint64_t act, uint64_t te, uint64_t reached, uint64_t *s_red /*12*/,
+                                                BfsLevel *__restrict__ lv) {
+  act = wave_reduce_add_u64(act);
+  te = wave_reduce_add_u64(te);
+  reached = wave_reduce_add_u64(reached);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_red[wave * 3] = act;
+    s_red[wave * 3 + 1] = te;
+    s_red[wave * 3 + 2] = reached;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const uint64_t s = s_red[threadIdx.x] + s_red[3 + threadIdx.x] + s_red[6 + threadIdx.x] + s_red[9 + threadIdx.x];
+    if (s) atomicAdd(threadIdx.x == 0 ? &lv->n_active : (threadIdx.x == 1 ? &lv->te : &lv->reached),
+                     (unsigned long long)s);
+  }
+}
+
+template <typename DistT>
+__global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ src_dense, int n_src,
+                                                 const uint32_t *__restrict__ off, uint64_t *__restrict__ frontier,
+                                                 uint64_t *__restrict__ seen, uint64_t *__restrict__ dist8,
+                                                 BfsLevel *__restrict__ lv) {
+  // serial over the (<= 64) sources so that a vertex seeded by several lanes is counted once
+  if (threadIdx.x != 0) return;
+  unsigned long long act = 0, te = 0, reached = 0;
+  for (int i = 0; i < n_src; i++) {
+    const uint32_t v = src_dense[i];
+    if (v == INVALID_U32) continue;
+    if (frontier[v] == 0) {
+      act++;
+      te += off[v + 1] - off[v];
+    }
+    frontier[v] |= 1ULL << i;
+    seen[v] |= 1ULL << i;
+    reinterpret_cast<DistT *>(dist8)[(uint64_t)v * 64 + i] = 0;
+    reached++;
+  }
+  lv->n_active = act;
+  lv->te = te;
+  lv->reached = reached;
 }
 
 __global__ __launch_bounds__(256) void k_bfs_compact(const uint64_t *__restrict__ frontier, uint64_t V,
-                                                     const uint32_t *__restrict__ off, uint32_t *__restrict__ active,
-                                                     BfsLevel *__restrict__ lv) {
+                                                     uint32_t *__restrict__ active,
+                                                     unsigned long long *__restrict__ cursor) {
+  __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_base;
   const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = v < V && frontier[v] != 0;
   const uint64_t m = __ballot(on);
-  if (m == 0) return;
-  const int lane = threadIdx.x & 63;
-  uint64_t deg = on ? (uint64_t)(off[v + 1] - off[v]) : 0;
-  deg = wave_reduce_add_u64(deg);
-  uint64_t base = 0;
-  if (lane == 0) {
-    base = atomicAdd(&lv->n_active, (unsigned long long)__popcll(m));
-    atomicAdd(&lv->te, (unsigned long long)deg);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? (uint32_t)atomicAdd(cursor, (unsigned long long)tot) : 0;  // one atomic per block
   }
-  base = __shfl(base, 0, 64);
-  if (on) active[base + __popcll(m & ((1ULL << lane) - 1ULL))] = (uint32_t)v;
+  __syncthreads();
+  uint32_t wbase = s_base;
+  for (int w = 0; w < wave; w++) wbase += s_cnt[w];
+  if (on) active[wbase + __popcll(m & ((1ULL << lane) - 1ULL))] = (uint32_t)v;
 }
 
-// a wavefront per active vertex (grid-strided)
-__global__ __launch_bounds__(256) void k_bfs_expand(const uint32_t *__restrict__ active, uint64_t n_active,
-                                                    const uint64_t *__restrict__ frontier,
-                                                    const uint64_t *__restrict__ seen, const uint32_t *__restrict__ off,
-                                                    const uint32_t *__restrict__ nbr, uint64_t *__restrict__ next) {
+// push: a wavefront per active vertex (grid-strided)
+__global__ __launch_bounds__(256) void k_bfs_push(const uint32_t *__restrict__ active, uint64_t n_active,
+                                                  const uint64_t *__restrict__ frontier,
+                                                  const uint64_t *__restrict__ seen, const uint32_t *__restrict__ off,
+                                                  const uint32_t *__restrict__ nbr, uint64_t *__restrict__ next) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -78,52 +144,93 @@ __global__ __launch_bounds__(256) void k_bfs_expand(const uint32_t *__restrict__
   }
 }
 
+// after a push: fold `next` into the new frontier
+template <typename DistT>
 __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
-                                                    uint64_t *__restrict__ next, uint64_t V, int level,
-                                                    int32_t *__restrict__ dist, BfsLevel *__restrict__ lv) {
+                                                    uint64_t *__restrict__ next, uint64_t V, uint32_t level,
+                                                    const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
+                                                    BfsLevel *__restrict__ lv) {
+  __shared__ uint64_t s_red[12];
   const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t nw = 0;
+  uint64_t nw = 0, te = 0;
   if (v < V) {
     const uint64_t s = seen[v];
     nw = next[v] & ~s;
     next[v] = 0;
     frontier[v] = nw;
-    if (nw) seen[v] = s | nw;
+    if (nw) {
+      seen[v] = s | nw;
+      write_dist<DistT>(dist8, v, nw, level);
+      te = off[v + 1] - off[v];
+    }
   }
-  uint64_t cnt = (uint64_t)__popcll(nw);
-  uint64_t bits = nw;
-  while (bits) {
-    const int b = __ffsll((long long)bits) - 1;
-    bits &= bits - 1;
-    dist[(uint64_t)b * V + v] = level;
-  }
-  cnt = wave_reduce_add_u64(cnt);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&lv->reached, (unsigned long long)cnt);
+  add_level_stats(nw ? 1 : 0, te, (uint64_t)__popcll(nw), s_red, lv);
 }
 
-__global__ __launch_bounds__(256) void k_bfs_gather(const int32_t *__restrict__ dist, uint64_t V, int n_src,
-                                                    const uint32_t *__restrict__ dst_dense, uint64_t n_dst,
-                                                    int32_t *__restrict__ out) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (uint64_t)n_src * n_dst) return;
-  const uint64_t s = i / n_dst, j = i % n_dst;
-  const uint32_t d = dst_dense[j];
-  out[i] = d == INVALID_U32 ? -1 : dist[s * V + d];
+// pull: a wavefront per vertex (grid-strided); reads fin, writes fout (ping-pong frontiers)
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
+                                                  uint64_t *__restrict__ seen, uint64_t V, uint32_t level,
+                                                  const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
+                                                  const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
+                                                  BfsLevel *__restrict__ lv) {
+  __shared__ uint64_t s_red[12];
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  uint64_t act = 0, te = 0, reached = 0;  // accumulated by lane 0 of each wave
+  for (uint64_t w = wave0; w < V; w += nwaves) {
+    const uint64_t s = seen[w];
+    uint64_t nw = 0;
+    if (~s) {  // some lane still missing at w
+      uint64_t acc = 0;
+      const uint32_t b = roff[w], e = roff[w + 1];
+      for (uint32_t i = b + lane; i < e; i += 64) acc |= fin[rnbr[i]];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);
+      nw = acc & ~s;
+    }
+    if (lane == 0) {
+      fout[w] = nw;
+      if (nw) {
+        seen[w] = s | nw;
+        write_dist<DistT>(dist8, w, nw, level);
+        act += 1;
+        te += off[w + 1] - off[w];
+        reached += (uint64_t)__popcll(nw);
+      }
+    }
+  }
+  add_level_stats(act, te, reached, s_red, lv);
+}
+
+// dist [V][64] cells -> out int32 [n_src][n_out] (targets: all vertices, or a dense target list)
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_widen(const DistT *__restrict__ dist8, uint64_t V, int n_src,
+                                                   const uint32_t *__restrict__ dst_dense /* nullable */,
+                                                   uint64_t n_out, int32_t *__restrict__ out) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_out) return;
+  const uint32_t d = dst_dense ? dst_dense[j] : (uint32_t)j;
+  for (int s = 0; s < n_src; s++) {
+    int32_t val = -1;
+    if (d != INVALID_U32) {
+      const DistT b = dist8[(uint64_t)d * 64 + s];
+      val = b == (DistT)~(DistT)0 ? -1 : (int32_t)b;
+    }
+    out[(uint64_t)s * n_out + j] = val;  // coalesced across j
+  }
 }
 
 }  // namespace gg
 
-extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
-                        const int64_t *dst_ids, uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats) {
-  if (!ctx || !csr || csr->ctx != ctx || !out_dist || n_src < 0 || n_src > GG_BFS_LANES || (n_src && !src_ids) ||
-      (n_dst && !dst_ids)) {
-    set_error("gg_bfs64: bad argument (n_src must be 0..%d)", GG_BFS_LANES);
-    return GG_ERR_INVALID_ARG;
-  }
-  if (csr->n_parts > 1) {
-    set_error("gg_bfs64 needs a whole CSR, not a shard");
-    return GG_ERR_STATE;
-  }
+// One BFS with DistT distance cells.  *overflow is set (and nothing is returned) if the frontier is
+// still non-empty at the deepest level DistT can record.
+template <typename DistT>
+static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops, const int64_t *dst_ids,
+                   uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats, bool *overflow) {
+  constexpr int MAX_LEVEL = sizeof(DistT) == 1 ? 254 : 65534;
+  *overflow = false;
   GG_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const uint64_t V = csr->V;
@@ -135,99 +242,104 @@ extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, 
     return GG_OK;
   }
   if (V == 0) {
-    for (uint64_t i = 0; i < (uint64_t)n_src * n_out; i++) out_dist[i] = -1;
+    for (uint64_t i = 0; out_dist && i < (uint64_t)n_src * n_out; i++) out_dist[i] = -1;
     if (stats) *stats = st;
     return GG_OK;
   }
 
   int64_t *ids_dev = nullptr;
   uint32_t *src_dense = nullptr, *active = nullptr;
-  uint64_t *frontier = nullptr, *seen = nullptr, *next = nullptr;
-  int32_t *dist = nullptr;
+  uint64_t *fa = nullptr, *fb = nullptr, *seen = nullptr, *dist8 = nullptr;
   BfsLevel *lv = nullptr;
+  unsigned long long *cursor = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&ids_dev, GG_BFS_LANES * sizeof(int64_t)));
   GG_TRY(ctx->dev_alloc((void **)&src_dense, GG_BFS_LANES * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&active, V * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&frontier, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&fa, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&fb, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&seen, V * sizeof(uint64_t)));
-  GG_TRY(ctx->dev_alloc((void **)&next, V * sizeof(uint64_t)));
-  GG_TRY(ctx->dev_alloc((void **)&dist, (uint64_t)n_src * V * sizeof(int32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&dist8, V * 64 * sizeof(DistT)));
   GG_TRY(ctx->dev_alloc((void **)&lv, sizeof(BfsLevel)));
+  GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
 
   GG_HIP(hipMemcpyAsync(ids_dev, src_ids, (size_t)n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
   GG_HIP(hipStreamSynchronize(s));
   GG_TRY(lookup_ids(ctx, csr, ids_dev, (uint64_t)n_src, src_dense));
-  GG_HIP(hipMemsetAsync(frontier, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(fa, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(fb, 0, V * sizeof(uint64_t), s));  // doubles as the push direction's `next`
   GG_HIP(hipMemsetAsync(seen, 0, V * sizeof(uint64_t), s));
-  GG_HIP(hipMemsetAsync(next, 0, V * sizeof(uint64_t), s));
-  GG_HIP(hipMemsetAsync(dist, 0xFF, (uint64_t)n_src * V * sizeof(int32_t), s));
-  GG_HIP(hipMemsetAsync(lv, 0, sizeof(BfsLevel), s));
-  GG_LAUNCH(ctx, "bfs_seed", k_bfs_seed, dim3(1), dim3(64), 0, src_dense, n_src, V, frontier, seen, dist, lv);
+  GG_HIP(hipMemsetAsync(dist8, 0xFF, V * 64 * sizeof(DistT), s));
+  GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<DistT>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, fa, seen, dist8, lv);
 
   const unsigned vgrid = (unsigned)((V + 255) / 256);
+  const uint64_t max_waves = (uint64_t)ctx->num_cus * 32;  // one resident set; grid-stride the rest
+  uint64_t *front = fa, *other = fb;  // `other` is all-zero whenever a level starts
   int level = 0;
   uint64_t reached = 0;
-  while (max_hops < 0 || level < max_hops) {
-    // active list of this level + its stats; the host needs n_active to size the expand launch
-    GG_LAUNCH(ctx, "bfs_compact", k_bfs_compact, dim3(vgrid), dim3(256), 0, frontier, V, csr->off, active, lv);
+  while (true) {
+    // stats of the current frontier (written by the seed / previous level); one small read per level
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, lv, sizeof(BfsLevel), hipMemcpyDeviceToHost, s));
     GG_HIP(hipStreamSynchronize(s));
     BfsLevel h;
     memcpy(&h, ctx->pin_scratch, sizeof(h));
     reached = h.reached;
-    if (h.n_active == 0) break;
+    if (h.n_active == 0 || (max_hops >= 0 && level >= max_hops)) break;
+    if (level >= MAX_LEVEL) {  // cannot record a deeper level in DistT
+      *overflow = true;
+      break;
+    }
     st.levels++;
     st.active_vertices += h.n_active;
     st.traversed_edges += h.te;
-    // reset per-level counters (reached keeps accumulating)
-    GG_HIP(hipMemsetAsync(lv, 0, 2 * sizeof(unsigned long long), s));
-    uint64_t waves = h.n_active;
-    uint64_t max_waves = (uint64_t)ctx->num_cus * 32;  // one resident set; grid-stride the rest
-    if (waves > max_waves) waves = max_waves;
-    GG_LAUNCH(ctx, "bfs_expand", k_bfs_expand, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, active,
-              (uint64_t)h.n_active, frontier, seen, csr->off, csr->nbr, next);
+    GG_HIP(hipMemsetAsync(lv, 0, 2 * sizeof(unsigned long long), s));  // reached keeps accumulating
     level++;
-    GG_LAUNCH(ctx, "bfs_update", k_bfs_update, dim3(vgrid), dim3(256), 0, frontier, seen, next, V, level, dist, lv);
-  }
-  // final reached count (the loop may have exited on the hop bound right after an update)
-  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, lv, sizeof(BfsLevel), hipMemcpyDeviceToHost, s));
-  GG_HIP(hipStreamSynchronize(s));
-  {
-    BfsLevel h;
-    memcpy(&h, ctx->pin_scratch, sizeof(h));
-    reached = h.reached;
+    const bool pull = h.te * 16 > csr->E;  // heavy frontier: gather instead of scatter
+    if (pull) {
+      GG_TRY(ensure_reverse(ctx, csr));
+      uint64_t waves = V < max_waves ? V : max_waves;
+      GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull<DistT>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, front, other,
+                seen, V, (uint32_t)level, csr->off, csr->roff, csr->rnbr, dist8, lv);
+      // the old frontier becomes the spare buffer and must be zero again for a later push level
+      GG_HIP(hipMemsetAsync(front, 0, V * sizeof(uint64_t), s));
+      uint64_t *t = front;
+      front = other;
+      other = t;
+    } else {
+      GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s));
+      GG_LAUNCH(ctx, "bfs_compact", k_bfs_compact, dim3(vgrid), dim3(256), 0, front, V, active, cursor);
+      uint64_t waves = h.n_active < max_waves ? h.n_active : max_waves;
+      GG_LAUNCH(ctx, "bfs_push", k_bfs_push, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, active,
+                (uint64_t)h.n_active, front, seen, csr->off, csr->nbr, other);
+      GG_LAUNCH(ctx, "bfs_update", (k_bfs_update<DistT>), dim3(vgrid), dim3(256), 0, front, seen, other, V, (uint32_t)level,
+                csr->off, dist8, lv);
+    }
   }
   st.reached_pairs = reached;
 
   int rc = GG_OK;
-  if (!dst_ids) {
-    hipError_t e = hipMemcpyAsync(out_dist, dist, (uint64_t)n_src * V * sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-      set_error("gg_bfs64: result copy failed: %s", hipGetErrorString(e));
-      rc = GG_ERR_HIP;
-    }
-  } else {
+  if (out_dist && !*overflow) {
     int64_t *dst_dev = nullptr;
     uint32_t *dst_dense = nullptr;
     int32_t *out_dev = nullptr;
-    rc = ctx->dev_alloc((void **)&dst_dev, n_dst * sizeof(int64_t));
-    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&dst_dense, n_dst * sizeof(uint32_t));
-    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&out_dev, (uint64_t)n_src * n_dst * sizeof(int32_t));
-    if (rc == GG_OK) {
-      hipError_t e = hipMemcpyAsync(dst_dev, dst_ids, n_dst * sizeof(int64_t), hipMemcpyHostToDevice, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-      if (e != hipSuccess) rc = GG_ERR_HIP;
+    rc = ctx->dev_alloc((void **)&out_dev, (uint64_t)n_src * n_out * sizeof(int32_t));
+    if (rc == GG_OK && dst_ids) {
+      rc = ctx->dev_alloc((void **)&dst_dev, n_dst * sizeof(int64_t));
+      if (rc == GG_OK) rc = ctx->dev_alloc((void **)&dst_dense, n_dst * sizeof(uint32_t));
+      if (rc == GG_OK) {
+        hipError_t e = hipMemcpyAsync(dst_dev, dst_ids, n_dst * sizeof(int64_t), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = GG_ERR_HIP;
+      }
+      if (rc == GG_OK) rc = lookup_ids(ctx, csr, dst_dev, n_dst, dst_dense);
     }
-    if (rc == GG_OK) rc = lookup_ids(ctx, csr, dst_dev, n_dst, dst_dense);
     if (rc == GG_OK) {
-      const uint64_t tot = (uint64_t)n_src * n_dst;
-      hipLaunchKernelGGL(k_bfs_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dist, V, n_src, dst_dense,
-                         n_dst, out_dev);
-      hipError_t e = hipMemcpyAsync(out_dist, out_dev, tot * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+      hipLaunchKernelGGL((k_bfs_widen<DistT>), dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, (const DistT *)dist8, V,
+                         n_src, (const uint32_t *)dst_dense, n_out, out_dev);
+      hipError_t e =
+          hipMemcpyAsync(out_dist, out_dev, (uint64_t)n_src * n_out * sizeof(int32_t), hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       if (e != hipSuccess) {
-        set_error("gg_bfs64: gather failed: %s", hipGetErrorString(e));
+        set_error("gg_bfs64: result copy failed: %s", hipGetErrorString(e));
         rc = GG_ERR_HIP;
       }
     }
@@ -238,11 +350,39 @@ extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, 
   ctx->dev_free(ids_dev);
   ctx->dev_free(src_dense);
   ctx->dev_free(active);
-  ctx->dev_free(frontier);
+  ctx->dev_free(fa);
+  ctx->dev_free(fb);
   ctx->dev_free(seen);
-  ctx->dev_free(next);
-  ctx->dev_free(dist);
+  ctx->dev_free(dist8);
   ctx->dev_free(lv);
+  ctx->dev_free(cursor);
   if (stats) *stats = st;
   return rc;
+}
+
+extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, int n_src, int max_hops,
+                        const int64_t *dst_ids, uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats) {
+  gg_csr *csr = const_cast<gg_csr *>(csr_c);
+  if (!ctx || !csr || csr->ctx != ctx || n_src < 0 || n_src > GG_BFS_LANES || (n_src && !src_ids) ||
+      (n_dst && !dst_ids)) {
+    set_error("gg_bfs64: bad argument (n_src must be 0..%d)", GG_BFS_LANES);
+    return GG_ERR_INVALID_ARG;
+  }
+  if (csr->n_parts > 1) {
+    set_error("gg_bfs64 needs a whole CSR, not a shard");
+    return GG_ERR_STATE;
+  }
+  // one byte per (vertex, lane) covers 254 levels; deeper searches rerun with two-byte cells
+  bool overflow = false;
+  if (max_hops < 0 || max_hops > 254) {
+    int rc = bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow);
+    if (rc != GG_OK || !overflow) return rc;
+    rc = bfs_run<uint16_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow);
+    if (rc == GG_OK && overflow) {
+      set_error("gg_bfs64: search deeper than 65534 levels is not supported");
+      return GG_ERR_TOO_LARGE;
+    }
+    return rc;
+  }
+  return bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow);
 }

@@ -267,11 +267,15 @@ class GG:
         return list(b)
 
     # ---- bfs
-    def bfs64(self, csr: Csr, sources, max_hops: int, targets=None):
+    def bfs64(self, csr: Csr, sources, max_hops: int, targets=None, fetch=True):
         s, ps = _i64(sources)
         n_out = csr.V if targets is None else len(targets)
-        out = np.empty((s.size, n_out), np.int32)
         st = BfsStats()
+        if not fetch:  # stats only: distances stay on the device
+            self._chk(self.lib.gg_bfs64(self.ctx, csr.handle, ps, s.size, max_hops, None, 0, None, C.byref(st)))
+            return None, {"levels": st.levels, "traversed_edges": st.traversed_edges,
+                          "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
+        out = np.empty((s.size, n_out), np.int32)
         if targets is None:
             rc = self.lib.gg_bfs64(self.ctx, csr.handle, ps, s.size, max_hops, None, 0, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st))
         else:

@@ -156,6 +156,7 @@ typedef struct gg_bfs_stats {
  * src_ids[i] to target j, or -1 if none of length <= max_hops (max_hops < 0: run to fixpoint).
  * Targets: dst_ids == NULL -> every vertex in vertex-table order (n = V); else the n_dst given ids
  * (ids absent from the vertex table get -1).  A source absent from the vertex table reaches nothing.
+ * out_dist == NULL: run the BFS and fill *stats only (no device-to-host copy of the distances).
  * Equals, for the reached pairs, the reference relation
  *   SELECT startPerson, friend, min(hopCount) FROM friends GROUP BY startPerson, friend
  * with the recursion bound `f.hopCount < max_hops` (bi-10-shortestpath.sql:8-31). */

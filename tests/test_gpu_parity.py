@@ -359,3 +359,18 @@ def test_each_shard_matches_oracle_sharded_the_same_way(gg, orc):
             assert got["frontier_entries"] == ref["frontier_entries"]
             sh.close()
     g.close()
+
+
+def test_bfs_deeper_than_254_levels(gg, orc):
+    """A 700-vertex chain: distances exceed one byte, the BFS reruns with 16-bit cells."""
+    vid = datagen.person_ids(700, 13)
+    src, dst = vid[:-1], vid[1:]
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = np.array([vid[0], vid[350], vid[699], vid[0]], np.int64)
+    for max_hops in (-1, 300, 254, 255):
+        dist, st = gg.bfs64(csr, sources, max_hops)
+        o_dist, o_st = g.bfs64(g.lookup(sources), max_hops)
+        assert np.array_equal(dist, o_dist) and st == o_st
+    assert dist[0].max() == 255 and gg.bfs64(csr, sources, -1)[0][0].max() == 699
+    csr.close()
+    g.close()
