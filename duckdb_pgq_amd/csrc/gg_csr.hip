@@ -459,6 +459,7 @@ extern "C" void gg_csr_destroy(gg_csr *csr) {
     ctx->dev_free(csr->ht);
     ctx->dev_free(csr->roff);
     ctx->dev_free(csr->rnbr);
+    ctx->dev_free(csr->rrow);
   }
   delete csr;
 }
@@ -575,7 +576,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   ctx->dev_free(st);
   ctx->dev_free(kept_dev);
   ctx->dev_free(kept_rev_dev);
-  ctx->dev_free(rkey_sorted);
+  csr->rrow = rkey_sorted;  // null unless this is a shard build (ensure_reverse fills it lazily otherwise)
   if (hs.dup_vertex) {
     set_error("vertex key column is not unique (duplicate vertex id)");
     return GG_ERR_DUPLICATE_VERTEX;
@@ -620,7 +621,7 @@ int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
   }
   GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, rkey, E,
             (const unsigned long long *)nullptr, V, csr->roff);
-  ctx->dev_free(rkey);
+  csr->rrow = rkey;
   return GG_OK;
 }
 

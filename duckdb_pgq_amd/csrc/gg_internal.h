@@ -121,7 +121,8 @@ struct gg_csr {
   // reverse CSR (in-neighbours), built lazily by ensure_reverse(): row x lists the sources u of
   // every edge u->x in ascending (u, rowid) order
   uint32_t *roff = nullptr;    // V+1
-  uint32_t *rnbr = nullptr;    // E
+  uint32_t *rnbr = nullptr;    // E   source u of the reverse entry
+  uint32_t *rrow = nullptr;    // E   destination x of the reverse entry (COO view, sorted by x)
 };
 
 struct gg_result {

@@ -271,7 +271,11 @@ __device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int 
                                                uint32_t (&ahi)[MID_R]) {
   int i = ia;
   for (; i + 4 <= ib; i += 4) {  // 4 states per trip: their LDS broadcast reads issue back to back
+#ifdef GG_EXP_NO_LDS  // timing experiment only: hash states from a register instead of LDS
+    const uint64_t q0 = (uint64_t)i * 0x9E3779B97F4A7C15ULL, q1 = q0 + 1, q2 = q0 + 2, q3 = q0 + 3;
+#else
     const uint64_t q0 = s_q[i], q1 = s_q[i + 1], q2 = s_q[i + 2], q3 = s_q[i + 3];
+#endif
     mid_fold<NREG>(q0, tlo, thi, alo, ahi);
     mid_fold<NREG>(q1, tlo, thi, alo, ahi);
     mid_fold<NREG>(q2, tlo, thi, alo, ahi);
@@ -281,38 +285,35 @@ __device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int 
 }
 
 __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
-                                                    const uint32_t *__restrict__ roff /* + mid_lo */,
-                                                    const uint32_t *__restrict__ rnbr, uint64_t n_mid, uint32_t mid_lo,
-                                                    uint64_t M, const uint32_t *__restrict__ tile_entry,
-                                                    int emit_mid, unsigned long long *__restrict__ partial) {
-  __shared__ uint64_t s_foff[XT + 1];
+                                                    const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
+                                                    uint64_t fbase, uint64_t M, int emit_mid,
+                                                    unsigned long long *__restrict__ partial) {
   __shared__ uint64_t s_q[XT];
   __shared__ uint64_t s_pq[XT + 1];   // lane-wise prefix sums of s_q: s_pq[i] = sum of s_q[0..i)
   __shared__ uint32_t s_x[XT];
   __shared__ uint32_t s_run[XT + 1];  // tile position where each run of equal x starts (+ end sentinel)
+  __shared__ uint32_t s_rst[XT];      // per run: start of out-row x in nbr
+  __shared__ uint32_t s_rdout[XT];    // per run: out-degree of x
   __shared__ uint32_t s_wcnt[XT / 64];
   __shared__ uint64_t s_wsum[XT / 64];
   __shared__ uint64_t s_red[12];
 
-  const uint64_t fbase = (uint64_t)roff[0];
+  // reverse-CSR entry p is the 1-hop row u -> x with x = rrow[p] (COO view of the reverse CSR), u = rnbr[p]:
+  // two coalesced loads, no search
   const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
-  const uint64_t i0 = tile_entry[blockIdx.x];
-  load_window(s_foff, roff, n_mid, i0);
-  __syncthreads();
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool valid = p < fbase + M;
   uint64_t mid_sum = 0, rows_last = 0, myq = 0;
-  uint32_t x = INVALID_U32;
+  uint32_t x = INVALID_U32, x_st = 0, x_dout = 0;
   if (valid) {
-    uint64_t k;
-    const uint64_t i = locate_entry(s_foff, roff, n_mid, i0, p, &k);
-    x = mid_lo + (uint32_t)i;
+    x = rrow[p];
     const uint32_t u = rnbr[p];
     const uint64_t P = dig_leaf(dig_q((uint64_t)u, 0), x);
     if (emit_mid) mid_sum = P;
     myq = dig_q(P, 1);
-    rows_last = (uint64_t)(off[x + 1] - off[x]);
+    x_st = off[x];
+    x_dout = off[x + 1] - x_st;
+    rows_last = (uint64_t)x_dout;
   }
   s_q[threadIdx.x] = myq;
   s_x[threadIdx.x] = x;
@@ -349,7 +350,12 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
     if (w < wave) hbase += s_wcnt[w];
     nruns += s_wcnt[w];
   }
-  if (head) s_run[hbase + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
+  if (head) {
+    const uint32_t r = hbase + __popcll(hm & ((1ULL << lane) - 1ULL));
+    s_run[r] = threadIdx.x;
+    s_rst[r] = x_st;
+    s_rdout[r] = x_dout;
+  }
   const uint64_t remaining = M - (uint64_t)blockIdx.x * XT;
   const uint32_t n_valid = remaining < XT ? (uint32_t)remaining : XT;
   if (threadIdx.x == 0) s_run[nruns] = n_valid;
@@ -360,33 +366,37 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
   for (int r = 0; r < MID_R; r++) alo[r] = ahi[r] = 0;
   uint64_t corr = 0;  // what lanes holding no leaf accumulated (q ^ 0), removed at the end
 
+#ifdef GG_EXP_NO_PHASE2  // timing experiment only (results are wrong): how much is phase 1?
+  if (nruns > XT) {
+#else
+  {
+#endif
   for (uint32_t rr = 0; rr < nruns; rr++) {
     const int a = (int)s_run[rr], b = (int)s_run[rr + 1];
-    const uint32_t xr = s_x[a];
-    const uint32_t st = off[xr];
-    const uint32_t dout = off[xr + 1] - st;
-    if (dout == 0) continue;
-    const uint32_t *__restrict__ row = nbr + st;
     const int len = b - a;
-    const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
     // long runs: every wave takes a slice of the run (i-split) and walks all J-blocks;
-    // short runs: whole run per wave, J-blocks dealt round-robin (rotated by run so waves share load)
+    // short runs: the whole run belongs to ONE wave (dealt round-robin), the others skip it at once
     const bool isplit = len >= 16;
+    if (!isplit && (rr & (XT / 64 - 1)) != (uint32_t)wave) continue;
+    const uint32_t dout = s_rdout[rr];
+    if (dout == 0) continue;
+    const uint32_t *__restrict__ row = nbr + s_rst[rr];
     const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
     const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : b;
     if (ia >= ib) continue;
     const uint64_t sq = dsum_sub(s_pq[ib], s_pq[ia]);  // sum of the slice's hash states
+    // J-blocks of equal size (multiple of 64 leaves, at most 64*MID_R): avoids a nearly empty tail block
+    const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
+    const uint32_t jsz = (((dout + nJ - 1) / nJ) + 63) & ~63u;
+    const int nreg = (int)(jsz >> 6);
     for (uint32_t jb = 0; jb < nJ; jb++) {
-      if (!isplit && ((jb + rr) & (XT / 64 - 1)) != (uint32_t)wave) continue;
-      const uint32_t base = jb * 64 * MID_R;
-      const uint32_t rem = dout - base;
+      const uint32_t base = jb * jsz;
       uint32_t tlo[MID_R], thi[MID_R];
-      const int nreg = rem >= 64 * MID_R ? MID_R : (int)((rem + 63) / 64);
       uint32_t ninv = 0;  // registers (among the nreg used) in which this lane holds no leaf
 #pragma unroll
       for (int r = 0; r < MID_R; r++) {
         const uint32_t j = base + r * 64 + lane;
-        const bool ok = j < dout;
+        const bool ok = r < nreg && j < dout;
         const uint64_t t = ok ? (uint64_t)row[j] * (uint64_t)DIG_K32 : 0ULL;
         tlo[r] = (uint32_t)t;
         thi[r] = (uint32_t)(t >> 32);
@@ -403,6 +413,7 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
       // a lane without a leaf added q ^ 0 = q for every state of the slice
       for (uint32_t c = 0; c < ninv; c++) corr = dsum_add(corr, sq);
     }
+  }
   }
   uint64_t total = 0;
 #pragma unroll
@@ -743,7 +754,7 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
   memset(st, 0, sizeof(*st));
   GG_TRY(ensure_reverse(ctx, csr));
   const uint64_t n_mid = mid_hi - mid_lo;
-  uint64_t M = csr->E_rev;
+  uint64_t M = csr->E_rev, fbase = 0;
   if (!(mid_lo == 0 && mid_hi == csr->V)) {
     uint32_t ends[2] = {0, 0};
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, csr->roff + mid_lo, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -753,17 +764,16 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
     memcpy(&ends[0], ctx->pin_scratch, sizeof(uint32_t));
     memcpy(&ends[1], ctx->pin_scratch + 1, sizeof(uint32_t));
     M = (uint64_t)ends[1] - ends[0];
+    fbase = ends[0];
   }
   uint64_t rows2 = 0, dig1 = 0, dig2 = 0;
   if (M) {
-    uint32_t *tile_entry = nullptr;
-    uint64_t n_tiles = 0;
+    const uint64_t n_tiles = (M + XT - 1) / XT;
     unsigned long long *partial = nullptr, *tmp = nullptr;
-    GG_TRY(make_tiles<uint32_t>(ctx, csr->roff + mid_lo, n_mid, M, &tile_entry, &n_tiles));
     GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
     GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
-    GG_LAUNCH(ctx, "expand_mid2", k_expand_mid2, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
-              csr->roff + mid_lo, csr->rnbr, n_mid, (uint32_t)mid_lo, M, tile_entry, (int)(k_min <= 1), partial);
+    GG_LAUNCH(ctx, "expand_mid2", k_expand_mid2, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr, csr->rrow,
+              csr->rnbr, fbase, M, (int)(k_min <= 1), partial);
     GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(hipStreamSynchronize(ctx->stream));
@@ -772,7 +782,6 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
     rows2 = ctx->pin_scratch[2];
     ctx->dev_free(tmp);
     ctx->dev_free(partial);
-    ctx->dev_free(tile_entry);
   }
   if (k_min <= 1) {
     st->rows[1] = M;

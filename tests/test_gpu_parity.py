@@ -374,3 +374,35 @@ def test_bfs_deeper_than_254_levels(gg, orc):
     assert dist[0].max() == 255 and gg.bfs64(csr, sources, -1)[0][0].max() == 699
     csr.close()
     g.close()
+
+
+def test_trainbenchmark_connectedsegments_path_part_on_gpu(gg, orc):
+    """Train Benchmark SF1 (data the reference ships): the connectsTo part of ConnectedSegments — the
+    6-vertex / 5-edge fixed-length path ct1..ct5 from every Segment — runs on the GPU (k = 5 materialised);
+    the monitoredBy same-sensor joins are then applied with the oracle's hash join, and the result must be
+    the reference's golden rows (benchmark/trainbenchmark/connectedsegments.benchmark:34-38)."""
+    from tests import trainbenchmark as tb
+
+    t = tb.tables()
+    te = tb.load("TrackElement")[:, 0]
+    ct, mb, seg = t["connectsTo"], t["monitoredBy"], t["Segment"][:, 0]
+    gg.staging_clear()
+    gg.append_vertices(te)
+    gg.append_edges(ct[:, 0], ct[:, 1])
+    csr = gg.build_csr()
+    got = gg.expand_khop(csr, 5, 5, sources=seg, materialise=True)["tables"][5]
+    # the same five joins through the oracle's JoinHashTable restatement
+    rows = seg.reshape(-1, 1)
+    for _ in range(5):
+        m = orc.hash_join(ct[:, 0], rows[:, -1])
+        rows = np.hstack([rows[m[:, 0]], ct[m[:, 1], 1:2]])
+    assert np.array_equal(sort_rows(got), sort_rows(rows))
+    # mb1..mb6 with equal sensors
+    m = orc.hash_join(mb[:, 0], got[:, 0])
+    out = np.hstack([mb[m[:, 1], 1:2], got[m[:, 0]]])
+    for i in range(2, 7):
+        m = orc.hash_join(mb[:, 0], out[:, i])
+        keep = mb[m[:, 1], 1] == out[m[:, 0], 0]
+        out = out[m[keep, 0]]
+    assert np.array_equal(sort_rows(out), sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN))
+    csr.close()
