@@ -363,6 +363,7 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
 extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, int n_src, int max_hops,
                         const int64_t *dst_ids, uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats) {
   gg_csr *csr = const_cast<gg_csr *>(csr_c);
+  ApiScope scope(ctx);
   if (!ctx || !csr || csr->ctx != ctx || n_src < 0 || n_src > GG_BFS_LANES || (n_src && !src_ids) ||
       (n_dst && !dst_ids)) {
     set_error("gg_bfs64: bad argument (n_src must be 0..%d)", GG_BFS_LANES);

@@ -467,6 +467,7 @@ extern "C" void gg_csr_destroy(gg_csr *csr) {
 static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   if (!ctx || !out || n_parts < 1 || part < 0 || part >= n_parts) return GG_ERR_INVALID_ARG;
   *out = nullptr;
+  ApiScope scope(ctx);
   const bool shard = n_parts > 1;
   GG_TRY(gg_staging_sync(ctx));
   GG_HIP(hipSetDevice(ctx->device));
@@ -586,6 +587,9 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   csr->E_rev = hs.kept_rev;
   csr->owned_vertices = shard ? hs.owned : V;
   csr->dropped = shard ? 0 : E - hs.kept;  // a shard cannot tell dropped edges from other shards' edges
+  for (void *p : {(void *)csr->off, (void *)csr->nbr, (void *)csr->row, (void *)csr->epos, (void *)csr->eid,
+                  (void *)csr->vid, (void *)csr->ht, (void *)csr->roff, (void *)csr->rnbr, (void *)csr->rrow})
+    ctx->keep(p);
   guard.armed = false;
   *out = csr;
   return GG_OK;
@@ -602,7 +606,18 @@ namespace gg {
 // Reverse CSR from the forward COO view (row, nbr), which is sorted by (source, rowid): a stable sort
 // by destination leaves every in-neighbour list in ascending (source, rowid) order.
 int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
-  if (csr->roff) return GG_OK;
+  if (csr->roff && csr->rrow) return GG_OK;
+  struct Reset {  // a failed attempt must not leave half-built members behind
+    gg_csr *c;
+    bool armed = true;
+    ~Reset() {
+      if (armed) {
+        c->ctx->dev_free(c->roff);
+        c->ctx->dev_free(c->rnbr);
+        c->roff = c->rnbr = c->rrow = nullptr;
+      }
+    }
+  } reset{csr};
   const uint64_t V = csr->V, E = csr->E;
   uint32_t *rkey = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&csr->roff, (V + 1) * sizeof(uint32_t)));
@@ -622,6 +637,10 @@ int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
   GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, rkey, E,
             (const unsigned long long *)nullptr, V, csr->roff);
   csr->rrow = rkey;
+  ctx->keep(csr->roff);
+  ctx->keep(csr->rnbr);
+  ctx->keep(csr->rrow);
+  reset.armed = false;
   return GG_OK;
 }
 

@@ -42,6 +42,8 @@ struct DevBlock {
   void *ptr;
   size_t size;
   bool in_use;
+  uint64_t serial;  // allocation number (ApiScope frees what an API call allocated and did not keep)
+  bool keep;        // owned by a long-lived object (gg_csr, gg_result)
 };
 
 struct ProfRec {
@@ -94,8 +96,10 @@ struct gg_ctx {
   // small pinned scratch for D2H of counters
   uint64_t *pin_scratch = nullptr;  // 64 x u64
 
+  uint64_t next_serial = 1;
   int dev_alloc(void **out, size_t bytes);
   void dev_free(void *p);
+  void keep(void *p);  // the block outlives the API call that allocated it
   int prof_begin(const char *name);
   void prof_end(int rec);
   int prof_flush();
@@ -133,6 +137,20 @@ struct gg_result {
 };
 
 namespace gg {
+
+// Put one at the top of every C-ABI entry point that allocates: whatever the call allocated from the pool
+// and neither freed nor handed to a long-lived object (gg_ctx::keep) goes back to the pool when the call
+// returns — including every early error return.
+struct ApiScope {
+  gg_ctx *ctx;
+  uint64_t mark;
+  explicit ApiScope(gg_ctx *c) : ctx(c), mark(c ? c->next_serial : 0) {}
+  ~ApiScope() {
+    if (!ctx) return;
+    for (auto &b : ctx->blocks)
+      if (b.in_use && !b.keep && b.serial >= mark) b.in_use = false;
+  }
+};
 
 // RAII-free helper: launch wrapper that records events when profiling is on.
 #define GG_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                         \

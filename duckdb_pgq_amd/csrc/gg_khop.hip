@@ -857,6 +857,7 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
       res->rows[h] = M;
       for (int c = 0; c <= h; c++) {
         GG_TRY(ctx->dev_alloc((void **)&res->cols[h][c], (M ? M : 1) * sizeof(int64_t)));
+        ctx->keep(res->cols[h][c]);
         if (M)
           GG_LAUNCH(ctx, "gather_ids", k_gather_ids, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, cols_cur[c],
                     csr->vid, M, res->cols[h][c]);
@@ -897,6 +898,7 @@ int check_args(gg_ctx *ctx, const gg_csr *csr, int k_min, int k_max, gg_khop_sta
 
 extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src_lo, uint64_t src_hi, int k_min,
                                     int k_max, int materialise, gg_khop_stats *stats, gg_result **out_result) {
+  ApiScope scope(ctx);
   GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
   if (out_result) *out_result = nullptr;
   if (materialise && !out_result) return GG_ERR_INVALID_ARG;
@@ -952,6 +954,7 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
 
 extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min,
                               int k_max, int materialise, gg_khop_stats *stats, gg_result **out_result) {
+  ApiScope scope(ctx);
   if (!src_ids)
     return gg_expand_khop_range(ctx, csr, 0, csr ? csr->V : 0, k_min, k_max, materialise, stats, out_result);
   GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
@@ -1010,6 +1013,7 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
 }
 
 extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds) {
+  ApiScope scope(ctx);
   if (!ctx || !csr || n_parts < 1 || !bounds || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
   GG_HIP(hipSetDevice(ctx->device));
   const uint64_t V = csr->V;
@@ -1046,6 +1050,7 @@ extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, ui
 
 extern "C" int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, int k_max,
                                   gg_khop_stats *stats) {
+  ApiScope scope(ctx);
   GG_TRY(check_args(ctx, csr, k_min, k_max, stats));
   if (k_max != 2) {
     set_error("gg_expand_khop_mid: only k_max == 2 is supported (got %d)", k_max);
@@ -1058,6 +1063,7 @@ extern "C" int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uin
 }
 
 extern "C" int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds) {
+  ApiScope scope(ctx);
   if (!ctx || !csr || n_parts < 1 || !bounds || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
   GG_HIP(hipSetDevice(ctx->device));
   const uint64_t V = csr->V;

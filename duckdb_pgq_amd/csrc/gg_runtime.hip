@@ -47,6 +47,8 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
   }
   if (best >= 0) {
     blocks[best].in_use = true;
+    blocks[best].serial = next_serial++;
+    blocks[best].keep = false;
     *out = blocks[best].ptr;
     return GG_OK;
   }
@@ -70,9 +72,18 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
     }
   }
   bytes_allocated += bytes;
-  blocks.push_back({p, bytes, true});
+  blocks.push_back({p, bytes, true, next_serial++, false});
   *out = p;
   return GG_OK;
+}
+
+void gg_ctx::keep(void *p) {
+  if (!p) return;
+  for (auto &b : blocks)
+    if (b.ptr == p) {
+      b.keep = true;
+      return;
+    }
 }
 
 void gg_ctx::dev_free(void *p) {

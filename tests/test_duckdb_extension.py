@@ -63,3 +63,22 @@ def test_shortest_path_matches_recursive_cte(db):
         got = d.execute(f"SELECT * FROM gg_shortest_path({GRAPH}, '{src_sql}', {max_hops})")
         ref = d.execute(R.sql_shortest(sources, max_hops))
         assert np.array_equal(sort_rows(got), sort_rows(ref))
+
+
+def test_null_keys_and_int32_columns_follow_join_semantics(db):
+    """Nullable INTEGER key columns: NULL never joins (JoinHashTable::PrepareKeys filters NULL keys,
+    join_hashtable.cpp:126-148); the sinks skip such rows, so GPU and CPU relations stay equal."""
+    d, _ = db
+    d.execute("CREATE TABLE v32 (id INTEGER)")
+    d.execute("CREATE TABLE e32 (a INTEGER, b INTEGER)")
+    d.execute("INSERT INTO v32 VALUES (1), (2), (3), (4), (NULL), (7)")
+    d.execute("INSERT INTO e32 VALUES (1,2), (2,3), (NULL,3), (3,NULL), (3,4), (4,1), (2,2), (9,1), (1,9), (NULL,NULL), (2,3)")
+    got = d.execute("SELECT v0, v1, v2 FROM gg_khop('v32','id','e32','a','b', 2, 2)")
+    ref = d.execute("SELECT p0.id, p1.id, p2.id FROM v32 p0, e32 k1, v32 p1, e32 k2, v32 p2 "
+                    "WHERE p0.id = k1.a AND k1.b = p1.id AND p1.id = k2.a AND k2.b = p2.id")
+    assert ref.shape[0] > 0 and np.array_equal(sort_rows(got), sort_rows(ref))
+    sp = d.execute("SELECT * FROM gg_shortest_path('v32','id','e32','a','b', 'SELECT id FROM v32', 4)")
+    cte = d.execute("""WITH RECURSIVE f(s, h, x) AS (SELECT id, 0, id FROM v32 WHERE id IS NOT NULL
+        UNION SELECT f.s, f.h+1, k.b FROM f, e32 k, v32 p WHERE f.x = k.a AND k.b = p.id AND f.h < 4)
+        SELECT s, x, min(h) FROM f GROUP BY s, x""")
+    assert np.array_equal(sort_rows(sp), sort_rows(cte))
