@@ -1,0 +1,71 @@
+"""Full-size GPU checks at BASELINE.json's configurations (seeded synthetic LDBC-shaped tables)."""
+import numpy as np
+import pytest
+
+from duckdb_pgq_amd import datagen, sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def stage(gg, vid, src, dst):
+    gg.staging_clear()
+    gg.chunk_rows = 122_880
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    gg.chunk_rows = 0
+
+
+def test_sf10_two_hop_and_bfs_against_oracle(gg, orc):
+    """configs[1]: SF10 Person-KNOWS*1..2-Person — counts, digests, TE bit-exact vs the oracle (1.07 G walks);
+    configs[2]-shaped BFS: 64 sources to fixpoint, every distance equal."""
+    vid, src, dst = datagen.ldbc("sf10")
+    stage(gg, vid, src, dst)
+    csr = gg.build_csr()
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    got = gg.expand_khop(csr, 1, 2)
+    assert got == g.khop(1, 2)
+    assert got["rows"][2] > 1_000_000_000
+    sources = datagen.pick_sources(vid, 64, 7)
+    dist, st = gg.bfs64(csr, sources, -1)
+    o_dist, o_st = g.bfs64(g.lookup(sources), -1)
+    assert np.array_equal(dist, o_dist) and st == o_st
+    csr.close()
+    g.close()
+
+
+def test_sf100_size_independent_properties(gg):
+    """configs[3] size (SF100, 12.8 G walks), checked through properties that need no oracle run:
+    product kernel == frontier kernels; ownership shards add up to the whole; rebuilding gives the same bits."""
+    vid, src, dst = datagen.ldbc("sf100")
+    stage(gg, vid, src, dst)
+    csr = gg.build_csr()
+    whole = gg.expand_khop(csr, 1, 2)
+    assert whole["rows"][1] == csr.E and whole["traversed_edges"] == whole["rows"][1] + whole["rows"][2]
+    gg.force_frontier(True)
+    try:
+        assert gg.expand_khop(csr, 1, 2) == whole
+    finally:
+        gg.force_frontier(False)
+    # the mirrored table makes the graph symmetric: 2-hop walks = sum of squared degrees
+    off = csr.export()[0]
+    deg = np.diff(off)
+    assert int((deg.astype(np.int64) ** 2).sum()) == whole["rows"][2]
+    csr.close()
+    rows = [0, 0, 0]
+    dig = [0, 0, 0]
+    for part in range(4):
+        sh = gg.build_csr_shard(part, 4)
+        st = gg.expand_khop(sh, 1, 2)
+        for h in (1, 2):
+            rows[h] += st["rows"][h]
+            dig[h] = sharding.dsum(dig[h], st["digest"][h])
+        sh.close()
+    assert rows[1:] == whole["rows"][1:3] and dig[1:] == whole["digest"][1:3]
+    csr2 = gg.build_csr()
+    assert gg.expand_khop(csr2, 1, 2) == whole
+    # BFS from 64 sources: an undirected connected component is reached symmetrically
+    sources = datagen.pick_sources(vid, 64, 3)
+    dist, st = gg.bfs64(csr2, sources, -1, targets=sources)
+    assert np.array_equal(dist, dist.T) and st["levels"] >= 3
+    csr2.close()

@@ -406,3 +406,28 @@ def test_trainbenchmark_connectedsegments_path_part_on_gpu(gg, orc):
         out = out[m[keep, 0]]
     assert np.array_equal(sort_rows(out), sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN))
     csr.close()
+
+
+def test_long_duplicate_chains(gg, orc):
+    """The reference's duplicate-key stress (test/sql/join/inner/test_join_duplicates.test:14-24: a
+    10 240-long chain for one key): 10 240 parallel edges a->b, a few b->a / b->c, plus a self loop."""
+    vid = np.array([11, 22, 33, 44], np.int64)
+    a, b, c, d = vid
+    src = np.concatenate([np.full(10240, a), np.full(3, b), np.full(700, b), [d]])
+    dst = np.concatenate([np.full(10240, b), np.full(3, a), np.full(700, c), [d]])
+    csr, g = build_both(gg, orc, vid, src, dst)
+    assert_csr_equal(csr, g)
+    for k in [(1, 1), (1, 2), (2, 2), (1, 3)]:
+        assert gg.expand_khop(csr, *k) == g.khop(*k)
+    gg.force_frontier(True)
+    try:
+        assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
+    finally:
+        gg.force_frontier(False)
+    m = gg.expand_khop(csr, 2, 2, sources=np.array([a], np.int64), materialise=True)
+    assert m["tables"][2].shape == (10240 * 703, 3)
+    dist, st = gg.bfs64(csr, vid, -1)
+    o_dist, o_st = g.bfs64(g.lookup(vid), -1)
+    assert np.array_equal(dist, o_dist) and st == o_st
+    csr.close()
+    g.close()
