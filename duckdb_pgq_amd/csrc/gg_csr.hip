@@ -171,27 +171,36 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
   }
 }
 
-// histogram of a later pass: n comes from device memory (edges kept is only known on the device)
+// histogram of a later pass: n comes from device memory (edges kept is only known on the device).
+// Per-wave private LDS histograms (8 x ndig) keep same-address LDS atomics apart; summed at the end.
 __global__ __launch_bounds__(RB_THREADS) void k_radix_hist(const uint32_t *__restrict__ key,
                                                            const unsigned long long *__restrict__ n_dev,
                                                            uint32_t lo_bit, uint32_t bits, uint64_t nblocks,
                                                            uint32_t *__restrict__ counts) {
-  __shared__ uint32_t hist[1 << RB_MAX_BITS];
+  __shared__ uint32_t hist[RB_WAVES << RB_MAX_BITS];
   const uint32_t ndig = 1u << bits;
-  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) hist[i] = 0;
+  const int wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < RB_WAVES * ndig; i += RB_THREADS) hist[i] = 0;
   __syncthreads();
   const uint64_t n = *n_dev;
   const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
-#pragma unroll 4
-  for (int it = 0; it < RB_ITEMS; it++) {
+  uint32_t *h = hist + wave * ndig;
+  uint32_t k[RB_ITEMS];
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++) {  // all loads first: 8 independent 4-byte loads in flight per lane
     const uint64_t idx = base + (uint64_t)it * RB_THREADS + threadIdx.x;
-    if (idx < n) {
-      const uint32_t k = key[idx];
-      if (k != INVALID_U32) atomicAdd(&hist[(k >> lo_bit) & (ndig - 1)], 1u);
-    }
+    k[it] = idx < n ? key[idx] : INVALID_U32;
   }
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++)
+    if (k[it] != INVALID_U32) atomicAdd(&h[(k[it] >> lo_bit) & (ndig - 1)], 1u);
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < RB_WAVES; w++) c += hist[w * ndig + d];
+    counts[(uint64_t)d * nblocks + blockIdx.x] = c;
+  }
 }
 
 // Scatter.  `bases` is the exclusive scan of `counts` (same layout).
@@ -318,21 +327,39 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
 }
 
 // Row offsets from the sorted key column: off[u] = first position whose key >= u.
+// Each thread owns 4 consecutive keys (one 16-byte load) and looks one key back.
 __global__ __launch_bounds__(256) void k_row_offsets(const uint32_t *__restrict__ key, uint64_t n_host,
                                                      const unsigned long long *__restrict__ n_dev, uint64_t V,
                                                      uint32_t *__restrict__ off) {
   const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n == 0) {
-    for (uint64_t u = i; u <= V; u += (uint64_t)gridDim.x * blockDim.x) off[u] = 0;
+    for (uint64_t u = t; u <= V; u += (uint64_t)gridDim.x * blockDim.x) off[u] = 0;
     return;
   }
-  if (i >= n) return;
-  const uint32_t k = key[i];
-  const int64_t kp = i ? (int64_t)key[i - 1] : -1;
-  for (int64_t u = kp + 1; u <= (int64_t)k; u++) off[u] = (uint32_t)i;  // runs of empty rows are short
-  if (i == n - 1)
-    for (uint64_t u = (uint64_t)k + 1; u <= V; u++) off[u] = (uint32_t)n;
+  const uint64_t i0 = t * 4;
+  if (i0 >= n) return;
+  uint32_t k[4];
+  if (i0 + 4 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(key + i0);
+    k[0] = v.x;
+    k[1] = v.y;
+    k[2] = v.z;
+    k[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j] = i0 + j < n ? key[i0 + j] : 0;
+  }
+  int64_t kp = i0 ? (int64_t)key[i0 - 1] : -1;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint64_t i = i0 + j;
+    if (i >= n) break;
+    for (int64_t u = kp + 1; u <= (int64_t)k[j]; u++) off[u] = (uint32_t)i;  // runs of empty rows are short
+    kp = (int64_t)k[j];
+    if (i == n - 1)
+      for (uint64_t u = (uint64_t)k[j] + 1; u <= V; u++) off[u] = (uint32_t)n;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_publish_kept(const uint64_t *__restrict__ total,
@@ -555,10 +582,10 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
     ctx->dev_free(rv);
   }
   if (shard) {
-    GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0,
+    GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0,
               rkey_sorted, (uint64_t)0, (const unsigned long long *)kept_rev_dev, V, csr->roff);
   }
-  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, csr->row,
+  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0, csr->row,
             (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
   GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
             (const uint64_t *)kept_rev_dev, st);
@@ -634,7 +661,7 @@ int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
     GG_TRY(radix_sort_stable(ctx, io, E, false, false, key_bits, nullptr, 0, tot, true));
     ctx->dev_free(tot);
   }
-  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 255) / 256)), dim3(256), 0, rkey, E,
+  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0, rkey, E,
             (const unsigned long long *)nullptr, V, csr->roff);
   csr->rrow = rkey;
   ctx->keep(csr->roff);
