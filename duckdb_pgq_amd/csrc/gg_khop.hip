@@ -1012,6 +1012,11 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
   return rc;
 }
 
+extern "C" int gg_expand_khop_result(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min,
+                                     int k_max, gg_khop_stats *stats, gg_result **out_result) {
+  return gg_expand_khop(ctx, csr, src_ids, n_src, k_min, k_max, 1, stats, out_result);
+}
+
 extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds) {
   ApiScope scope(ctx);
   if (!ctx || !csr || n_parts < 1 || !bounds || csr->n_parts > 1) return GG_ERR_INVALID_ARG;

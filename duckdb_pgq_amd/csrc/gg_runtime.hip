@@ -364,6 +364,17 @@ extern "C" int gg_staging_clear(gg_ctx *ctx) {
   return GG_OK;
 }
 
+extern "C" int gg_staging_clear_edges(gg_ctx *ctx) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  GG_HIP(hipSetDevice(ctx->device));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->n_edges = 0;
+  ctx->fill_e = 0;
+  ctx->rowid_explicit = false;
+  return GG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // exclusive scans (hand-written: per-block reduce -> single-block scan of block sums -> apply)
 // ------------------------------------------------------------------------------------------

@@ -128,3 +128,21 @@ def pick_sources(vid: np.ndarray, n: int, seed: int, batch: int = 0) -> np.ndarr
     V = vid.size
     p = _perm(seed ^ 0xB0F5, 20 + batch, V)
     return vid[p[: min(n, V)]] if V else np.zeros(0, np.int64)
+
+
+def replicate_tables(tables: dict, copies: int, stride: int | None = None) -> dict:
+    """Scale a small graph fixture by id-shifted replication (Train Benchmark SF1 -> SF<copies>): copy c
+    adds c*stride to every id, so the result of a pattern query is the union of the shifted SF1 results."""
+    if stride is None:
+        stride = int(max(int(t.max()) for t in tables.values() if t.size)) + 1
+    out = {}
+    shift = (np.arange(copies, dtype=np.int64) * stride)
+    for name, t in tables.items():
+        t = np.asarray(t, np.int64)
+        rep = np.repeat(shift, t.shape[0])
+        if t.ndim == 1:
+            out[name] = np.tile(t, copies) + rep
+        else:
+            out[name] = np.tile(t, (copies, 1)) + rep[:, None]
+    out["_stride"] = stride
+    return out

@@ -19,7 +19,8 @@ SYMBOLS = [
     "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
     "gg_debug_force_frontier",
-    "gg_result_rows", "gg_result_fetch", "gg_result_destroy",
+    "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
+    "gg_result_filter_common_neighbour", "gg_staging_clear_edges",
     "gg_bfs64",
     "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
@@ -90,6 +91,9 @@ def load_library(path: str | None = None):
     lib.gg_debug_force_frontier.argtypes = [P, C.c_int]
     lib.gg_result_rows.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_fetch.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
+    lib.gg_expand_khop_result.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
+    lib.gg_result_filter_common_neighbour.argtypes = [P, P, C.c_int, P, C.POINTER(P)]
+    lib.gg_staging_clear_edges.argtypes = [P]
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
@@ -238,6 +242,25 @@ class GG:
         if materialise:
             d["tables"] = self._collect(res, k_min, k_max)
         return d
+
+    def staging_clear_edges(self):
+        self._chk(self.lib.gg_staging_clear_edges(self.ctx))
+
+    def connected_paths_same_neighbour(self, path_csr: Csr, filter_csr: Csr, hops: int, sources=None):
+        """`hops`-hop walks over path_csr whose vertices all share a neighbour in filter_csr; rows (w, v0..vh)."""
+        st = KhopStats()
+        res, out = C.c_void_p(), C.c_void_p()
+        if sources is None:
+            sp, ns = None, 0
+        else:
+            a, sp = _i64(sources)
+            ns = a.size
+        self._chk(self.lib.gg_expand_khop_result(self.ctx, path_csr.handle, sp, ns, hops, hops, C.byref(st), C.byref(res)))
+        try:
+            self._chk(self.lib.gg_result_filter_common_neighbour(self.ctx, res, hops, filter_csr.handle, C.byref(out)))
+        finally:
+            self.lib.gg_result_destroy(res)
+        return self._collect(out, hops + 1, hops + 1)[hops + 1]
 
     def expand_khop_range(self, csr: Csr, lo: int, hi: int, k_min: int, k_max: int, materialise=False):
         st = KhopStats()

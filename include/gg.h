@@ -143,6 +143,19 @@ int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows);
 int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *cols,
                     uint32_t *n_out);
 void gg_result_destroy(gg_result *res);
+/* gg_expand_khop with the result left on the device for further operators (same arguments; only the
+ * handle is returned, nothing is copied to the host). */
+int gg_expand_khop_result(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min, int k_max,
+                          gg_khop_stats *stats, gg_result **out_result);
+/* Same-neighbour filter (Train Benchmark ConnectedSegments: six segments monitored by one sensor).
+ * Input: the `hops`-hop table of `res` (columns v0..vh).  `filter` is a CSR over a vertex table that
+ * contains the path vertices' ids and the filter targets (e.g. TrackElements and Sensors; edges =
+ * monitoredBy).  Output table (fetch it with hops+1): one row (w, v0..vh) for every filter neighbour w
+ * common to ALL of v0..vh, with the multiplicity the chained joins would give. */
+int gg_result_filter_common_neighbour(gg_ctx *ctx, const gg_result *res, int hops, const gg_csr *filter,
+                                      gg_result **out);
+/* Forget the staged edge rows but keep the staged vertex table (several edge tables, one vertex set). */
+int gg_staging_clear_edges(gg_ctx *ctx);
 
 /* ---- 64-lane bitset BFS (shortest path length) --------------------------------------------- */
 typedef struct gg_bfs_stats {

@@ -431,3 +431,43 @@ def test_long_duplicate_chains(gg, orc):
     assert np.array_equal(dist, o_dist) and st == o_st
     csr.close()
     g.close()
+
+
+def _connectedsegments_on_gpu(gg, te, sensors, seg, ct, mb):
+    gg.staging_clear()
+    gg.append_vertices(np.concatenate([te, sensors]))  # one id space: track elements and sensors
+    gg.append_edges(ct[:, 0], ct[:, 1])
+    path_csr = gg.build_csr()
+    gg.staging_clear_edges()
+    gg.append_edges(mb[:, 0], mb[:, 1])
+    filter_csr = gg.build_csr()
+    rows = gg.connected_paths_same_neighbour(path_csr, filter_csr, 5, sources=seg)
+    path_csr.close()
+    filter_csr.close()
+    return rows
+
+
+def test_trainbenchmark_connectedsegments_full_query_on_gpu(gg, orc):
+    """BASELINE.json configs[4]: the whole ConnectedSegments query on the GPU (5-hop path over connectsTo
+    from every Segment + same-sensor filter over monitoredBy).  SF1 = the reference's golden rows
+    (benchmark/trainbenchmark/connectedsegments.benchmark:34-38); a 1024-fold id-shifted replication
+    (SF1024-sized) = the shifted union of them, and equals the oracle's 11-join evaluation at SF16."""
+    from tests import trainbenchmark as tb
+
+    t = tb.tables()
+    te = tb.load("TrackElement")[:, 0]
+    sensors = tb.load("Sensor")[:, 0]
+    seg, ct, mb = t["Segment"][:, 0], t["connectsTo"], t["monitoredBy"]
+    got = _connectedsegments_on_gpu(gg, te, sensors, seg, ct, mb)
+    assert np.array_equal(sort_rows(got), sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN))
+
+    base = {"te": te, "sensors": sensors, "seg": seg, "ct": ct, "mb": mb}
+    for copies in (16, 1024):
+        r = datagen.replicate_tables(base, copies)
+        got = _connectedsegments_on_gpu(gg, r["te"], r["sensors"], r["seg"], r["ct"], r["mb"])
+        shift = (np.arange(copies, dtype=np.int64) * r["_stride"])
+        want = (tb.CONNECTEDSEGMENTS_GOLDEN[None, :, :] + shift[:, None, None]).reshape(-1, 7)
+        assert np.array_equal(sort_rows(got), sort_rows(want))
+        if copies == 16:
+            ref = tb.connectedsegments_via_joins(orc, {"Segment": r["seg"].reshape(-1, 1), "connectsTo": r["ct"], "monitoredBy": r["mb"]})
+            assert np.array_equal(sort_rows(got), sort_rows(ref))
