@@ -35,7 +35,8 @@ struct BuildStatus {  // device-side status block, copied back once per build
 
 // shard ownership of a vertex id: independent of table order, so every rank decides it alone
 __device__ __forceinline__ bool owns(int64_t id, uint32_t part, uint32_t n_parts) {
-  return n_parts <= 1 || (uint32_t)((((uint64_t)id * DIG_GOLD) >> 32) % n_parts) == part;
+  // owner = floor(h32 * n_parts / 2^32) with h32 the high half of the multiplicative hash (no division)
+  return n_parts <= 1 || (uint32_t)((((((uint64_t)id * DIG_GOLD) >> 32)) * (uint64_t)n_parts) >> 32) == part;
 }
 
 __global__ __launch_bounds__(256) void k_ht_init(HtSlot *__restrict__ ht, uint64_t cap) {
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void k_ht_init(HtSlot *__restrict__ ht, uint64
 }
 
 __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ vid, uint64_t V,
-                                                   HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
+                                                   HtSlot *__restrict__ ht, uint64_t cap,
                                                    BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n_parts > 1) {  // owned-vertex count (whole builds own everything: set on the host)
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
     if (prev != -1LL) atomicOr(&st->dup_vertex, 1ULL);
     return;
   }
-  uint64_t slot = ((uint64_t)key * DIG_GOLD) >> shift;
+  uint64_t slot = ht_slot(key, cap);
   while (true) {
     unsigned long long prev =
         atomicCAS((unsigned long long *)&ht[slot].key, (unsigned long long)HT_EMPTY, (unsigned long long)key);
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
       atomicOr(&st->dup_vertex, 1ULL);
       return;
     }
-    slot = (slot + 1) & mask;
+    slot = ht_next(slot, cap);
   }
 }
 
@@ -106,7 +107,7 @@ constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
 // counts[digit * nblocks + block] = number of valid elements of that tile with that digit
 __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
     const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
-    uint32_t shift, uint64_t mask, const BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts,
+    uint64_t cap, const BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts,
     uint32_t *__restrict__ fk, uint32_t *__restrict__ fv, uint32_t *__restrict__ rk /* nullable */,
     uint32_t *__restrict__ rv /* nullable */, uint32_t bits, uint64_t nblocks, uint32_t *__restrict__ counts,
     uint32_t *__restrict__ counts_r /* nullable */) {
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
     }
 #pragma unroll
     for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
-      ss[j] = ((uint64_t)ks[j] * DIG_GOLD) >> shift;
-      sd[j] = ((uint64_t)kd[j] * DIG_GOLD) >> shift;
+      ss[j] = ht_slot(ks[j], cap);
+      sd[j] = ht_slot(kd[j], cap);
       if (of[j] || orv[j]) {
         rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
         rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
       if (e >= E) continue;
       uint32_t u = INVALID_U32, v = INVALID_U32;
       if (of[j] || orv[j]) {
-        u = ht_resolve(ht, mask, min_idx, ks[j], ss[j], rs[j]);
-        v = ht_resolve(ht, mask, min_idx, kd[j], sd[j], rd[j]);
+        u = ht_resolve(ht, cap, min_idx, ks[j], ss[j], rs[j]);
+        v = ht_resolve(ht, cap, min_idx, kd[j], sd[j], rd[j]);
       }
       const bool ok = u != INVALID_U32 && v != INVALID_U32;
       const bool f = ok && of[j], r = ok && orv[j];
@@ -168,6 +169,120 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
   for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) {
     counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
     if (counts_r) counts_r[(uint64_t)d * nblocks + blockIdx.x] = hist_r[d];
+  }
+}
+
+// Shard builds (gg_csr_build_shard): only the rows this rank owns survive, 1/N of the table per
+// direction, so they are COMPACTED inside their tile (stable: element order kept) and the first radix
+// pass of each direction reads only the tile's valid prefix (tile_valid[]).  Non-owned rows are dropped
+// before the id lookups.  Forward stream: (u, v) of edges whose SOURCE is owned; reverse stream: (v, u) of
+// edges whose DESTINATION is owned.
+__global__ __launch_bounds__(RB_THREADS) void k_densify_shard(
+    const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
+    uint64_t cap, const BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts, uint32_t *__restrict__ fk,
+    uint32_t *__restrict__ fv, uint32_t *__restrict__ rk, uint32_t *__restrict__ rv, uint32_t bits, uint64_t nblocks,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ counts_r, uint32_t *__restrict__ tile_valid_f,
+    uint32_t *__restrict__ tile_valid_r) {
+  __shared__ uint32_t hist[1 << RB_MAX_BITS];
+  __shared__ uint32_t hist_r[1 << RB_MAX_BITS];
+  __shared__ uint32_t s_wf[RB_WAVES], s_wr[RB_WAVES];
+  const uint32_t ndig = 1u << bits;
+  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) {
+    hist[i] = 0;
+    hist_r[i] = 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t min_idx = st->min_idx;
+  const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
+  uint32_t u[RB_ITEMS], v[RB_ITEMS];
+  uint32_t fmask = 0, rmask = 0;  // bit `it`: item survives in the forward / reverse stream
+  constexpr int B = 4;
+  for (int it0 = 0; it0 < RB_ITEMS; it0 += B) {
+    int64_t ks[B], kd[B];
+    uint64_t ss[B], sd[B];
+    uint4 rs[B], rd[B];
+    bool of[B], orv[B];
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
+      ks[j] = e < E ? src[e] : HT_EMPTY;
+      kd[j] = e < E ? dst[e] : HT_EMPTY;
+      of[j] = e < E && owns(ks[j], part, n_parts);
+      orv[j] = e < E && owns(kd[j], part, n_parts);
+    }
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      ss[j] = ht_slot(ks[j], cap);
+      sd[j] = ht_slot(kd[j], cap);
+      if (of[j] || orv[j]) {
+        rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
+        rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      uint32_t uu = INVALID_U32, vv = INVALID_U32;
+      if (of[j] || orv[j]) {
+        uu = ht_resolve(ht, cap, min_idx, ks[j], ss[j], rs[j]);
+        vv = ht_resolve(ht, cap, min_idx, kd[j], sd[j], rd[j]);
+      }
+      const bool ok = uu != INVALID_U32 && vv != INVALID_U32;
+      u[it0 + j] = uu;
+      v[it0 + j] = vv;
+      if (ok && of[j]) {
+        fmask |= 1u << (it0 + j);
+        atomicAdd(&hist[uu & (ndig - 1)], 1u);
+      }
+      if (ok && orv[j]) {
+        rmask |= 1u << (it0 + j);
+        atomicAdd(&hist_r[vv & (ndig - 1)], 1u);
+      }
+    }
+  }
+  // stable compaction inside the tile: element order = (item, thread)
+  uint32_t base_f = 0, base_r = 0;
+  const uint64_t lane_lt = (1ULL << lane) - 1ULL;
+#pragma unroll
+  for (int it = 0; it < RB_ITEMS; it++) {
+    const bool f = (fmask >> it) & 1u, r = (rmask >> it) & 1u;
+    const uint64_t bf = __ballot(f), br = __ballot(r);
+    if (lane == 0) {
+      s_wf[wave] = (uint32_t)__popcll(bf);
+      s_wr[wave] = (uint32_t)__popcll(br);
+    }
+    __syncthreads();
+    uint32_t wf = 0, wr = 0, tf = 0, tr = 0;
+#pragma unroll
+    for (int w = 0; w < RB_WAVES; w++) {
+      if (w < wave) {
+        wf += s_wf[w];
+        wr += s_wr[w];
+      }
+      tf += s_wf[w];
+      tr += s_wr[w];
+    }
+    if (f) {
+      const uint64_t o = base + base_f + wf + __popcll(bf & lane_lt);
+      fk[o] = u[it];
+      fv[o] = v[it];
+    }
+    if (r) {
+      const uint64_t o = base + base_r + wr + __popcll(br & lane_lt);
+      rk[o] = v[it];
+      rv[o] = u[it];
+    }
+    base_f += tf;
+    base_r += tr;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    tile_valid_f[blockIdx.x] = base_f;
+    tile_valid_r[blockIdx.x] = base_r;
+  }
+  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) {
+    counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
+    counts_r[(uint64_t)d * nblocks + blockIdx.x] = hist_r[d];
   }
 }
 
@@ -210,8 +325,8 @@ template <bool HAS_B, bool GEN_B>
 __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
     const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ a_in, const uint32_t *__restrict__ b_in,
     uint64_t n_host, const unsigned long long *__restrict__ n_dev, uint32_t lo_bit, uint32_t bits, uint64_t nblocks,
-    const uint32_t *__restrict__ bases, uint32_t *__restrict__ key_out, uint32_t *__restrict__ a_out,
-    uint32_t *__restrict__ b_out) {
+    const uint32_t *__restrict__ bases, const uint32_t *__restrict__ tile_valid /* nullable: valid prefix per tile */,
+    uint32_t *__restrict__ key_out, uint32_t *__restrict__ a_out, uint32_t *__restrict__ b_out) {
   extern __shared__ uint32_t lds[];
   const uint32_t ndig = 1u << bits;
   uint32_t *xk = lds;                                  // staged keys, digit order
@@ -225,6 +340,8 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
   const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
   const uint64_t tile_base = (uint64_t)blockIdx.x * RB_TILE;
   if (tile_base >= n) return;  // block-uniform
+  const uint32_t tcnt = tile_valid ? tile_valid[blockIdx.x] : (uint32_t)RB_TILE;  // compacted tiles: valid prefix
+  if (tcnt == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t i = threadIdx.x; i < RB_WAVES * ndig; i += RB_THREADS) hw[i] = 0;
   __syncthreads();
@@ -239,7 +356,7 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
     k[it] = INVALID_U32;
     a[it] = 0;
     b[it] = 0;
-    if (idx < n) {
+    if (idx < n && (uint32_t)(wave * RB_WTILE + it * 64 + lane) < tcnt) {
       k[it] = key_in[idx];
       a[it] = a_in[idx];
       if (HAS_B) b[it] = GEN_B ? (uint32_t)idx : b_in[idx];
@@ -401,7 +518,7 @@ struct RadixIO {
 int radix_sort_stable(gg_ctx *ctx, const RadixIO &io, uint64_t n, bool has_b, bool gen_b, int key_bits,
                       uint32_t *counts0 /* nullable: pass-0 histogram already computed */, int bits0,
                       unsigned long long *total_dev /* nullable: where pass 0's valid count goes / comes from */,
-                      bool n_exact) {
+                      bool n_exact, const uint32_t *tile_valid0 = nullptr /* pass-0 input is tile-compacted */) {
   if (n == 0) return GG_OK;
   int passes = (key_bits + RB_MAX_BITS - 1) / RB_MAX_BITS;
   if (passes < 1) passes = 1;
@@ -447,13 +564,13 @@ int radix_sort_stable(gg_ctx *ctx, const RadixIO &io, uint64_t n, bool has_b, bo
     const unsigned long long *nd = (p == 0) ? nullptr : total_dev;
     if (has_b && gen_b && p == 0)
       GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true, true>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
-                bin, n, nd, lo_bit, bits, nblocks64, counts, kout, aout, bout);
+                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout);
     else if (has_b)
       GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true, false>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
-                bin, n, nd, lo_bit, bits, nblocks64, counts, kout, aout, bout);
+                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout);
     else
       GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<false, false>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
-                bin, n, nd, lo_bit, bits, nblocks64, counts, kout, aout, bout);
+                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout);
     if (!(p == 0 && counts0)) ctx->dev_free(counts);
     kin = kout;
     ain = aout;
@@ -516,9 +633,8 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   } guard{csr};
 
   // ---- id hash table --------------------------------------------------------------------
-  int lg = ceil_log2_u64(V * 2 < 1024 ? 1024 : V * 2);
-  csr->ht_cap = 1ULL << lg;
-  csr->ht_shift = 64 - lg;
+  // load factor ~0.7: a smaller table keeps more of it in the 4 MiB per-XCD L2 (probes are random)
+  csr->ht_cap = V + V / 2 < 1024 ? 1024 : V + (V * 2) / 5;
   GG_TRY(ctx->dev_alloc((void **)&csr->ht, csr->ht_cap * sizeof(HtSlot)));
   GG_TRY(ctx->dev_alloc((void **)&csr->vid, (V ? V : 1) * sizeof(int64_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->off, (V + 1) * sizeof(uint32_t)));
@@ -535,7 +651,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
             csr->ht_cap);
   if (V)
     GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_shift, csr->ht_cap - 1, st, (uint32_t)part, (uint32_t)n_parts);
+              csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts);
 
   unsigned long long *kept_dev = nullptr, *kept_rev_dev = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
@@ -564,16 +680,29 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
       GG_TRY(ctx->dev_alloc((void **)&rv, E * sizeof(uint32_t)));
       GG_TRY(ctx->dev_alloc((void **)&counts0r, (uint64_t)(1u << bits0) * nblocks64 * sizeof(uint32_t)));
     }
-    GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, csr->ht, csr->ht_shift, csr->ht_cap - 1, st, (uint32_t)part, (uint32_t)n_parts, su,
-              dv, rk, rv, (uint32_t)bits0, nblocks64, counts0, counts0r);
-    // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
-    RadixIO io{su, dv, nullptr, csr->row, csr->nbr, csr->epos};
-    GG_TRY(radix_sort_stable(ctx, io, E, true, true, key_bits, counts0, bits0, kept_dev, false));
-    if (shard) {  // reverse CSR of the edges whose DESTINATION this shard owns (rowid order inside a row)
+    uint32_t *tvf = nullptr, *tvr = nullptr;
+    if (shard) {
+      GG_TRY(ctx->dev_alloc((void **)&tvf, nblocks64 * sizeof(uint32_t)));
+      GG_TRY(ctx->dev_alloc((void **)&tvr, nblocks64 * sizeof(uint32_t)));
+      GG_LAUNCH(ctx, "densify_shard", k_densify_shard, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
+                ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts, su, dv, rk, rv,
+                (uint32_t)bits0, nblocks64, counts0, counts0r, tvf, tvr);
+      // a shard only serves all-source 2-hop counting: no edge-rowid payload (csr->epos stays unset)
+      RadixIO io{su, dv, nullptr, csr->row, csr->nbr, nullptr};
+      GG_TRY(radix_sort_stable(ctx, io, E, false, false, key_bits, counts0, bits0, kept_dev, false, tvf));
+      // reverse CSR of the edges whose DESTINATION this shard owns (rowid order inside a row)
       RadixIO ior{rk, rv, nullptr, rkey_sorted, csr->rnbr, nullptr};
-      GG_TRY(radix_sort_stable(ctx, ior, E, false, false, key_bits, counts0r, bits0, kept_rev_dev, false));
+      GG_TRY(radix_sort_stable(ctx, ior, E, false, false, key_bits, counts0r, bits0, kept_rev_dev, false, tvr));
+    } else {
+      GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
+                ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts, su, dv, rk, rv,
+                (uint32_t)bits0, nblocks64, counts0, counts0r);
+      // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
+      RadixIO io{su, dv, nullptr, csr->row, csr->nbr, csr->epos};
+      GG_TRY(radix_sort_stable(ctx, io, E, true, true, key_bits, counts0, bits0, kept_dev, false));
     }
+    ctx->dev_free(tvf);
+    ctx->dev_free(tvr);
     ctx->dev_free(counts0);
     ctx->dev_free(counts0r);
     ctx->dev_free(su);
@@ -698,7 +827,9 @@ extern "C" int gg_csr_export(const gg_csr *csr, int64_t *off, int64_t *nbr, int6
     for (uint64_t i = 0; i < csr->E; i++) nbr[i] = (int64_t)h[i];
   }
   if (eid && csr->E) {
-    if (csr->eid) {
+    if (csr->n_parts > 1) {  // shards carry no edge rowids
+      for (uint64_t i = 0; i < csr->E; i++) eid[i] = -1;
+    } else if (csr->eid) {
       GG_HIP(hipMemcpy(eid, csr->eid, csr->E * sizeof(int64_t), hipMemcpyDeviceToHost));
     } else {  // implicit rowids: the edge's append position
       std::vector<uint32_t> h(csr->E);

@@ -33,7 +33,7 @@ __device__ __forceinline__ uint32_t mult_of(const uint32_t *__restrict__ off, co
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_filter(RowCols in, int ncols, uint64_t n_rows, const HtSlot *__restrict__ ht,
-                                                uint32_t shift, uint64_t mask, int64_t min_idx,
+                                                uint64_t cap, int64_t min_idx,
                                                 const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
                                                 const int64_t *__restrict__ vid, uint64_t *__restrict__ counts,
                                                 const uint64_t *__restrict__ offsets, OutCols out) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_filter(RowCols in, int ncols, uint64_t 
   uint32_t d[GG_MAX_HOPS + 1];
   bool ok = true;
   for (int c = 0; c < ncols; c++) {
-    d[c] = ht_lookup(ht, shift, mask, min_idx, in.c[c][r]);  // row vertex -> dense index in the FILTER graph
+    d[c] = ht_lookup(ht, cap, min_idx, in.c[c][r]);  // row vertex -> dense index in the FILTER graph
     ok = ok && d[c] != INVALID_U32;
   }
   uint64_t n = 0, o = FILL ? offsets[r] : 0;
@@ -98,7 +98,7 @@ extern "C" int gg_result_filter_common_neighbour(gg_ctx *ctx, const gg_result *r
     GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(uint64_t)));
     const unsigned grid = (unsigned)((n_rows + 255) / 256);
     GG_LAUNCH(ctx, "filter_count", (k_filter<false>), dim3(grid), dim3(256), 0, in, ncols, n_rows, filter->ht,
-              filter->ht_shift, filter->ht_cap - 1, filter->ht_min_idx, filter->off, filter->nbr, filter->vid, counts,
+              filter->ht_cap, filter->ht_min_idx, filter->off, filter->nbr, filter->vid, counts,
               (const uint64_t *)nullptr, oc);
     GG_TRY(scan_exclusive_u64(ctx, counts, counts, n_rows, tot));
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tot, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -111,7 +111,7 @@ extern "C" int gg_result_filter_common_neighbour(gg_ctx *ctx, const gg_result *r
     }
     if (total)
       GG_LAUNCH(ctx, "filter_fill", (k_filter<true>), dim3(grid), dim3(256), 0, in, ncols, n_rows, filter->ht,
-                filter->ht_shift, filter->ht_cap - 1, filter->ht_min_idx, filter->off, filter->nbr, filter->vid,
+                filter->ht_cap, filter->ht_min_idx, filter->off, filter->nbr, filter->vid,
                 (uint64_t *)nullptr, (const uint64_t *)counts, oc);
     GG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->dev_free(counts);

@@ -119,8 +119,7 @@ struct gg_csr {
   int64_t *eid = nullptr;      // E   explicit edge rowids (only if the Sink passed rowids), else null
   int64_t *vid = nullptr;      // V   vertex ids by dense index
   gg::HtSlot *ht = nullptr;    // id hash table (open addressing, 16-byte slots: one line per probe)
-  uint32_t ht_shift = 0;       // slot = (key * GOLD) >> ht_shift
-  uint64_t ht_cap = 0;
+  uint64_t ht_cap = 0;         // slots; slot = mulhi(key * GOLD, ht_cap)
   int64_t ht_min_idx = -1;     // dense index of the vertex whose id == HT_EMPTY, if any
   // reverse CSR (in-neighbours), built lazily by ensure_reverse(): row x lists the sources u of
   // every edge u->x in ascending (u, rowid) order
@@ -185,29 +184,36 @@ __device__ __forceinline__ uint64_t dig_leaf(uint64_t q, uint32_t d) {
   return q ^ ((uint64_t)d * (uint64_t)DIG_K32);  // one v_mad_u64_u32
 }
 
-__device__ __forceinline__ uint32_t ht_lookup(const HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
+// slot of a key in a table of `cap` slots (any capacity, not only powers of two): multiplicative hash,
+// then multiply-high range reduction; linear probing wraps at cap
+__device__ __forceinline__ uint64_t ht_slot(int64_t key, uint64_t cap) {
+  return __umul64hi((uint64_t)key * DIG_GOLD, cap);
+}
+__device__ __forceinline__ uint64_t ht_next(uint64_t slot, uint64_t cap) { return slot + 1 == cap ? 0 : slot + 1; }
+
+__device__ __forceinline__ uint32_t ht_lookup(const HtSlot *__restrict__ ht, uint64_t cap,
                                               int64_t min_idx, int64_t key) {
   if (key == HT_EMPTY) return min_idx >= 0 ? (uint32_t)min_idx : INVALID_U32;
-  uint64_t slot = ((uint64_t)key * DIG_GOLD) >> shift;
+  uint64_t slot = ht_slot(key, cap);
   while (true) {
     // one 16-byte load per probe: key and value share a cache line
     const uint4 raw = *reinterpret_cast<const uint4 *>(&ht[slot]);
     const int64_t k = (int64_t)(((uint64_t)raw.y << 32) | raw.x);
     if (k == key) return raw.z;
     if (k == HT_EMPTY) return INVALID_U32;
-    slot = (slot + 1) & mask;
+    slot = ht_next(slot, cap);
   }
 }
 
 // finish a lookup whose first probe (slot, raw) is already loaded; continues linear probing on a miss
-__device__ __forceinline__ uint32_t ht_resolve(const HtSlot *__restrict__ ht, uint64_t mask, int64_t min_idx,
+__device__ __forceinline__ uint32_t ht_resolve(const HtSlot *__restrict__ ht, uint64_t cap, int64_t min_idx,
                                                int64_t key, uint64_t slot, uint4 raw) {
   if (key == HT_EMPTY) return min_idx >= 0 ? (uint32_t)min_idx : INVALID_U32;
   while (true) {
     const int64_t k = (int64_t)(((uint64_t)raw.y << 32) | raw.x);
     if (k == key) return raw.z;
     if (k == HT_EMPTY) return INVALID_U32;
-    slot = (slot + 1) & mask;
+    slot = ht_next(slot, cap);
     raw = *reinterpret_cast<const uint4 *>(&ht[slot]);
   }
 }

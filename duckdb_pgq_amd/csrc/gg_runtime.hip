@@ -498,16 +498,16 @@ int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t 
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lookup_ids(const int64_t *__restrict__ ids, uint64_t n,
-                                                    const HtSlot *__restrict__ ht, uint32_t shift, uint64_t mask,
+                                                    const HtSlot *__restrict__ ht, uint64_t cap,
                                                     int64_t min_idx, uint32_t *__restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = ht_lookup(ht, shift, mask, min_idx, ids[i]);
+  if (i < n) out[i] = ht_lookup(ht, cap, min_idx, ids[i]);
 }
 
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev) {
   if (n == 0) return GG_OK;
   GG_LAUNCH(ctx, "lookup_ids", k_lookup_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids_dev, n,
-            csr->ht, csr->ht_shift, csr->ht_cap - 1, csr->ht_min_idx, out_dev);
+            csr->ht, csr->ht_cap, csr->ht_min_idx, out_dev);
   return GG_OK;
 }
 

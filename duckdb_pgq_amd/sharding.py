@@ -25,7 +25,7 @@ def owner_of(ids: np.ndarray, n_parts: int) -> np.ndarray:
         return np.zeros(ids.shape, np.int64)
     with np.errstate(over="ignore"):
         h = (ids * GOLD) >> np.uint64(32)
-    return (h % np.uint64(n_parts)).astype(np.int64)
+    return ((h * np.uint64(n_parts)) >> np.uint64(32)).astype(np.int64)  # floor(h32 * n / 2^32)
 
 
 def stats_to_vec(st: dict) -> list:

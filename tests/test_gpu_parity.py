@@ -471,3 +471,45 @@ def test_trainbenchmark_connectedsegments_full_query_on_gpu(gg, orc):
         if copies == 16:
             ref = tb.connectedsegments_via_joins(orc, {"Segment": r["seg"].reshape(-1, 1), "connectsTo": r["ct"], "monitoredBy": r["mb"]})
             assert np.array_equal(sort_rows(got), sort_rows(ref))
+
+
+def test_concurrent_sink_appends(gg, orc):
+    """Sink is called concurrently from the pipeline's worker threads (physical_operator.hpp:137-139):
+    8 threads append disjoint slices in 1024-row chunks with explicit rowids.  Row contents must not
+    depend on the interleaving (compared per CSR row as sets of (rowid, neighbour))."""
+    import threading
+
+    vid, src, dst = datagen.ldbc_knows(4000, 150_000, 61)
+    rowid = np.arange(src.size, dtype=np.int64)
+    gg.staging_clear()
+    gg.append_vertices(vid)
+    nthreads = 8
+    bounds = np.linspace(0, src.size, nthreads + 1).astype(int)
+    errs = []
+
+    def work(t):
+        try:
+            for o in range(bounds[t], bounds[t + 1], 1024):
+                e = min(o + 1024, bounds[t + 1])
+                gg.append_edges(src[o:e], dst[o:e], rowid[o:e])
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    assert gg.staging_counts() == (vid.size, src.size)
+    csr = gg.build_csr()
+    off, nbr, eid, _ = csr.export()
+    rc, g = orc.csr_build(vid, src, dst, rowid)
+    o_off, o_nbr, o_eid, _ = g.arrays()
+    assert np.array_equal(off, o_off)
+    # canonical order inside each row: by rowid
+    row = np.repeat(np.arange(csr.V), np.diff(off))
+    k = np.lexsort((eid, row))
+    ko = np.lexsort((o_eid, row))
+    assert np.array_equal(eid[k], o_eid[ko]) and np.array_equal(nbr[k], o_nbr[ko])
+    assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
+    csr.close()
+    g.close()
