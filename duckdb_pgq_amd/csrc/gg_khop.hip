@@ -284,80 +284,102 @@ __device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int 
   for (; i < ib; i++) mid_fold<NREG>(s_q[i], tlo, thi, alo, ahi);
 }
 
+#ifndef GG_MID_EPT
+#define GG_MID_EPT 2
+#endif
+constexpr int MID_EPT = GG_MID_EPT;    // reverse-CSR entries per thread
+constexpr int MT = XT * MID_EPT;       // entries per tile (workgroup): 512
+constexpr int MID_SEG = MID_EPT * (XT / 64);  // (entry slot, wave) segments of a tile, in position order
+
 __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
                                                     const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
                                                     uint64_t fbase, uint64_t M, int emit_mid,
                                                     unsigned long long *__restrict__ partial) {
-  __shared__ uint64_t s_q[XT];
-  __shared__ uint64_t s_pq[XT + 1];   // lane-wise prefix sums of s_q: s_pq[i] = sum of s_q[0..i)
-  __shared__ uint32_t s_x[XT];
-  __shared__ uint32_t s_run[XT + 1];  // tile position where each run of equal x starts (+ end sentinel)
-  __shared__ uint32_t s_rst[XT];      // per run: start of out-row x in nbr
-  __shared__ uint32_t s_rdout[XT];    // per run: out-degree of x
-  __shared__ uint32_t s_wcnt[XT / 64];
-  __shared__ uint64_t s_wsum[XT / 64];
+  __shared__ uint64_t s_q[MT];
+  __shared__ uint64_t s_pq[MT + 1];   // lane-wise prefix sums of s_q: s_pq[i] = sum of s_q[0..i)
+  __shared__ uint32_t s_x[MT];
+  __shared__ uint32_t s_run[MT + 1];  // tile position where each run of equal x starts (+ end sentinel)
+  __shared__ uint32_t s_rst[MT];      // per run: start of out-row x in nbr
+  __shared__ uint32_t s_rdout[MT];    // per run: out-degree of x
+  __shared__ uint32_t s_wcnt[MID_SEG];
+  __shared__ uint64_t s_wsum[MID_SEG];
   __shared__ uint64_t s_red[12];
 
   // reverse-CSR entry p is the 1-hop row u -> x with x = rrow[p] (COO view of the reverse CSR), u = rnbr[p]:
-  // two coalesced loads, no search
-  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  // two coalesced loads, no search.  Tile position of thread t's e-th entry: e*XT + t.
+  const uint64_t tile0 = (uint64_t)blockIdx.x * MT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool valid = p < fbase + M;
-  uint64_t mid_sum = 0, rows_last = 0, myq = 0;
-  uint32_t x = INVALID_U32, x_st = 0, x_dout = 0;
-  if (valid) {
-    x = rrow[p];
-    const uint32_t u = rnbr[p];
-    const uint64_t P = dig_leaf(dig_q((uint64_t)u, 0), x);
-    if (emit_mid) mid_sum = P;
-    myq = dig_q(P, 1);
-    x_st = off[x];
-    x_dout = off[x + 1] - x_st;
-    rows_last = (uint64_t)x_dout;
-  }
-  s_q[threadIdx.x] = myq;
-  s_x[threadIdx.x] = x;
-  // lane-wise inclusive scan of q inside the wave, wave totals through LDS
-  uint32_t plo = (uint32_t)myq, phi = (uint32_t)(myq >> 32);
+  uint64_t mid_sum = 0, rows_last = 0;
+  uint32_t x[MID_EPT], x_st[MID_EPT], x_dout[MID_EPT], plo[MID_EPT], phi[MID_EPT];
+  bool valid[MID_EPT];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t a = __shfl_up(plo, o, 64), b = __shfl_up(phi, o, 64);
-    if (lane >= o) {
-      plo += a;
-      phi += b;
+  for (int e = 0; e < MID_EPT; e++) {
+    const uint32_t idx = e * XT + threadIdx.x;
+    const uint64_t p = fbase + tile0 + idx;
+    valid[e] = tile0 + idx < M;
+    uint64_t myq = 0;
+    x[e] = INVALID_U32;
+    x_st[e] = x_dout[e] = 0;
+    if (valid[e]) {
+      x[e] = rrow[p];
+      const uint32_t u = rnbr[p];
+      const uint64_t P = dig_leaf(dig_q((uint64_t)u, 0), x[e]);
+      if (emit_mid) mid_sum = dsum_add(mid_sum, P);
+      myq = dig_q(P, 1);
+      x_st[e] = off[x[e]];
+      x_dout[e] = off[x[e] + 1] - x_st[e];
+      rows_last += (uint64_t)x_dout[e];
     }
+    s_q[idx] = myq;
+    s_x[idx] = x[e];
+    // lane-wise inclusive scan of q inside the wave, segment totals through LDS
+    plo[e] = (uint32_t)myq;
+    phi[e] = (uint32_t)(myq >> 32);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t a = __shfl_up(plo[e], o, 64), b = __shfl_up(phi[e], o, 64);
+      if (lane >= o) {
+        plo[e] += a;
+        phi[e] += b;
+      }
+    }
+    if (lane == 63) s_wsum[e * (XT / 64) + wave] = ((uint64_t)phi[e] << 32) | plo[e];
   }
-  if (lane == 63) s_wsum[wave] = ((uint64_t)phi << 32) | plo;
   __syncthreads();
 
-  // run heads -> compact list of run start positions (ballot + popcount, wave bases through LDS)
-  const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
-  const uint64_t hm = __ballot(head);
-  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
-  {
-    uint64_t wbase = 0;
+  // run heads -> compact list of run start positions (ballot + popcount, segment bases through LDS)
+  bool head[MID_EPT];
+  uint64_t hm[MID_EPT];
 #pragma unroll
-    for (int w = 0; w < XT / 64; w++)
-      if (w < wave) wbase = dsum_add(wbase, s_wsum[w]);
-    const uint64_t incl = dsum_add(wbase, ((uint64_t)phi << 32) | plo);
-    s_pq[threadIdx.x + 1] = incl;
-    if (threadIdx.x == 0) s_pq[0] = 0;
+  for (int e = 0; e < MID_EPT; e++) {
+    const uint32_t idx = e * XT + threadIdx.x;
+    head[e] = valid[e] && (idx == 0 || s_x[idx - 1] != x[e]);
+    hm[e] = __ballot(head[e]);
+    const int seg = e * (XT / 64) + wave;
+    if (lane == 0) s_wcnt[seg] = (uint32_t)__popcll(hm[e]);
+    uint64_t sbase = 0;
+    for (int w = 0; w < seg; w++) sbase = dsum_add(sbase, s_wsum[w]);
+    s_pq[idx + 1] = dsum_add(sbase, ((uint64_t)phi[e] << 32) | plo[e]);
   }
+  if (threadIdx.x == 0) s_pq[0] = 0;
   __syncthreads();
-  uint32_t hbase = 0, nruns = 0;
+  uint32_t nruns = 0;
 #pragma unroll
-  for (int w = 0; w < XT / 64; w++) {
-    if (w < wave) hbase += s_wcnt[w];
-    nruns += s_wcnt[w];
+  for (int w = 0; w < MID_SEG; w++) nruns += s_wcnt[w];
+#pragma unroll
+  for (int e = 0; e < MID_EPT; e++) {
+    if (head[e]) {
+      const int seg = e * (XT / 64) + wave;
+      uint32_t hbase = 0;
+      for (int w = 0; w < seg; w++) hbase += s_wcnt[w];
+      const uint32_t r = hbase + __popcll(hm[e] & ((1ULL << lane) - 1ULL));
+      s_run[r] = e * XT + threadIdx.x;
+      s_rst[r] = x_st[e];
+      s_rdout[r] = x_dout[e];
+    }
   }
-  if (head) {
-    const uint32_t r = hbase + __popcll(hm & ((1ULL << lane) - 1ULL));
-    s_run[r] = threadIdx.x;
-    s_rst[r] = x_st;
-    s_rdout[r] = x_dout;
-  }
-  const uint64_t remaining = M - (uint64_t)blockIdx.x * XT;
-  const uint32_t n_valid = remaining < XT ? (uint32_t)remaining : XT;
+  const uint64_t remaining = M - tile0;
+  const uint32_t n_valid = remaining < MT ? (uint32_t)remaining : MT;
   if (threadIdx.x == 0) s_run[nruns] = n_valid;
   __syncthreads();
 
@@ -768,7 +790,7 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
   }
   uint64_t rows2 = 0, dig1 = 0, dig2 = 0;
   if (M) {
-    const uint64_t n_tiles = (M + XT - 1) / XT;
+    const uint64_t n_tiles = (M + MT - 1) / MT;
     unsigned long long *partial = nullptr, *tmp = nullptr;
     GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
     GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
