@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries out of gpurun_out/ into profiles/ (tracked):
+   summarize_profiles.py <tag>   expects gpurun_out/prof_<tag>, pmc_fetch_<tag>, pmc_write_<tag> (rocprofv3 csv output)"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+out = os.path.join(ROOT, "profiles")
+ks = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*", "*kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(out, f"r01_{tag}_sf100_kernel_stats.csv"))
+res = {}
+lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --no-cpu (SF100, 1 MI355X)",
+         "# raw counter values are KB per dispatch (avg over dispatches); gfx950: FETCH_SIZE under-reports wide coalesced streams by 2x (MI355X_MICROARCH.md HBM section)"]
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{'fetch' if name == 'FETCH_SIZE' else 'write'}_{tag}", "*", "*counter_collection.csv"))
+    if not fs:
+        continue
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        d[r["Kernel_Name"].split("(")[0][:70]].append(float(r["Counter_Value"]))
+    lines.append(name)
+    for k, v in d.items():
+        lines.append("  %-70s n=%3d avg=%14.1f KB" % (k, len(v), sum(v) / len(v)))
+        res.setdefault(k, {})[name] = sum(v) / len(v)
+open(os.path.join(out, f"r01_{tag}_sf100_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+traffic = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, "
+           f"profiles/r01_{tag}_sf100_pmc_summary.txt): (2*FETCH_SIZE + WRITE_SIZE) * 1024; the factor 2 on FETCH_SIZE is the "
+           "gfx950 correction of MI355X_MICROARCH.md (upper bound for our 4-byte-per-lane coalesced loads)"}
+short = {"k_expand_mid2": "expand_mid2", "k_densify_hist": "densify_hist"}
+for k, v in res.items():
+    n = k.split("::")[-1].split("<")[0]
+    if n in short and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        traffic[f"sf100/{short[n]}/n1"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
