@@ -2,7 +2,7 @@
 //
 // Loaded with   LOAD '<repo>/duckdb_pgq_amd/gg_duckdb.duckdb_extension';
 // (PhysicalLoad: dlopen + <basename>_init / <basename>_version,
-//  src/execution/operator/helper/physical_load.cpp:29-70 of the reference).  It registers three table
+//  src/execution/operator/helper/physical_load.cpp:29-70 of the reference).  It registers four table
 // functions that the planner wraps in an ordinary PhysicalTableScan, so no reference
 // file changes:
 //
@@ -12,6 +12,9 @@
 //        -> (hops INTEGER, rows BIGINT, digest BIGINT, traversed_edges BIGINT)
 //   gg_shortest_path(vertex_table, vertex_key, edge_table, src_col, dst_col, sources_sql, max_hops)
 //        -> (startPerson BIGINT, friend BIGINT, hopCount INTEGER)
+//   gg_same_neighbour_paths(vertices_sql, sources_sql, path_table, path_src, path_dst,
+//                           filter_table, filter_src, filter_dst, hops)
+//        -> (w BIGINT, v0 BIGINT, ..., v{hops} BIGINT)      Train Benchmark ConnectedSegments
 //
 // Each function runs the operator classes of gg_operators.hpp exactly the way the reference's
 // PipelineExecutor would (pipeline_executor.cpp:47-131): source chunks -> Sink (per <=1024-row
@@ -110,6 +113,58 @@ static void GGFunction(ClientContext &context, const FunctionData *bind_data_p, 
 	data.source->GetData(ec, output, *data.gstate, lstate);
 }
 
+static vector<int64_t> QueryInt64Column(ClientContext &context, const string &sql, const char *what) {
+	Connection con(*context.db);
+	auto result = con.Query(sql);
+	if (!result->success) {
+		throw BinderException(string(what) + " query failed: " + result->error);
+	}
+	vector<int64_t> out;
+	for (idx_t r = 0; r < result->collection.Count(); r++) {
+		auto v = result->GetValue(0, r);
+		if (!v.is_null) {
+			out.push_back(v.GetValue<int64_t>());
+		}
+	}
+	return out;
+}
+
+//! gg_same_neighbour_paths(vertices_sql, sources_sql, path_table, path_src, path_dst,
+//!                         filter_table, filter_src, filter_dst, hops) -> (w, v0..v{hops})
+static unique_ptr<FunctionData> FilteredPathsBind(ClientContext &context, vector<Value> &inputs,
+                                                  unordered_map<string, Value> &named_parameters,
+                                                  vector<LogicalType> &input_table_types,
+                                                  vector<string> &input_table_names,
+                                                  vector<LogicalType> &return_types, vector<string> &names) {
+	const auto hops = inputs[8].GetValue<int64_t>();
+	if (hops < 1 || hops + 1 > GG_MAX_HOPS) {
+		throw BinderException("gg_same_neighbour_paths: need 1 <= hops <= " + to_string(GG_MAX_HOPS - 1));
+	}
+	auto data = make_unique<GGFunctionData>();
+	data->graph = make_shared<GGGraph>(0);
+	PhysicalGGVertexSink vsink(data->graph, {LogicalType::BIGINT}, 0);
+	RunSinkPipeline(context, inputs[0].ToString(), vsink);
+	PhysicalGGEdgeSink psink(data->graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0);
+	RunSinkPipeline(context,
+	                "SELECT " + Quote(inputs[3].ToString()) + ", " + Quote(inputs[4].ToString()) + " FROM " +
+	                    Quote(inputs[2].ToString()),
+	                psink);
+	PhysicalGGEdgeSink fsink(data->graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, true);
+	RunSinkPipeline(context,
+	                "SELECT " + Quote(inputs[6].ToString()) + ", " + Quote(inputs[7].ToString()) + " FROM " +
+	                    Quote(inputs[5].ToString()),
+	                fsink);
+	auto sources = QueryInt64Column(context, inputs[1].ToString(), "gg_same_neighbour_paths: sources");
+	data->source = make_unique<PhysicalGGFilteredPaths>(data->graph, (int)hops, move(sources), 0);
+	data->gstate = data->source->GetGlobalSourceState(context);
+	return_types = data->source->GetTypes();
+	names.push_back("w");
+	for (int64_t c = 0; c <= hops; c++) {
+		names.push_back("v" + to_string(c));
+	}
+	return move(data);
+}
+
 static void CheckHops(int64_t k_min, int64_t k_max) {
 	if (k_min < 1 || k_max < k_min || k_max > GG_MAX_HOPS) {
 		throw BinderException("gg: need 1 <= k_min <= k_max <= " + to_string(GG_MAX_HOPS));
@@ -162,20 +217,7 @@ static unique_ptr<FunctionData> ShortestBind(ClientContext &context, vector<Valu
                                              vector<string> &names) {
 	auto data = make_unique<GGFunctionData>();
 	data->graph = BuildGraph(context, inputs);
-	vector<int64_t> sources;
-	{
-		Connection con(*context.db);
-		auto result = con.Query(inputs[5].ToString());
-		if (!result->success) {
-			throw BinderException("gg_shortest_path: sources query failed: " + result->error);
-		}
-		for (idx_t r = 0; r < result->collection.Count(); r++) {
-			auto v = result->GetValue(0, r);
-			if (!v.is_null) {
-				sources.push_back(v.GetValue<int64_t>());
-			}
-		}
-	}
+	auto sources = QueryInt64Column(context, inputs[5].ToString(), "gg_shortest_path: sources");
 	data->source = make_unique<PhysicalGGShortestPath>(data->graph, move(sources), (int)inputs[6].GetValue<int64_t>(), 0);
 	data->gstate = data->source->GetGlobalSourceState(context);
 	return_types = data->source->GetTypes();
@@ -196,7 +238,13 @@ static void LoadInternal(DatabaseInstance &db) {
 	TableFunction khop("gg_khop", khop_args, GGFunction, KhopBind, GGInit);
 	TableFunction khop_count("gg_khop_count", khop_args, GGFunction, KhopCountBind, GGInit);
 	TableFunction shortest("gg_shortest_path", sp_args, GGFunction, ShortestBind, GGInit);
-	CreateTableFunctionInfo khop_info(khop), khop_count_info(khop_count), shortest_info(shortest);
+	TableFunction filtered("gg_same_neighbour_paths",
+	                       {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
+	                        LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
+	                        LogicalType::BIGINT},
+	                       GGFunction, FilteredPathsBind, GGInit);
+	CreateTableFunctionInfo khop_info(khop), khop_count_info(khop_count), shortest_info(shortest),
+	    filtered_info(filtered);
 
 	Connection con(db);
 	con.BeginTransaction();
@@ -204,6 +252,7 @@ static void LoadInternal(DatabaseInstance &db) {
 	catalog.CreateTableFunction(*con.context, &khop_info);
 	catalog.CreateTableFunction(*con.context, &khop_count_info);
 	catalog.CreateTableFunction(*con.context, &shortest_info);
+	catalog.CreateTableFunction(*con.context, &filtered_info);
 	con.Commit();
 }
 

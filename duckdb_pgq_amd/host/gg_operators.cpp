@@ -22,6 +22,9 @@ GGGraph::GGGraph(int device) {
 }
 
 GGGraph::~GGGraph() {
+	if (filter_csr) {
+		gg_csr_destroy(filter_csr);
+	}
 	if (csr) {
 		gg_csr_destroy(csr);
 	}
@@ -131,11 +134,16 @@ SinkFinalizeType PhysicalGGVertexSink::Finalize(Pipeline &pipeline, Event &event
 }
 
 PhysicalGGEdgeSink::PhysicalGGEdgeSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
-                                       idx_t estimated_cardinality)
-    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), graph(move(graph_p)) {
+                                       idx_t estimated_cardinality, bool as_filter_p)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), graph(move(graph_p)),
+      as_filter(as_filter_p) {
 }
 
 unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext &context) const {
+	if (as_filter) {
+		// second edge table over the same staged vertices: drop the first table's staged rows only
+		GGGraph::Check(gg_staging_clear_edges(graph->ctx), "gg_staging_clear_edges");
+	}
 	return make_unique<GGSinkGlobalState>();
 }
 
@@ -163,11 +171,12 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
                                               GlobalSinkState &gstate) const {
 	// single-threaded, after every Sink/Combine (physical_operator.hpp:145-147): build the index
 	lock_guard<mutex> guard(graph->lock);
-	if (graph->csr) {
-		gg_csr_destroy(graph->csr);
-		graph->csr = nullptr;
+	gg_csr *&target = as_filter ? graph->filter_csr : graph->csr;
+	if (target) {
+		gg_csr_destroy(target);
+		target = nullptr;
 	}
-	GGGraph::Check(gg_csr_build(graph->ctx, &graph->csr), "gg_csr_build");
+	GGGraph::Check(gg_csr_build(graph->ctx, &target), "gg_csr_build");
 	return SinkFinalizeType::READY;
 }
 
@@ -290,6 +299,71 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 		chunk.data[1 + c].SetVectorType(VectorType::CONSTANT_VECTOR);
 		ConstantVector::SetNull(chunk.data[1 + c], true);
 	}
+	chunk.SetCardinality(n);
+}
+
+//===--------------------------------------------------------------------===//
+// Filtered paths source (ConnectedSegments)
+//===--------------------------------------------------------------------===//
+class GGFilteredGlobalState : public GlobalSourceState {
+public:
+	~GGFilteredGlobalState() override {
+		if (result) {
+			gg_result_destroy(result);
+		}
+	}
+	gg_result *result = nullptr;
+	idx_t rows = 0;
+	idx_t offset = 0;
+};
+
+static vector<LogicalType> BigintColumns(idx_t n) {
+	return vector<LogicalType>(n, LogicalType::BIGINT);
+}
+
+PhysicalGGFilteredPaths::PhysicalGGFilteredPaths(shared_ptr<GGGraph> graph_p, int hops_p, vector<int64_t> sources_p,
+                                                 idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, BigintColumns(hops_p + 2), estimated_cardinality),
+      graph(move(graph_p)), hops(hops_p), sources(move(sources_p)) {
+}
+
+unique_ptr<GlobalSourceState> PhysicalGGFilteredPaths::GetGlobalSourceState(ClientContext &context) const {
+	auto state = make_unique<GGFilteredGlobalState>();
+	lock_guard<mutex> guard(graph->lock);
+	if (!graph->csr || !graph->filter_csr) {
+		throw InternalException("GG_FILTERED_PATHS scheduled before both CSRs were built");
+	}
+	gg_khop_stats stats;
+	gg_result *paths = nullptr;
+	GGGraph::Check(gg_expand_khop_result(graph->ctx, graph->csr, sources.data(), sources.size(), hops, hops, &stats,
+	                                     &paths),
+	               "gg_expand_khop_result");
+	int rc = gg_result_filter_common_neighbour(graph->ctx, paths, hops, graph->filter_csr, &state->result);
+	gg_result_destroy(paths);
+	GGGraph::Check(rc, "gg_result_filter_common_neighbour");
+	uint64_t n = 0;
+	GGGraph::Check(gg_result_rows(state->result, hops + 1, &n), "gg_result_rows");
+	state->rows = n;
+	return move(state);
+}
+
+void PhysicalGGFilteredPaths::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
+                                      LocalSourceState &lstate) const {
+	auto &gstate = (GGFilteredGlobalState &)gstate_p;
+	if (gstate.offset >= gstate.rows) {
+		return;
+	}
+	int64_t *cols[GG_MAX_HOPS + 2];
+	for (int c = 0; c <= hops + 1; c++) {
+		cols[c] = FlatVector::GetData<int64_t>(chunk.data[c]);
+	}
+	uint32_t n = 0;
+	{
+		lock_guard<mutex> guard(graph->lock);
+		GGGraph::Check(gg_result_fetch(gstate.result, hops + 1, gstate.offset, STANDARD_VECTOR_SIZE, cols, &n),
+		               "gg_result_fetch");
+	}
+	gstate.offset += n;
 	chunk.SetCardinality(n);
 }
 

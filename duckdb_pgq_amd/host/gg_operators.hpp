@@ -36,7 +36,8 @@ struct GGGraph {
 	static void Check(int rc, const char *what);
 
 	gg_ctx *ctx = nullptr;
-	gg_csr *csr = nullptr;
+	gg_csr *csr = nullptr;        // path graph
+	gg_csr *filter_csr = nullptr; // optional second edge table over the same vertex set (same-neighbour filter)
 	std::mutex lock; // gg calls other than the appends are externally serialised (gg.h)
 };
 
@@ -73,9 +74,13 @@ public:
 //! Input columns: (source key, destination key[, edge rowid]).  Finalize builds the CSR.
 class PhysicalGGEdgeSink : public PhysicalOperator {
 public:
-	PhysicalGGEdgeSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality);
+	//! as_filter: the rows are a SECOND edge table over the already staged vertex set; Finalize builds
+	//! GGGraph::filter_csr instead of GGGraph::csr
+	PhysicalGGEdgeSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality,
+	                   bool as_filter = false);
 
 	shared_ptr<GGGraph> graph;
+	bool as_filter;
 
 public:
 	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
@@ -124,6 +129,31 @@ public:
 	}
 	string GetName() const override {
 		return "GG_PATH_EXPAND";
+	}
+};
+
+//! Source: fixed-length walks whose vertices all share a neighbour in the filter graph — Train Benchmark
+//! ConnectedSegments (benchmark/trainbenchmark/queries/connectedsegments.sql:1-25): `hops` connectsTo
+//! edges from the source segments, all hops+1 segments monitored by one sensor.
+//! Output: (w BIGINT, v0 BIGINT, ..., v{hops} BIGINT).
+class PhysicalGGFilteredPaths : public PhysicalOperator {
+public:
+	PhysicalGGFilteredPaths(shared_ptr<GGGraph> graph, int hops, vector<int64_t> sources,
+	                        idx_t estimated_cardinality);
+
+	shared_ptr<GGGraph> graph;
+	int hops;
+	vector<int64_t> sources;
+
+public:
+	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
+	             LocalSourceState &lstate) const override;
+	bool IsSource() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_FILTERED_PATHS";
 	}
 };
 
