@@ -206,7 +206,6 @@ def main():
 
     # ---- roofline of the dominant kernel on this rank ---------------------------------------------------
     # dominant kernel = largest total time in the timed region; algorithmic bytes per launch
-    E_kept = rows1 if world == 1 else R
     alg = {
         "expand_mid2": 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"],
         "expand_fused2": 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"],

@@ -95,9 +95,15 @@ __global__ __launch_bounds__(256) void k_ht_insert(const int64_t *__restrict__ v
 // order is fully determined (stable).  Elements are first ranked INSIDE the tile and staged in LDS in
 // digit order, then written out: consecutive LDS slots of one digit go to consecutive global
 // addresses, so the global stores are coalesced runs instead of 4-byte scatters.
-constexpr int RB_THREADS = 512;                    // 8 waves share one 4096-element tile (LDS-bound occupancy)
+#ifndef GG_RB_THREADS
+#define GG_RB_THREADS 512
+#endif
+constexpr int RB_THREADS = GG_RB_THREADS;          // 8 waves share one 4096-element tile (LDS-bound occupancy)
 constexpr int RB_WAVES = RB_THREADS / 64;
-constexpr int RB_ITEMS = 8;                        // elements per lane
+#ifndef GG_RB_ITEMS
+#define GG_RB_ITEMS 8
+#endif
+constexpr int RB_ITEMS = GG_RB_ITEMS;              // elements per lane
 constexpr int RB_TILE = RB_THREADS * RB_ITEMS;     // 4096 elements per workgroup
 constexpr int RB_WTILE = RB_TILE / RB_WAVES;       // 1024 per wave
 constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
@@ -105,19 +111,16 @@ constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
 // Densify + pass-0 histogram.  One lane per edge row: two id lookups (hash table is V-sized, L2 /
 // Infinity-Cache resident), dense endpoints written coalesced, digit counted in the tile's LDS histogram.
 // counts[digit * nblocks + block] = number of valid elements of that tile with that digit
-__global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
-    const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
-    uint64_t cap, const BuildStatus *__restrict__ st, uint32_t part, uint32_t n_parts,
-    uint32_t *__restrict__ fk, uint32_t *__restrict__ fv, uint32_t *__restrict__ rk /* nullable */,
-    uint32_t *__restrict__ rv /* nullable */, uint32_t bits, uint64_t nblocks, uint32_t *__restrict__ counts,
-    uint32_t *__restrict__ counts_r /* nullable */) {
+__global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__restrict__ src,
+                                                             const int64_t *__restrict__ dst, uint64_t E,
+                                                             const HtSlot *__restrict__ ht, uint64_t cap,
+                                                             const BuildStatus *__restrict__ st,
+                                                             uint32_t *__restrict__ fk, uint32_t *__restrict__ fv,
+                                                             uint32_t bits, uint64_t nblocks,
+                                                             uint32_t *__restrict__ counts) {
   __shared__ uint32_t hist[1 << RB_MAX_BITS];
-  __shared__ uint32_t hist_r[1 << RB_MAX_BITS];
   const uint32_t ndig = 1u << bits;
-  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) {
-    hist[i] = 0;
-    hist_r[i] = 0;
-  }
+  for (uint32_t i = threadIdx.x; i < ndig; i += RB_THREADS) hist[i] = 0;
   __syncthreads();
   const int64_t min_idx = st->min_idx;
   const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
@@ -126,50 +129,37 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(
     int64_t ks[B], kd[B];
     uint64_t ss[B], sd[B];
     uint4 rs[B], rd[B];
-    bool of[B], orv[B];
 #pragma unroll
     for (int j = 0; j < B; j++) {
       const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
       ks[j] = e < E ? src[e] : HT_EMPTY;
       kd[j] = e < E ? dst[e] : HT_EMPTY;
-      of[j] = e < E && owns(ks[j], part, n_parts);   // edge belongs to this shard's forward CSR
-      orv[j] = e < E && owns(kd[j], part, n_parts);  // ... reverse CSR
     }
 #pragma unroll
     for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
       ss[j] = ht_slot(ks[j], cap);
       sd[j] = ht_slot(kd[j], cap);
-      if (of[j] || orv[j]) {
-        rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
-        rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
-      }
+      rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
+      rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
     }
 #pragma unroll
     for (int j = 0; j < B; j++) {
       const uint64_t e = base + (uint64_t)(it0 + j) * RB_THREADS + threadIdx.x;
       if (e >= E) continue;
-      uint32_t u = INVALID_U32, v = INVALID_U32;
-      if (of[j] || orv[j]) {
-        u = ht_resolve(ht, cap, min_idx, ks[j], ss[j], rs[j]);
-        v = ht_resolve(ht, cap, min_idx, kd[j], sd[j], rd[j]);
+      uint32_t u = ht_resolve(ht, cap, min_idx, ks[j], ss[j], rs[j]);
+      uint32_t v = ht_resolve(ht, cap, min_idx, kd[j], sd[j], rd[j]);
+      if (u == INVALID_U32 || v == INVALID_U32) {
+        u = INVALID_U32;  // dropped: an endpoint is not a vertex (inner-join semantics)
+        v = INVALID_U32;
+      } else {
+        atomicAdd(&hist[u & (ndig - 1)], 1u);
       }
-      const bool ok = u != INVALID_U32 && v != INVALID_U32;
-      const bool f = ok && of[j], r = ok && orv[j];
-      if (f) atomicAdd(&hist[u & (ndig - 1)], 1u);
-      fk[e] = f ? u : INVALID_U32;
+      fk[e] = u;
       fv[e] = v;
-      if (rk) {
-        if (r) atomicAdd(&hist_r[v & (ndig - 1)], 1u);
-        rk[e] = r ? v : INVALID_U32;
-        rv[e] = u;
-      }
     }
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) {
-    counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
-    if (counts_r) counts_r[(uint64_t)d * nblocks + blockIdx.x] = hist_r[d];
-  }
+  for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
 }
 
 // Shard builds (gg_csr_build_shard): only the rows this rank owns survive, 1/N of the table per
@@ -695,8 +685,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
       GG_TRY(radix_sort_stable(ctx, ior, E, false, false, key_bits, counts0r, bits0, kept_rev_dev, false, tvr));
     } else {
       GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
-                ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts, su, dv, rk, rv,
-                (uint32_t)bits0, nblocks64, counts0, counts0r);
+                ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, su, dv, (uint32_t)bits0, nblocks64, counts0);
       // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
       RadixIO io{su, dv, nullptr, csr->row, csr->nbr, csr->epos};
       GG_TRY(radix_sort_stable(ctx, io, E, true, true, key_bits, counts0, bits0, kept_dev, false));
