@@ -139,13 +139,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the gg hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; GG_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path
+    backend = os.environ.get("GG_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:
@@ -159,7 +165,7 @@ def main():
     vid, src, dst = pkg.datagen.ldbc(args.workload)
     t_gen = time.perf_counter() - t0
     V, R = vid.size, src.size
-    gg = pkg.GG(local_rank)
+    gg = pkg.GG(device_index)
     t0 = time.perf_counter()
     gg.chunk_rows = 122_880  # one DuckDB row group per append (storage/table/row_group.hpp:38-39)
     gg.append_vertices(vid)
