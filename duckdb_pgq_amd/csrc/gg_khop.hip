@@ -291,122 +291,140 @@ constexpr int MID_EPT = GG_MID_EPT;    // reverse-CSR entries per thread
 constexpr int MT = XT * MID_EPT;       // entries per tile (workgroup): 512
 constexpr int MID_SEG = MID_EPT * (XT / 64);  // (entry slot, wave) segments of a tile, in position order
 
-__global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
-                                                    const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
-                                                    uint64_t fbase, uint64_t M, int emit_mid,
-                                                    unsigned long long *__restrict__ partial) {
-  __shared__ uint64_t s_q[MT];
-  __shared__ uint64_t s_pq[MT + 1];   // lane-wise prefix sums of s_q: s_pq[i] = sum of s_q[0..i)
-  __shared__ uint32_t s_x[MT];
-  __shared__ uint32_t s_run[MT + 1];  // tile position where each run of equal x starts (+ end sentinel)
-  __shared__ uint32_t s_rst[MT];      // per run: start of out-row x in nbr
-  __shared__ uint32_t s_rdout[MT];    // per run: out-degree of x
-  __shared__ uint32_t s_wcnt[MID_SEG];
-  __shared__ uint64_t s_wsum[MID_SEG];
-  __shared__ uint64_t s_red[12];
+struct MidShared {  // LDS image of one tile
+  uint64_t q[MT];          // hash state q_1 of each 1-hop row of the tile
+  uint64_t pq[MT + 1];     // lane-wise prefix sums of q: pq[i] = sum of q[0..i)
+  uint32_t x[MT];          // middle vertex of each row
+  uint32_t run[MT + 1];    // tile position where each run of equal x starts (+ end sentinel)
+  uint32_t rst[MT];        // per run: start of out-row x in nbr
+  uint32_t rdout[MT];      // per run: out-degree of x
+  uint32_t wcnt[MID_SEG];
+  uint64_t wsum[MID_SEG];
+  uint64_t red[12];
+};
 
-  // reverse-CSR entry p is the 1-hop row u -> x with x = rrow[p] (COO view of the reverse CSR), u = rnbr[p]:
-  // two coalesced loads, no search.  Tile position of thread t's e-th entry: e*XT + t.
-  const uint64_t tile0 = (uint64_t)blockIdx.x * MT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint64_t mid_sum = 0, rows_last = 0;
-  uint32_t x[MID_EPT], x_st[MID_EPT], x_dout[MID_EPT], plo[MID_EPT], phi[MID_EPT];
+struct MidRows {  // a thread's MID_EPT rows of one tile, as loaded from the reverse CSR
+  uint32_t x[MID_EPT], u[MID_EPT];
   bool valid[MID_EPT];
+};
+struct MidPrep {  // the same rows after hashing and the out-row lookups
+  uint64_t q[MID_EPT];
+  uint32_t st[MID_EPT], dout[MID_EPT];
+};
+
+// stage 1: reverse-CSR entry p is the 1-hop row u -> x with x = rrow[p] (COO view), u = rnbr[p]:
+// two coalesced loads, no search.  Tile position of thread t's e-th entry: e*XT + t.
+__device__ __forceinline__ void mid_load_rows(const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
+                                              uint64_t fbase, uint64_t M, uint64_t tile, MidRows &r) {
+#pragma unroll
+  for (int e = 0; e < MID_EPT; e++) {
+    const uint64_t i = tile * MT + (uint64_t)(e * XT) + threadIdx.x;
+    r.valid[e] = i < M;
+    r.x[e] = INVALID_U32;
+    r.u[e] = 0;
+    if (r.valid[e]) {
+      r.x[e] = rrow[fbase + i];
+      r.u[e] = rnbr[fbase + i];
+    }
+  }
+}
+
+// stage 2: row hashes (two fmix64 each) and the out-row extents of the middle vertices (gathers)
+__device__ __forceinline__ void mid_prepare(const uint32_t *__restrict__ off, const MidRows &r, int emit_mid,
+                                            MidPrep &p, uint64_t &mid_sum, uint64_t &rows_last) {
+#pragma unroll
+  for (int e = 0; e < MID_EPT; e++) {
+    p.q[e] = 0;
+    p.st[e] = p.dout[e] = 0;
+    if (r.valid[e]) {
+      p.st[e] = off[r.x[e]];
+      p.dout[e] = off[r.x[e] + 1] - p.st[e];
+      const uint64_t P = dig_leaf(dig_q((uint64_t)r.u[e], 0), r.x[e]);
+      if (emit_mid) mid_sum = dsum_add(mid_sum, P);
+      p.q[e] = dig_q(P, 1);
+      rows_last += (uint64_t)p.dout[e];
+    }
+  }
+}
+
+// stage 3: LDS image of the tile (states, their prefix sums, runs of equal middle vertex).  Returns the
+// number of runs.  Contains three workgroup barriers; the caller must have finished reading the previous image.
+__device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, const MidPrep &p, uint64_t M,
+                                              uint64_t tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t plo[MID_EPT], phi[MID_EPT];
 #pragma unroll
   for (int e = 0; e < MID_EPT; e++) {
     const uint32_t idx = e * XT + threadIdx.x;
-    const uint64_t p = fbase + tile0 + idx;
-    valid[e] = tile0 + idx < M;
-    uint64_t myq = 0;
-    x[e] = INVALID_U32;
-    x_st[e] = x_dout[e] = 0;
-    if (valid[e]) {
-      x[e] = rrow[p];
-      const uint32_t u = rnbr[p];
-      const uint64_t P = dig_leaf(dig_q((uint64_t)u, 0), x[e]);
-      if (emit_mid) mid_sum = dsum_add(mid_sum, P);
-      myq = dig_q(P, 1);
-      x_st[e] = off[x[e]];
-      x_dout[e] = off[x[e] + 1] - x_st[e];
-      rows_last += (uint64_t)x_dout[e];
-    }
-    s_q[idx] = myq;
-    s_x[idx] = x[e];
-    // lane-wise inclusive scan of q inside the wave, segment totals through LDS
-    plo[e] = (uint32_t)myq;
-    phi[e] = (uint32_t)(myq >> 32);
+    sm.q[idx] = p.q[e];
+    sm.x[idx] = r.x[e];
+    plo[e] = (uint32_t)p.q[e];
+    phi[e] = (uint32_t)(p.q[e] >> 32);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
+    for (int o = 1; o < 64; o <<= 1) {  // lane-wise inclusive scan inside the wave
       const uint32_t a = __shfl_up(plo[e], o, 64), b = __shfl_up(phi[e], o, 64);
       if (lane >= o) {
         plo[e] += a;
         phi[e] += b;
       }
     }
-    if (lane == 63) s_wsum[e * (XT / 64) + wave] = ((uint64_t)phi[e] << 32) | plo[e];
+    if (lane == 63) sm.wsum[e * (XT / 64) + wave] = ((uint64_t)phi[e] << 32) | plo[e];
   }
   __syncthreads();
-
-  // run heads -> compact list of run start positions (ballot + popcount, segment bases through LDS)
   bool head[MID_EPT];
   uint64_t hm[MID_EPT];
 #pragma unroll
   for (int e = 0; e < MID_EPT; e++) {
     const uint32_t idx = e * XT + threadIdx.x;
-    head[e] = valid[e] && (idx == 0 || s_x[idx - 1] != x[e]);
+    head[e] = r.valid[e] && (idx == 0 || sm.x[idx - 1] != r.x[e]);
     hm[e] = __ballot(head[e]);
     const int seg = e * (XT / 64) + wave;
-    if (lane == 0) s_wcnt[seg] = (uint32_t)__popcll(hm[e]);
+    if (lane == 0) sm.wcnt[seg] = (uint32_t)__popcll(hm[e]);
     uint64_t sbase = 0;
-    for (int w = 0; w < seg; w++) sbase = dsum_add(sbase, s_wsum[w]);
-    s_pq[idx + 1] = dsum_add(sbase, ((uint64_t)phi[e] << 32) | plo[e]);
+    for (int w = 0; w < seg; w++) sbase = dsum_add(sbase, sm.wsum[w]);
+    sm.pq[idx + 1] = dsum_add(sbase, ((uint64_t)phi[e] << 32) | plo[e]);
   }
-  if (threadIdx.x == 0) s_pq[0] = 0;
+  if (threadIdx.x == 0) sm.pq[0] = 0;
   __syncthreads();
   uint32_t nruns = 0;
 #pragma unroll
-  for (int w = 0; w < MID_SEG; w++) nruns += s_wcnt[w];
+  for (int w = 0; w < MID_SEG; w++) nruns += sm.wcnt[w];
 #pragma unroll
   for (int e = 0; e < MID_EPT; e++) {
     if (head[e]) {
       const int seg = e * (XT / 64) + wave;
       uint32_t hbase = 0;
-      for (int w = 0; w < seg; w++) hbase += s_wcnt[w];
-      const uint32_t r = hbase + __popcll(hm[e] & ((1ULL << lane) - 1ULL));
-      s_run[r] = e * XT + threadIdx.x;
-      s_rst[r] = x_st[e];
-      s_rdout[r] = x_dout[e];
+      for (int w = 0; w < seg; w++) hbase += sm.wcnt[w];
+      const uint32_t rr = hbase + __popcll(hm[e] & ((1ULL << lane) - 1ULL));
+      sm.run[rr] = e * XT + threadIdx.x;
+      sm.rst[rr] = p.st[e];
+      sm.rdout[rr] = p.dout[e];
     }
   }
-  const uint64_t remaining = M - tile0;
-  const uint32_t n_valid = remaining < MT ? (uint32_t)remaining : MT;
-  if (threadIdx.x == 0) s_run[nruns] = n_valid;
+  const uint64_t remaining = M - tile * MT;
+  if (threadIdx.x == 0) sm.run[nruns] = remaining < MT ? (uint32_t)remaining : MT;
   __syncthreads();
+  return nruns;
+}
 
-  uint32_t alo[MID_R], ahi[MID_R];
-#pragma unroll
-  for (int r = 0; r < MID_R; r++) alo[r] = ahi[r] = 0;
-  uint64_t corr = 0;  // what lanes holding no leaf accumulated (q ^ 0), removed at the end
-
-#ifdef GG_EXP_NO_PHASE2  // timing experiment only (results are wrong): how much is phase 1?
-  if (nruns > XT) {
-#else
-  {
-#endif
+// stage 4: fold every staged state against the out-row of its run's middle vertex
+__device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nruns, const uint32_t *__restrict__ nbr,
+                                              uint32_t (&alo)[MID_R], uint32_t (&ahi)[MID_R], uint64_t &corr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t rr = 0; rr < nruns; rr++) {
-    const int a = (int)s_run[rr], b = (int)s_run[rr + 1];
+    const int a = (int)sm.run[rr], b = (int)sm.run[rr + 1];
     const int len = b - a;
     // long runs: every wave takes a slice of the run (i-split) and walks all J-blocks;
     // short runs: the whole run belongs to ONE wave (dealt round-robin), the others skip it at once
     const bool isplit = len >= 16;
     if (!isplit && (rr & (XT / 64 - 1)) != (uint32_t)wave) continue;
-    const uint32_t dout = s_rdout[rr];
+    const uint32_t dout = sm.rdout[rr];
     if (dout == 0) continue;
-    const uint32_t *__restrict__ row = nbr + s_rst[rr];
+    const uint32_t *__restrict__ row = nbr + sm.rst[rr];
     const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
     const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : b;
     if (ia >= ib) continue;
-    const uint64_t sq = dsum_sub(s_pq[ib], s_pq[ia]);  // sum of the slice's hash states
+    const uint64_t sq = dsum_sub(sm.pq[ib], sm.pq[ia]);  // sum of the slice's hash states
     // J-blocks of equal size (multiple of 64 leaves, at most 64*MID_R): avoids a nearly empty tail block
     const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
     const uint32_t jsz = (((dout + nJ - 1) / nJ) + 63) & ~63u;
@@ -425,23 +443,40 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
         if (!ok && r < nreg) ninv++;
       }
       if (nreg == MID_R)
-        mid_accumulate<MID_R>(s_q, ia, ib, tlo, thi, alo, ahi);
+        mid_accumulate<MID_R>(sm.q, ia, ib, tlo, thi, alo, ahi);
       else if (nreg == 3)
-        mid_accumulate<3>(s_q, ia, ib, tlo, thi, alo, ahi);
+        mid_accumulate<3>(sm.q, ia, ib, tlo, thi, alo, ahi);
       else if (nreg == 2)
-        mid_accumulate<2>(s_q, ia, ib, tlo, thi, alo, ahi);
+        mid_accumulate<2>(sm.q, ia, ib, tlo, thi, alo, ahi);
       else
-        mid_accumulate<1>(s_q, ia, ib, tlo, thi, alo, ahi);
+        mid_accumulate<1>(sm.q, ia, ib, tlo, thi, alo, ahi);
       // a lane without a leaf added q ^ 0 = q for every state of the slice
       for (uint32_t c = 0; c < ninv; c++) corr = dsum_add(corr, sq);
     }
   }
-  }
+}
+
+// One tile per workgroup.
+__global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                    const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
+                                                    uint64_t fbase, uint64_t M, int emit_mid,
+                                                    unsigned long long *__restrict__ partial) {
+  __shared__ MidShared sm;
+  uint64_t mid_sum = 0, rows_last = 0, corr = 0;
+  uint32_t alo[MID_R], ahi[MID_R];
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) alo[r] = ahi[r] = 0;
+  MidRows rows;
+  MidPrep prep;
+  mid_load_rows(rrow, rnbr, fbase, M, blockIdx.x, rows);
+  mid_prepare(off, rows, emit_mid, prep, mid_sum, rows_last);
+  const uint32_t nruns = mid_stage(sm, rows, prep, M, blockIdx.x);
+  mid_fold_tile(sm, nruns, nbr, alo, ahi, corr);
   uint64_t total = 0;
 #pragma unroll
   for (int r = 0; r < MID_R; r++) total = dsum_add(total, ((uint64_t)ahi[r] << 32) | alo[r]);
   total = dsum_sub(total, corr);
-  block_store_partials(mid_sum, total, rows_last, s_red, partial);
+  block_store_partials(mid_sum, total, rows_last, sm.red, partial);
 }
 
 // per-vertex work of the product kernel: in-degree x (1 + out-degree)
