@@ -218,26 +218,19 @@ __device__ __forceinline__ uint32_t ht_resolve(const HtSlot *__restrict__ ht, ui
   }
 }
 
-// Digest sums are LANE-WISE: two independent u32 sums (low / high half of the row hash), no carry
-// between the halves.  One v_xad_u32 (xor + add) per half per walk on gfx950.
+// Digest sums are 32-bit: the LOW half of each row hash, summed mod 2^32 (carried in u64 fields whose
+// high half stays zero).  One v_xad_u32 (xor + add) per walk in the product kernel.
 __host__ __device__ __forceinline__ uint64_t dsum_add(uint64_t a, uint64_t b) {
-  const uint32_t lo = (uint32_t)a + (uint32_t)b;
-  const uint32_t hi = (uint32_t)(a >> 32) + (uint32_t)(b >> 32);
-  return ((uint64_t)hi << 32) | lo;
+  return (uint64_t)(uint32_t)((uint32_t)a + (uint32_t)b);
 }
 __host__ __device__ __forceinline__ uint64_t dsum_sub(uint64_t a, uint64_t b) {
-  const uint32_t lo = (uint32_t)a - (uint32_t)b;
-  const uint32_t hi = (uint32_t)(a >> 32) - (uint32_t)(b >> 32);
-  return ((uint64_t)hi << 32) | lo;
+  return (uint64_t)(uint32_t)((uint32_t)a - (uint32_t)b);
 }
 __device__ __forceinline__ uint64_t wave_reduce_dsum(uint64_t v) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  uint32_t lo = (uint32_t)v;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    lo += __shfl_xor(lo, o, 64);
-    hi += __shfl_xor(hi, o, 64);
-  }
-  return ((uint64_t)hi << 32) | lo;
+  for (int o = 32; o > 0; o >>= 1) lo += __shfl_xor(lo, o, 64);
+  return (uint64_t)lo;
 }
 
 __device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v) {

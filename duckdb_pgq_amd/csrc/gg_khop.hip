@@ -248,40 +248,30 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced) and every
 // staged state of the run is folded against it (LDS broadcast read + 4 VALU ops per walk).  The kernel
 // is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
-constexpr int MID_R = 4;  // out-row values per lane per J-block: a J-block covers 64*MID_R = 256 leaves
+constexpr int MID_R = 8;  // out-row values per lane per J-block: a J-block covers 64*MID_R = 512 leaves
 
 #define GG_XAD(acc, q, t) asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(q), "v"(t))
 
-// acc = (q ^ t) + acc in ONE instruction per 32-bit half; spelled out because the compiler otherwise
-// splits the unrolled loop into v_xor_b32 + v_add3_u32 (12 instead of 8 VALU per state at NREG = 4).
+// acc = (q ^ t) + acc in ONE instruction per walk; spelled out because the compiler otherwise splits the
+// unrolled loop into v_xor_b32 + v_add3_u32.
 template <int NREG>
-__device__ __forceinline__ void mid_fold(uint64_t q, const uint32_t (&tlo)[MID_R], const uint32_t (&thi)[MID_R],
-                                         uint32_t (&alo)[MID_R], uint32_t (&ahi)[MID_R]) {
-  const uint32_t qlo = (uint32_t)q, qhi = (uint32_t)(q >> 32);
+__device__ __forceinline__ void mid_fold(uint32_t q, const uint32_t (&t)[MID_R], uint32_t (&acc)[MID_R]) {
 #pragma unroll
-  for (int r = 0; r < NREG; r++) {
-    GG_XAD(alo[r], qlo, tlo[r]);
-    GG_XAD(ahi[r], qhi, thi[r]);
-  }
+  for (int r = 0; r < NREG; r++) GG_XAD(acc[r], q, t[r]);
 }
 
 template <int NREG>
-__device__ __forceinline__ void mid_accumulate(const uint64_t *s_q, int ia, int ib, const uint32_t (&tlo)[MID_R],
-                                               const uint32_t (&thi)[MID_R], uint32_t (&alo)[MID_R],
-                                               uint32_t (&ahi)[MID_R]) {
+__device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int ib, const uint32_t (&t)[MID_R],
+                                               uint32_t (&acc)[MID_R]) {
   int i = ia;
   for (; i + 4 <= ib; i += 4) {  // 4 states per trip: their LDS broadcast reads issue back to back
-#ifdef GG_EXP_NO_LDS  // timing experiment only: hash states from a register instead of LDS
-    const uint64_t q0 = (uint64_t)i * 0x9E3779B97F4A7C15ULL, q1 = q0 + 1, q2 = q0 + 2, q3 = q0 + 3;
-#else
-    const uint64_t q0 = s_q[i], q1 = s_q[i + 1], q2 = s_q[i + 2], q3 = s_q[i + 3];
-#endif
-    mid_fold<NREG>(q0, tlo, thi, alo, ahi);
-    mid_fold<NREG>(q1, tlo, thi, alo, ahi);
-    mid_fold<NREG>(q2, tlo, thi, alo, ahi);
-    mid_fold<NREG>(q3, tlo, thi, alo, ahi);
+    const uint32_t q0 = s_q[i], q1 = s_q[i + 1], q2 = s_q[i + 2], q3 = s_q[i + 3];
+    mid_fold<NREG>(q0, t, acc);
+    mid_fold<NREG>(q1, t, acc);
+    mid_fold<NREG>(q2, t, acc);
+    mid_fold<NREG>(q3, t, acc);
   }
-  for (; i < ib; i++) mid_fold<NREG>(s_q[i], tlo, thi, alo, ahi);
+  for (; i < ib; i++) mid_fold<NREG>(s_q[i], t, acc);
 }
 
 #ifndef GG_MID_EPT
@@ -292,14 +282,14 @@ constexpr int MT = XT * MID_EPT;       // entries per tile (workgroup): 512
 constexpr int MID_SEG = MID_EPT * (XT / 64);  // (entry slot, wave) segments of a tile, in position order
 
 struct MidShared {  // LDS image of one tile
-  uint64_t q[MT];          // hash state q_1 of each 1-hop row of the tile
-  uint64_t pq[MT + 1];     // lane-wise prefix sums of q: pq[i] = sum of q[0..i)
+  uint32_t q[MT];          // low half of the hash state q_1 of each 1-hop row of the tile
+  uint32_t pq[MT + 1];     // prefix sums (mod 2^32) of q: pq[i] = sum of q[0..i)
   uint32_t x[MT];          // middle vertex of each row
   uint32_t run[MT + 1];    // tile position where each run of equal x starts (+ end sentinel)
   uint32_t rst[MT];        // per run: start of out-row x in nbr
   uint32_t rdout[MT];      // per run: out-degree of x
   uint32_t wcnt[MID_SEG];
-  uint64_t wsum[MID_SEG];
+  uint32_t wsum[MID_SEG];
   uint64_t red[12];
 };
 
@@ -352,23 +342,19 @@ __device__ __forceinline__ void mid_prepare(const uint32_t *__restrict__ off, co
 __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, const MidPrep &p, uint64_t M,
                                               uint64_t tile) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t plo[MID_EPT], phi[MID_EPT];
+  uint32_t plo[MID_EPT];
 #pragma unroll
   for (int e = 0; e < MID_EPT; e++) {
     const uint32_t idx = e * XT + threadIdx.x;
-    sm.q[idx] = p.q[e];
+    sm.q[idx] = (uint32_t)p.q[e];
     sm.x[idx] = r.x[e];
     plo[e] = (uint32_t)p.q[e];
-    phi[e] = (uint32_t)(p.q[e] >> 32);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {  // lane-wise inclusive scan inside the wave
-      const uint32_t a = __shfl_up(plo[e], o, 64), b = __shfl_up(phi[e], o, 64);
-      if (lane >= o) {
-        plo[e] += a;
-        phi[e] += b;
-      }
+    for (int o = 1; o < 64; o <<= 1) {  // inclusive scan (mod 2^32) inside the wave
+      const uint32_t a = __shfl_up(plo[e], o, 64);
+      if (lane >= o) plo[e] += a;
     }
-    if (lane == 63) sm.wsum[e * (XT / 64) + wave] = ((uint64_t)phi[e] << 32) | plo[e];
+    if (lane == 63) sm.wsum[e * (XT / 64) + wave] = plo[e];
   }
   __syncthreads();
   bool head[MID_EPT];
@@ -380,9 +366,9 @@ __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, c
     hm[e] = __ballot(head[e]);
     const int seg = e * (XT / 64) + wave;
     if (lane == 0) sm.wcnt[seg] = (uint32_t)__popcll(hm[e]);
-    uint64_t sbase = 0;
-    for (int w = 0; w < seg; w++) sbase = dsum_add(sbase, sm.wsum[w]);
-    sm.pq[idx + 1] = dsum_add(sbase, ((uint64_t)phi[e] << 32) | plo[e]);
+    uint32_t sbase = 0;
+    for (int w = 0; w < seg; w++) sbase += sm.wsum[w];
+    sm.pq[idx + 1] = sbase + plo[e];
   }
   if (threadIdx.x == 0) sm.pq[0] = 0;
   __syncthreads();
@@ -409,7 +395,7 @@ __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, c
 
 // stage 4: fold every staged state against the out-row of its run's middle vertex
 __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nruns, const uint32_t *__restrict__ nbr,
-                                              uint32_t (&alo)[MID_R], uint32_t (&ahi)[MID_R], uint64_t &corr) {
+                                              uint32_t (&acc)[MID_R], uint32_t &corr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t rr = 0; rr < nruns; rr++) {
     const int a = (int)sm.run[rr], b = (int)sm.run[rr + 1];
@@ -424,34 +410,34 @@ __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nrun
     const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
     const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : b;
     if (ia >= ib) continue;
-    const uint64_t sq = dsum_sub(sm.pq[ib], sm.pq[ia]);  // sum of the slice's hash states
+    const uint32_t sq = sm.pq[ib] - sm.pq[ia];  // sum of the slice's hash states
     // J-blocks of equal size (multiple of 64 leaves, at most 64*MID_R): avoids a nearly empty tail block
     const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
     const uint32_t jsz = (((dout + nJ - 1) / nJ) + 63) & ~63u;
     const int nreg = (int)(jsz >> 6);
     for (uint32_t jb = 0; jb < nJ; jb++) {
       const uint32_t base = jb * jsz;
-      uint32_t tlo[MID_R], thi[MID_R];
+      uint32_t t[MID_R];
       uint32_t ninv = 0;  // registers (among the nreg used) in which this lane holds no leaf
 #pragma unroll
       for (int r = 0; r < MID_R; r++) {
         const uint32_t j = base + r * 64 + lane;
         const bool ok = r < nreg && j < dout;
-        const uint64_t t = ok ? (uint64_t)row[j] * (uint64_t)DIG_K32 : 0ULL;
-        tlo[r] = (uint32_t)t;
-        thi[r] = (uint32_t)(t >> 32);
+        t[r] = ok ? row[j] * DIG_K32 : 0u;  // low half of the leaf term (w * K mod 2^32: a bijection of w)
         if (!ok && r < nreg) ninv++;
       }
-      if (nreg == MID_R)
-        mid_accumulate<MID_R>(sm.q, ia, ib, tlo, thi, alo, ahi);
-      else if (nreg == 3)
-        mid_accumulate<3>(sm.q, ia, ib, tlo, thi, alo, ahi);
-      else if (nreg == 2)
-        mid_accumulate<2>(sm.q, ia, ib, tlo, thi, alo, ahi);
-      else
-        mid_accumulate<1>(sm.q, ia, ib, tlo, thi, alo, ahi);
+      switch (nreg) {
+      case 1: mid_accumulate<1>(sm.q, ia, ib, t, acc); break;
+      case 2: mid_accumulate<2>(sm.q, ia, ib, t, acc); break;
+      case 3: mid_accumulate<3>(sm.q, ia, ib, t, acc); break;
+      case 4: mid_accumulate<4>(sm.q, ia, ib, t, acc); break;
+      case 5: mid_accumulate<5>(sm.q, ia, ib, t, acc); break;
+      case 6: mid_accumulate<6>(sm.q, ia, ib, t, acc); break;
+      case 7: mid_accumulate<7>(sm.q, ia, ib, t, acc); break;
+      default: mid_accumulate<8>(sm.q, ia, ib, t, acc); break;
+      }
       // a lane without a leaf added q ^ 0 = q for every state of the slice
-      for (uint32_t c = 0; c < ninv; c++) corr = dsum_add(corr, sq);
+      corr += ninv * sq;
     }
   }
 }
@@ -462,20 +448,21 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
                                                     uint64_t fbase, uint64_t M, int emit_mid,
                                                     unsigned long long *__restrict__ partial) {
   __shared__ MidShared sm;
-  uint64_t mid_sum = 0, rows_last = 0, corr = 0;
-  uint32_t alo[MID_R], ahi[MID_R];
+  uint64_t mid_sum = 0, rows_last = 0;
+  uint32_t corr = 0;
+  uint32_t acc[MID_R];
 #pragma unroll
-  for (int r = 0; r < MID_R; r++) alo[r] = ahi[r] = 0;
+  for (int r = 0; r < MID_R; r++) acc[r] = 0;
   MidRows rows;
   MidPrep prep;
   mid_load_rows(rrow, rnbr, fbase, M, blockIdx.x, rows);
   mid_prepare(off, rows, emit_mid, prep, mid_sum, rows_last);
   const uint32_t nruns = mid_stage(sm, rows, prep, M, blockIdx.x);
-  mid_fold_tile(sm, nruns, nbr, alo, ahi, corr);
-  uint64_t total = 0;
+  mid_fold_tile(sm, nruns, nbr, acc, corr);
+  uint32_t tsum = 0;
 #pragma unroll
-  for (int r = 0; r < MID_R; r++) total = dsum_add(total, ((uint64_t)ahi[r] << 32) | alo[r]);
-  total = dsum_sub(total, corr);
+  for (int r = 0; r < MID_R; r++) tsum += acc[r];
+  const uint64_t total = (uint64_t)(uint32_t)(tsum - corr);
   block_store_partials(mid_sum, total, rows_last, sm.red, partial);
 }
 
@@ -509,11 +496,9 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const unsigned long lon
   if (threadIdx.x < 3) {
     const uint64_t v0 = s_red[threadIdx.x], v1 = s_red[3 + threadIdx.x], v2 = s_red[6 + threadIdx.x],
                    v3 = s_red[9 + threadIdx.x];
-    if (threadIdx.x < 2) {  // the two halves are independent u32 sums: two 32-bit atomics, no carry
+    if (threadIdx.x < 2) {  // digests are u32 sums kept in the low half of a u64 slot: 32-bit atomic, no carry
       const uint64_t sv = dsum_add(dsum_add(v0, v1), dsum_add(v2, v3));
-      unsigned int *o32 = reinterpret_cast<unsigned int *>(&out[threadIdx.x]);
-      atomicAdd(&o32[0], (unsigned int)sv);
-      atomicAdd(&o32[1], (unsigned int)(sv >> 32));
+      atomicAdd(reinterpret_cast<unsigned int *>(&out[threadIdx.x]), (unsigned int)sv);
     } else {
       atomicAdd(&out[2], v0 + v1 + v2 + v3);
     }

@@ -15,7 +15,7 @@ MASK32 = 0xFFFFFFFF
 
 # order of the per-query result vector that ranks exchange
 FIELDS = ("rows1", "rows2", "digest1", "digest2", "traversed_edges", "frontier_entries")
-LANEWISE = (2, 3)  # digests: low and high 32-bit halves are independent sums (DESIGN.md "Row digest")
+LANEWISE = (2, 3)  # digests: u32 sums mod 2^32 carried in the low half (DESIGN.md "Row digest")
 
 
 def owner_of(ids: np.ndarray, n_parts: int) -> np.ndarray:
@@ -45,7 +45,7 @@ def join_halves(parts) -> list:
     for i in range(len(parts) // 2):
         lo, hi = int(parts[2 * i]), int(parts[2 * i + 1])
         if i in LANEWISE:
-            vec.append((lo & MASK32) | ((hi & MASK32) << 32))  # no carry between the halves
+            vec.append(lo & MASK32)  # 32-bit digest: wraps mod 2^32, never carries into the high half
         else:
             vec.append((lo + (hi << 32)) & MASK64)
     return vec
@@ -63,4 +63,4 @@ def combine(vec, dist=None, device=None) -> list:
 
 
 def dsum(a: int, b: int) -> int:
-    return (((a & MASK32) + (b & MASK32)) & MASK32) | ((((a >> 32) + (b >> 32)) & MASK32) << 32)
+    return ((a & MASK32) + (b & MASK32)) & MASK32

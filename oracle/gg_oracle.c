@@ -31,11 +31,8 @@ uint64_t orc_fmix64(uint64_t x) {
 static inline uint64_t orc_q(uint64_t p, int j) { return orc_fmix64(p + ORC_GOLD * (uint64_t)(j + 1)); }
 static inline uint64_t orc_leaf(uint64_t q, uint32_t d) { return q ^ ((uint64_t)d * (uint64_t)ORC_K32); }
 
-/* digest sums are lane-wise: two independent u32 sums (low/high half), no carry between them */
-uint64_t orc_dsum_add(uint64_t a, uint64_t b) {
-  uint32_t lo = (uint32_t)a + (uint32_t)b, hi = (uint32_t)(a >> 32) + (uint32_t)(b >> 32);
-  return ((uint64_t)hi << 32) | lo;
-}
+/* digest sums are 32-bit: the low halves of the row hashes, summed mod 2^32 */
+uint64_t orc_dsum_add(uint64_t a, uint64_t b) { return (uint64_t)(uint32_t)((uint32_t)a + (uint32_t)b); }
 
 uint64_t orc_row_hash(const uint32_t *d, int h) {
   uint64_t p = d[0]; /* P_0 := d0 */
@@ -537,14 +534,10 @@ static void khop_rec(const orc_csr *g, uint32_t v, uint64_t q, int j, int k_min,
   st->frontier_entries += 1;
   if (h >= k_min) st->rows[h] += (uint64_t)(e - b);
   if (h == k_max) {
-    uint32_t slo = 0, shi = 0;
+    uint32_t slo = 0;
     const uint32_t *nb = g->nbr;
-    for (int64_t i = b; i < e; i++) {
-      uint64_t r = orc_leaf(q, nb[i]);
-      slo += (uint32_t)r;
-      shi += (uint32_t)(r >> 32);
-    }
-    st->digest[h] = orc_dsum_add(st->digest[h], ((uint64_t)shi << 32) | slo);
+    for (int64_t i = b; i < e; i++) slo += (uint32_t)orc_leaf(q, nb[i]);
+    st->digest[h] = orc_dsum_add(st->digest[h], slo);
     return;
   }
   for (int64_t i = b; i < e; i++) {

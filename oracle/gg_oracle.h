@@ -26,7 +26,7 @@ extern "C" {
 
 /* ---- row digest shared with the HIP path (definition: DESIGN.md §"Row digest") ------------ */
 uint64_t orc_fmix64(uint64_t x);
-/* digest accumulation: lane-wise 2 x u32 add (low and high halves summed independently) */
+/* digest accumulation: (a + low32(b)) mod 2^32 */
 uint64_t orc_dsum_add(uint64_t a, uint64_t b);
 /* digest value of one walk given as dense vertex indices d[0..h] (h >= 1) */
 uint64_t orc_row_hash(const uint32_t *d, int h);

@@ -87,12 +87,10 @@ class Oracle:
         return int(self.lib.orc_row_hash(a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size - 1))
 
     def digest_rows(self, dense_rows: np.ndarray) -> int:
-        lo = hi = 0  # lane-wise digest: low and high halves of the row hashes are summed independently
+        s = 0  # 32-bit digest: low halves of the row hashes, summed mod 2^32 (DESIGN.md "Row digest")
         for r in dense_rows:
-            h = self.row_hash(r)
-            lo = (lo + (h & 0xFFFFFFFF)) & 0xFFFFFFFF
-            hi = (hi + (h >> 32)) & 0xFFFFFFFF
-        return (hi << 32) | lo
+            s = (s + (self.row_hash(r) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        return s
 
     # ---- join restatement
     def hash_join(self, build_keys, probe_keys) -> np.ndarray:
