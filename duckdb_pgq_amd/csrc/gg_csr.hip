@@ -687,8 +687,9 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
       GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
                 ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, su, dv, (uint32_t)bits0, nblocks64, counts0);
       // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
-      RadixIO io{su, dv, nullptr, csr->row, csr->nbr, csr->epos};
-      GG_TRY(radix_sort_stable(ctx, io, E, true, true, key_bits, counts0, bits0, kept_dev, false));
+      const bool rowid = ctx->keep_edge_rowid;
+      RadixIO io{su, dv, nullptr, csr->row, csr->nbr, rowid ? csr->epos : nullptr};
+      GG_TRY(radix_sort_stable(ctx, io, E, rowid, rowid, key_bits, counts0, bits0, kept_dev, false));
     }
     ctx->dev_free(tvf);
     ctx->dev_free(tvr);
@@ -707,7 +708,8 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
             (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
   GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
             (const uint64_t *)kept_rev_dev, st);
-  if (ctx->rowid_explicit && E) {
+  csr->has_rowid = !shard && ctx->keep_edge_rowid;
+  if (ctx->rowid_explicit && E && csr->has_rowid) {
     GG_TRY(ctx->dev_alloc((void **)&csr->eid, E * sizeof(int64_t)));
     GG_LAUNCH(ctx, "gather_rowid", k_gather_rowid, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, csr->epos,
               ctx->c_rowid.dev, (const unsigned long long *)kept_dev, csr->eid);
@@ -816,7 +818,7 @@ extern "C" int gg_csr_export(const gg_csr *csr, int64_t *off, int64_t *nbr, int6
     for (uint64_t i = 0; i < csr->E; i++) nbr[i] = (int64_t)h[i];
   }
   if (eid && csr->E) {
-    if (csr->n_parts > 1) {  // shards carry no edge rowids
+    if (!csr->has_rowid) {  // shards and rowid-free builds carry no edge rowids
       for (uint64_t i = 0; i < csr->E; i++) eid[i] = -1;
     } else if (csr->eid) {
       GG_HIP(hipMemcpy(eid, csr->eid, csr->E * sizeof(int64_t), hipMemcpyDeviceToHost));

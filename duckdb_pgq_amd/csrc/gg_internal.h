@@ -87,6 +87,7 @@ struct gg_ctx {
 
   // ---- profiling ----
   bool force_frontier = false;  // gg_debug_force_frontier
+  bool keep_edge_rowid = true;  // gg_ctx_set_edge_rowid
   bool profiling = false;
   std::vector<std::string> prof_names;
   std::vector<uint64_t> prof_launches;
@@ -112,6 +113,7 @@ struct gg_csr {
   uint64_t E_rev = 0;          // entries of the reverse CSR (== E unless this is a shard)
   uint64_t owned_vertices = 0; // vertices owned by this shard (== V unless this is a shard)
   int part = 0, n_parts = 1;   // shard identity (gg_csr_build_shard)
+  bool has_rowid = true;       // epos/eid valid (gg_ctx_set_edge_rowid, never for shards)
   uint32_t *off = nullptr;     // V+1 row offsets
   uint32_t *nbr = nullptr;     // E   dense neighbour (destination) per entry
   uint32_t *row = nullptr;     // E   dense source per entry (COO view, sorted by source)

@@ -135,6 +135,12 @@ int gg_ctx::prof_flush() {
   return GG_OK;
 }
 
+extern "C" int gg_ctx_set_edge_rowid(gg_ctx *ctx, int keep) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  ctx->keep_edge_rowid = keep != 0;
+  return GG_OK;
+}
+
 extern "C" int gg_debug_force_frontier(gg_ctx *ctx, int on) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   ctx->force_frontier = on != 0;

@@ -16,7 +16,7 @@ GG_CHUNK_ROWS = 1024
 SYMBOLS = [
     "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
-    "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
+    "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
     "gg_debug_force_frontier",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
@@ -79,6 +79,7 @@ def load_library(path: str | None = None):
     lib.gg_staging_clear.argtypes = [P]
     lib.gg_csr_build.argtypes = [P, C.POINTER(P)]
     lib.gg_csr_build_shard.argtypes = [P, C.c_int, C.c_int, C.POINTER(P)]
+    lib.gg_ctx_set_edge_rowid.argtypes = [P, C.c_int]
     lib.gg_csr_destroy.argtypes = [P]
     lib.gg_csr_destroy.restype = None
     lib.gg_csr_info.argtypes = [P, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -192,6 +193,9 @@ class GG:
         h = C.c_void_p()
         self._chk(self.lib.gg_csr_build(self.ctx, C.byref(h)))
         return Csr(self, h)
+
+    def set_edge_rowid(self, keep: bool):
+        self._chk(self.lib.gg_ctx_set_edge_rowid(self.ctx, int(keep)))
 
     def build_csr_shard(self, part: int, n_parts: int) -> Csr:
         h = C.c_void_p()

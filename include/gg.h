@@ -87,6 +87,12 @@ int gg_staging_counts(gg_ctx *ctx, uint64_t *n_vertices, uint64_t *n_edges);
 int gg_staging_clear(gg_ctx *ctx);
 
 /* ---- CSR build (Finalize side) ------------------------------------------------------------ */
+/* Whether later builds carry the edge rowid per CSR entry (default 1).  A MATCH that binds no edge
+ * variable — e.g. count(*) or Person-KNOWS*1..2-Person returning persons — does not need it, exactly as
+ * the reference's hash-join build side only carries the columns the query references; the build then
+ * sorts 8 instead of 12 bytes per edge ("+8E if edge rowid kept").  With 0, gg_csr_export
+ * reports -1 as rowid. */
+int gg_ctx_set_edge_rowid(gg_ctx *ctx, int keep);
 /* Densify ids (device hash table), histogram + prefix-scan + stable LSD radix scatter by source.
  * Within a CSR row, neighbours are in ascending edge-rowid (append) order: the build is
  * deterministic.  Staged columns stay resident, so the build can be repeated.

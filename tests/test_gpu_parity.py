@@ -511,3 +511,23 @@ def test_concurrent_sink_appends(gg, orc):
     assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
     csr.close()
     g.close()
+
+
+def test_build_without_edge_rowid(gg, orc):
+    """gg_ctx_set_edge_rowid(0): same CSR (offsets, neighbours in rowid order), rowids reported as -1."""
+    vid, src, dst = datagen.ldbc_knows(3000, 90_000, 71)
+    gg.set_edge_rowid(False)
+    try:
+        csr, g = build_both(gg, orc, vid, src, dst)
+        off, nbr, eid, v2 = csr.export()
+        o_off, o_nbr, _, o_vid = g.arrays()
+        assert np.array_equal(off, o_off) and np.array_equal(nbr, o_nbr) and np.array_equal(v2, o_vid)
+        assert np.all(eid == -1)
+        assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
+        dist, st = gg.bfs64(csr, vid[:64], 4)
+        o_dist, o_st = g.bfs64(g.lookup(vid[:64]), 4)
+        assert np.array_equal(dist, o_dist) and st == o_st
+        csr.close()
+        g.close()
+    finally:
+        gg.set_edge_rowid(True)
