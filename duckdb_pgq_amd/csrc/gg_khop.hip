@@ -568,6 +568,81 @@ __global__ __launch_bounds__(XT) void k_mat_fill(const uint32_t *__restrict__ of
   if (ndeg) ndeg[o] = (uint64_t)(off[x + 1] - off[x]);
 }
 
+// Last level of a materialised expansion, written directly as int64 ids: a tile of XT parent rows is
+// staged in LDS (their ids, output offset, out-row extent), then each wavefront takes whole parents and
+// streams their children: the child column is a coalesced CSR row read + id gather, the parent columns
+// are broadcasts; every store instruction writes 64 consecutive rows (512 contiguous bytes per column).
+struct IdCols {
+  int64_t *c[GG_MAX_HOPS + 1];
+};
+
+__global__ __launch_bounds__(XT) void k_mat_last(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                 const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
+                                                 uint64_t n_parents, int j /* columns of a parent = j + 1 */,
+                                                 const uint32_t *const *__restrict__ cols_in, IdCols out) {
+  __shared__ int64_t s_id[GG_MAX_HOPS][XT];
+  __shared__ uint64_t s_base[XT];
+  __shared__ uint32_t s_start[XT], s_len[XT];
+  const uint64_t i = (uint64_t)blockIdx.x * XT + threadIdx.x;
+  uint32_t len = 0;
+  if (i < n_parents) {
+    for (int c = 0; c <= j; c++) s_id[c][threadIdx.x] = vid[cols_in[c][i]];
+    const uint32_t v = cols_in[j][i];
+    s_start[threadIdx.x] = off[v];
+    len = off[v + 1] - off[v];
+    s_base[threadIdx.x] = foff[i] - foff[0];
+  }
+  s_len[threadIdx.x] = len;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < XT; r += XT / 64) {
+    const uint32_t n = s_len[r];
+    if (n == 0) continue;
+    const uint32_t *__restrict__ row = nbr + s_start[r];
+    const uint64_t base = s_base[r];
+    // Stores are 16 bytes per lane (two consecutive rows of a column): half the store instructions of
+    // 8-byte stores.  Rows before the first 16-byte-aligned output slot and a possible odd last row are
+    // written singly by lane 0.  All loads and id gathers of a trip come first, then its (non-temporal)
+    // stores: the output is written once, never re-read here, and stores must not serialise the loads.
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const uint32_t head = (uint32_t)(base & 1);
+    if (lane == 0) {
+      if (head) {
+        out.c[j + 1][base] = vid[row[0]];
+        for (int c = 0; c <= j; c++) out.c[c][base] = s_id[c][r];
+      }
+      if (((n - head) & 1) && n > head) {
+        out.c[j + 1][base + n - 1] = vid[row[n - 1]];
+        for (int c = 0; c <= j; c++) out.c[c][base + n - 1] = s_id[c][r];
+      }
+    }
+    const uint32_t npairs = (n - head) >> 1;
+    for (uint32_t p0 = 0; p0 < npairs; p0 += 128) {
+      ll2 idv[2];
+      bool okv[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const uint32_t pi = p0 + q * 64 + lane;
+        okv[q] = pi < npairs;
+        const uint32_t k = head + 2 * pi;
+        idv[q].x = okv[q] ? vid[row[k]] : 0;
+        idv[q].y = okv[q] ? vid[row[k + 1]] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        if (!okv[q]) continue;
+        const uint64_t o = base + head + 2 * (uint64_t)(p0 + q * 64 + lane);  // even: 16-byte aligned
+        __builtin_nontemporal_store(idv[q], reinterpret_cast<ll2 *>(&out.c[j + 1][o]));
+        for (int c = 0; c <= j; c++) {
+          ll2 two;
+          two.x = two.y = s_id[c][r];
+          __builtin_nontemporal_store(two, reinterpret_cast<ll2 *>(&out.c[c][o]));
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gather_ids(const uint32_t *__restrict__ dense, const int64_t *__restrict__ vid,
                                                     uint64_t n, int64_t *__restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -876,6 +951,25 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
   GG_TRY(ctx->dev_alloc((void **)&d_out, (GG_MAX_HOPS + 1) * sizeof(void *)));
 
   for (int h = 1; h <= k_max; h++) {
+    if (h == k_max) {
+      // last level: straight to int64 id columns, no dense intermediate
+      res->rows[h] = M;
+      IdCols oc;
+      for (int c = 0; c <= GG_MAX_HOPS; c++) oc.c[c] = nullptr;
+      for (int c = 0; c <= h; c++) {
+        GG_TRY(ctx->dev_alloc((void **)&res->cols[h][c], (M ? M : 1) * sizeof(int64_t)));
+        ctx->keep(res->cols[h][c]);
+        oc.c[c] = res->cols[h][c];
+      }
+      if (M) {
+        GG_HIP(hipMemcpyAsync(d_in, cols_prev.data(), cols_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
+                              ctx->stream));
+        GG_HIP(hipStreamSynchronize(ctx->stream));
+        GG_LAUNCH(ctx, "mat_last", k_mat_last, dim3((unsigned)((n_prev + XT - 1) / XT)), dim3(XT), 0, csr->off, csr->nbr,
+                  csr->vid, foff, n_prev, h - 1, d_in, oc);
+      }
+      break;
+    }
     cols_cur.assign((size_t)h + 1, nullptr);
     for (int c = 0; c <= h; c++) GG_TRY(ctx->dev_alloc((void **)&cols_cur[c], (M ? M : 1) * sizeof(uint32_t)));
     uint64_t *noff = nullptr;
@@ -893,7 +987,7 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
       GG_LAUNCH(ctx, "mat_fill", (k_mat_fill<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
                 foff, n_prev, M, tile_entry, h - 1, d_in, d_out, noff);
       ctx->dev_free(tile_entry);
-      if (h < k_max) GG_TRY(offsets_from_deg(ctx, noff, M, &Mn));
+      GG_TRY(offsets_from_deg(ctx, noff, M, &Mn));
     }
     if (h >= k_min) {  // convert this level to int64 ids
       res->rows[h] = M;
