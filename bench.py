@@ -213,30 +213,51 @@ def main():
     value = te_total * args.steps / elapsed
 
     # ---- roofline of the dominant kernel on this rank ---------------------------------------------------
-    # dominant kernel = largest total time in the timed region; algorithmic bytes per launch
+    # dominant kernel = largest total time in the timed region; algorithmic bytes per launch:
+    # SURVEY.md §8d's figures — expansion 8*TE + 16*frontier entries; densification 32E + 8V; CSR scatter
+    # 16E read + 8E write = 24E per CSR, which our LSD sort spreads over 3 passes (x2 CSRs = 6 launches),
+    # so one radix_scatter launch is charged 8E: the multi-pass overhead shows up as a low fraction.
+    te_l, fr_l = st_local["traversed_edges"], st_local["frontier_entries"]
     alg = {
-        "expand_mid2": 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"],
-        "expand_fused2": 8 * st_local["traversed_edges"] + 16 * st_local["frontier_entries"],
-        "densify_hist": 32 * R + 8 * V,          # id densification, SURVEY.md §8d
-        "radix_scatter": 32 * R,                  # per launch: read (key, payload) 16E + write 16E at int64 width
+        "expand_mid2": 8 * te_l + 16 * fr_l,
+        "expand_fused2": 8 * te_l + 16 * fr_l,
+        "densify_hist": 32 * R + 8 * V,
+        "densify_shard": 32 * R + 8 * V,
+        "radix_scatter": 8 * R,
     }
     dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
     launches, total_ms = prof.get(dom, (0, 0.0)) if dom else (0, 0.0)
+    traffic_tab = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic_tab = json.load(open(tpath))
+        except Exception:
+            traffic_tab = {}
     roof = None
     if launches:
         avg_s = total_ms / launches * 1e-3
-        alg_bytes = alg[dom]
-        achieved = alg_bytes / avg_s
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}/{dom}/n{world}")
-            except Exception:
-                traffic = None
+        achieved = alg[dom] / avg_s
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
-                "algorithmic_bytes_per_launch": alg_bytes}
+                "frac": achieved / HBM_PEAK, "traffic": traffic_tab.get(f"{args.workload}/{dom}/n{world}"),
+                "avg_launch_ms": avg_s * 1e3, "launches_per_step": launches / args.steps,
+                "algorithmic_bytes_per_launch": alg[dom]}
+    # the same figure per phase of the step (all kernels of the phase together)
+    expand_names = {"expand_mid2", "expand_fused2", "reduce_partials", "tile_partition"}
+    t_expand = sum(v[1] for k, v in prof.items() if k in expand_names) / args.steps * 1e-3
+    t_build = sum(v[1] for k, v in prof.items() if k not in expand_names) / args.steps * 1e-3
+    alg_build = (32 * R + 8 * V) + (32 * R + 16 * V)  # densification + one CSR without rowid
+    phases = {}
+    if t_build > 0:
+        phases["csr_build"] = {"kernel_ms": t_build * 1e3, "algorithmic_bytes": alg_build,
+                               "achieved": alg_build / t_build / 1e9, "frac": alg_build / t_build / HBM_PEAK,
+                               "note": "our build also makes the reverse CSR the product kernel needs; it is not in the algorithmic count"}
+    if t_expand > 0:
+        a = 8 * te_l + 16 * fr_l
+        phases["expand"] = {"kernel_ms": t_expand * 1e3, "algorithmic_bytes": a, "achieved": a / t_expand / 1e9,
+                            "frac": a / t_expand / HBM_PEAK,
+                            "traffic": traffic_tab.get(f"{args.workload}/expand_mid2/n{world}"),
+                            "note": "above 1: the product kernel reads each CSR row once and is VALU-bound (DESIGN.md §4.3)"}
     kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
                    "us_per_step": v[1] * 1e3 / args.steps} for k, v in prof.items()}
 
@@ -274,6 +295,7 @@ def main():
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
                        "traversed_edges": int(te_total), "parallelism": f"vertex-ownership shards x{world} (base tables replicated, CSR + expansion sharded, no data-path collective)"},
             "roofline": roof,
+            "roofline_phases": phases,
             "kernels": kernels,
             "staging_ms_pcie": t_stage * 1e3,
         }

@@ -33,10 +33,13 @@ open(os.path.join(out, f"r01_{tag}_sf100_pmc_summary.txt"), "w").write("\n".join
 traffic = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, "
            f"profiles/r01_{tag}_sf100_pmc_summary.txt): (2*FETCH_SIZE + WRITE_SIZE) * 1024; the factor 2 on FETCH_SIZE is the "
            "gfx950 correction of MI355X_MICROARCH.md (upper bound for our 4-byte-per-lane coalesced loads)"}
-short = {"k_expand_mid2": "expand_mid2", "k_densify_hist": "densify_hist"}
+short = {"k_expand_mid2": "expand_mid2", "k_densify_hist": "densify_hist", "k_radix_scatter": "radix_scatter"}
+acc = collections.defaultdict(list)
 for k, v in res.items():
     n = k.split("::")[-1].split("<")[0]
     if n in short and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        traffic[f"sf100/{short[n]}/n1"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+        acc[short[n]].append((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+for n, vals in acc.items():  # template instantiations of one kernel name: plain mean per launch
+    traffic[f"sf100/{n}/n1"] = int(sum(vals) / len(vals))
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
