@@ -793,6 +793,173 @@ int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
 
 }  // namespace gg
 
+// ---- vertex table from the edge endpoints (gg_vertices_from_edges) ---------------------------------
+// distinct ids via an open-addressing key set (8-byte slots), compacted and then sorted ascending with
+// two stable 32-bit radix sorts (low half, then sign-flipped high half), so the dense numbering does not
+// depend on insertion races.
+namespace gg {
+
+struct SetStatus {
+  unsigned long long count;     // distinct keys inserted (the sentinel id is counted through has_min)
+  unsigned long long has_min;   // the id equal to the empty-slot sentinel occurs
+  unsigned long long overflow;  // the table got fuller than `limit` or a probe sequence exceeded its bound
+};
+
+__global__ __launch_bounds__(256) void k_set_init(int64_t *__restrict__ set, uint64_t cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) set[i] = HT_EMPTY;
+}
+
+__global__ __launch_bounds__(256) void k_set_insert(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                    uint64_t E, int64_t *__restrict__ set, uint64_t cap,
+                                                    uint64_t limit, uint32_t max_probes,
+                                                    SetStatus *__restrict__ st) {
+  __shared__ uint32_t s_new;
+  if (threadIdx.x == 0) s_new = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool inserted = false;
+  if (i < 2 * E && *(volatile unsigned long long *)&st->overflow == 0ULL) {
+    const int64_t key = i < E ? src[i] : dst[i - E];
+    if (key == HT_EMPTY) {
+      st->has_min = 1ULL;  // benign race: every writer stores the same value
+    } else {
+      uint64_t slot = ht_slot(key, cap);
+      uint32_t probes = 0;
+      while (true) {
+        int64_t k = set[slot];
+        if (k == HT_EMPTY) {
+          k = (int64_t)atomicCAS((unsigned long long *)&set[slot], (unsigned long long)HT_EMPTY,
+                                 (unsigned long long)key);
+          if (k == HT_EMPTY) {
+            inserted = true;
+            break;
+          }
+        }
+        if (k == key) break;
+        if (++probes > max_probes) {  // only reachable while the table may still fill up: ask for a bigger one
+          st->overflow = 1ULL;
+          break;
+        }
+        slot = ht_next(slot, cap);
+      }
+    }
+  }
+  const uint64_t m = __ballot(inserted);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_new, (uint32_t)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0 && s_new) {
+    const unsigned long long before = atomicAdd(&st->count, (unsigned long long)s_new);
+    if (before + s_new > limit) st->overflow = 1ULL;
+  }
+}
+
+// non-empty slots -> (low half, sign-flipped high half); slot order is arbitrary, the sort fixes it
+__global__ __launch_bounds__(256) void k_set_compact(const int64_t *__restrict__ set, uint64_t cap,
+                                                     unsigned long long *__restrict__ cursor,
+                                                     uint32_t *__restrict__ lo, uint32_t *__restrict__ hi) {
+  __shared__ uint32_t s_cnt[4];
+  __shared__ unsigned long long s_base;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = i < cap ? set[i] : HT_EMPTY;
+  const bool live = k != HT_EMPTY;
+  const uint64_t m = __ballot(live);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ULL;
+  }
+  __syncthreads();
+  if (live) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += s_cnt[w];
+    const uint64_t pos = s_base + before + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+    lo[pos] = (uint32_t)(uint64_t)k;
+    hi[pos] = (uint32_t)((uint64_t)k >> 32) ^ 0x80000000u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_set_emit(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
+                                                  uint64_t n, uint32_t has_min, int64_t *__restrict__ vid) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && has_min) vid[0] = HT_EMPTY;  // INT64_MIN sorts first
+  if (i < n) vid[i + has_min] = (int64_t)(((uint64_t)(hi[i] ^ 0x80000000u) << 32) | (uint64_t)lo[i]);
+}
+
+}  // namespace gg
+
+extern "C" int gg_vertices_from_edges(gg_ctx *ctx, uint64_t *n_vertices) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  if (n_vertices) *n_vertices = 0;
+  GG_TRY(gg_staging_sync(ctx));
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ApiScope scope(ctx);
+  GG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t E = ctx->n_edges;
+  ctx->n_vertices = 0;
+  ctx->fill_v = 0;
+  if (E == 0) return GG_OK;
+
+  SetStatus *st = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&st, sizeof(SetStatus)));
+  // the table starts small (graphs have far fewer vertices than edge rows) and is rebuilt larger when it
+  // passes half full; at cap > 2E it cannot fill, so the probe bound is lifted and the loop ends
+  uint64_t cap = 1u << 16;
+  while (cap < E / 8) cap <<= 1;
+  int64_t *set = nullptr;
+  SetStatus host{};
+  while (true) {
+    const bool cannot_fill = cap > 2 * E + 1;
+    GG_TRY(ctx->dev_alloc((void **)&set, cap * sizeof(int64_t)));
+    GG_HIP(hipMemsetAsync(st, 0, sizeof(SetStatus), s));
+    GG_LAUNCH(ctx, "set_init", k_set_init, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, set, cap);
+    GG_LAUNCH(ctx, "set_insert", k_set_insert, dim3((unsigned)((2 * E + 255) / 256)), dim3(256), 0, ctx->c_src.dev,
+              ctx->c_dst.dev, E, set, cap, cannot_fill ? ~0ULL : cap / 2, cannot_fill ? 0xFFFFFFFFu : 4096u, st);
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(SetStatus), hipMemcpyDeviceToHost, s));
+    GG_HIP(hipStreamSynchronize(s));
+    memcpy(&host, ctx->pin_scratch, sizeof(SetStatus));
+    if (!host.overflow) break;
+    ctx->dev_free(set);
+    cap <<= 3;
+  }
+  const uint64_t n = host.count, has_min = host.has_min ? 1 : 0, V = n + has_min;
+  if (V >= (uint64_t)INVALID_U32) {
+    set_error("more than 2^32-2 distinct endpoint ids are not supported");
+    return GG_ERR_TOO_LARGE;
+  }
+  GG_TRY(grow_column(ctx, ctx->c_vid, 0, V));
+  if (n) {
+    uint32_t *lo = nullptr, *hi = nullptr, *lo1 = nullptr, *hi1 = nullptr, *lo2 = nullptr, *hi2 = nullptr;
+    unsigned long long *cursor = nullptr, *tot = nullptr;
+    for (uint32_t **p : {&lo, &hi, &lo1, &hi1, &lo2, &hi2}) GG_TRY(ctx->dev_alloc((void **)p, n * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
+    GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(unsigned long long)));
+    GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s));
+    GG_LAUNCH(ctx, "set_compact", k_set_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, set, cap, cursor,
+              lo, hi);
+    // pass 0 of each sort reads its element count from the device: `cursor` holds exactly n by then
+    GG_HIP(hipMemcpyAsync(tot, cursor, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    RadixIO by_lo{lo, hi, nullptr, lo1, hi1, nullptr};
+    GG_TRY(radix_sort_stable(ctx, by_lo, n, false, false, 32, nullptr, 0, tot, true));
+    GG_HIP(hipMemcpyAsync(tot, cursor, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    RadixIO by_hi{hi1, lo1, nullptr, hi2, lo2, nullptr};
+    GG_TRY(radix_sort_stable(ctx, by_hi, n, false, false, 32, nullptr, 0, tot, true));
+    GG_LAUNCH(ctx, "set_emit", k_set_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lo2, hi2, n,
+              (uint32_t)has_min, ctx->c_vid.dev);
+  } else {
+    const int64_t only = HT_EMPTY;  // has_min with nothing else
+    memcpy(ctx->pin_scratch, &only, sizeof(only));
+    GG_HIP(hipMemcpyAsync(ctx->c_vid.dev, ctx->pin_scratch, sizeof(only), hipMemcpyHostToDevice, s));
+  }
+  GG_HIP(hipStreamSynchronize(s));
+  ctx->n_vertices = V;
+  if (n_vertices) *n_vertices = V;
+  return GG_OK;
+}
+
 extern "C" int gg_csr_info(const gg_csr *csr, uint64_t *n_vertices, uint64_t *n_edges_kept,
                            uint64_t *n_edges_dropped) {
   if (!csr) return GG_ERR_INVALID_ARG;

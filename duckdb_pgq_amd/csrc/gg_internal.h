@@ -170,6 +170,8 @@ int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t 
 
 // id -> dense lookup of n host ids; writes dense (uint32, INVALID_U32 if absent) to out_dev
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev);
+// make a staged column hold need_rows rows, keeping the first live_rows (gg_runtime.hip; caller holds mu)
+int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows);
 // build csr->roff / csr->rnbr if absent (gg_csr.hip)
 int ensure_reverse(gg_ctx *ctx, gg_csr *csr);
 

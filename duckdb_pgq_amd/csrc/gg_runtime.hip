@@ -234,7 +234,8 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
 // ------------------------------------------------------------------------------------------
 // staging: DataChunk columns -> pinned block -> HBM   (Sink side; thread-safe)
 // ------------------------------------------------------------------------------------------
-static int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows) {
+namespace gg {
+int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows) {
   if (need_rows <= c.cap) return GG_OK;
   size_t ncap = c.cap ? c.cap : (size_t)1 << 16;
   while (ncap < need_rows) ncap *= 2;
@@ -250,6 +251,7 @@ static int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_row
   c.cap = ncap;
   return GG_OK;
 }
+}  // namespace gg
 
 // push the current (partially) filled pinned vertex block to the device; caller holds mu
 static int flush_vertices(gg_ctx *ctx) {

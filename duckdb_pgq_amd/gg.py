@@ -20,7 +20,7 @@ SYMBOLS = [
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
     "gg_debug_force_frontier",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
-    "gg_result_filter_common_neighbour", "gg_staging_clear_edges",
+    "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64",
     "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
@@ -95,6 +95,7 @@ def load_library(path: str | None = None):
     lib.gg_expand_khop_result.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_result_filter_common_neighbour.argtypes = [P, P, C.c_int, P, C.POINTER(P)]
     lib.gg_staging_clear_edges.argtypes = [P]
+    lib.gg_vertices_from_edges.argtypes = [P, C.POINTER(u64)]
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
@@ -249,6 +250,12 @@ class GG:
 
     def staging_clear_edges(self):
         self._chk(self.lib.gg_staging_clear_edges(self.ctx))
+
+    def vertices_from_edges(self) -> int:
+        """Vertex table := distinct endpoint ids of the staged edges, ascending; returns their number."""
+        n = C.c_uint64()
+        self._chk(self.lib.gg_vertices_from_edges(self.ctx, C.byref(n)))
+        return int(n.value)
 
     def connected_paths_same_neighbour(self, path_csr: Csr, filter_csr: Csr, hops: int, sources=None):
         """`hops`-hop walks over path_csr whose vertices all share a neighbour in filter_csr; rows (w, v0..vh)."""

@@ -18,8 +18,10 @@
 //
 // Each function runs the operator classes of gg_operators.hpp exactly the way the reference's
 // PipelineExecutor would (pipeline_executor.cpp:47-131): source chunks -> Sink (per <=1024-row
-// DataChunk) -> Combine -> Finalize, then GetData until an empty chunk.  The true plan-level
-// substitution (a PhysicalPlanGenerator rule + one BuildPipelines case) is described in INTEGRATION.md.
+// DataChunk) -> Combine -> Finalize, then GetData until an empty chunk.  Binding only fixes the schema;
+// the base-table scans and the device work happen when the scan is initialised, i.e. at execution time.
+// The same machinery serves the planner rules of gg_plan_rule.cpp, which put these scans in place of
+// hash-join chains over an edge table (plan-level substitution).
 #include "duckdb.hpp"
 #include "duckdb/catalog/catalog.hpp"
 #include "duckdb/common/exception.hpp"
@@ -30,7 +32,7 @@
 #include "duckdb/parallel/pipeline.hpp"
 #include "duckdb/parallel/thread_context.hpp"
 #include "duckdb/parser/parsed_data/create_table_function_info.hpp"
-#include "gg_operators.hpp"
+#include "gg_extension.hpp"
 
 namespace duckdb {
 
@@ -42,7 +44,7 @@ public:
 	}
 };
 
-static string Quote(const string &ident) {
+string GGQuote(const string &ident) {
 	string out = "\"";
 	for (auto c : ident) {
 		if (c == '"') {
@@ -78,39 +80,59 @@ static void RunSinkPipeline(ClientContext &context, const string &sql, PhysicalO
 	sink.Finalize(pipeline, event, context, *sink.sink_state);
 }
 
-static shared_ptr<GGGraph> BuildGraph(ClientContext &context, vector<Value> &inputs) {
+shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec) {
 	auto graph = make_shared<GGGraph>(0);
-	const string vt = inputs[0].ToString(), vk = inputs[1].ToString(), et = inputs[2].ToString(),
-	             es = inputs[3].ToString(), ed = inputs[4].ToString();
-	PhysicalGGVertexSink vsink(graph, {LogicalType::BIGINT}, 0);
-	RunSinkPipeline(context, "SELECT " + Quote(vk) + " FROM " + Quote(vt), vsink);
-	// rowid comes out of the scan as a sequence vector (row_group.cpp:335): the sink Orrifies it
-	PhysicalGGEdgeSink esink(graph, {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::BIGINT}, 0);
-	RunSinkPipeline(context, "SELECT " + Quote(es) + ", " + Quote(ed) + ", rowid FROM " + Quote(et), esink);
+	const bool derive = spec.vertex_sql.empty();
+	if (!derive) {
+		PhysicalGGVertexSink vsink(graph, {LogicalType::BIGINT}, 0);
+		RunSinkPipeline(context, spec.vertex_sql, vsink);
+	}
+	// the sink takes (src, dst[, rowid]); rowid comes out of the scan as a sequence vector
+	// (row_group.cpp:335) and is Orrified there
+	PhysicalGGEdgeSink esink(graph, {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::BIGINT}, 0, false, derive);
+	RunSinkPipeline(context, spec.edge_sql, esink);
 	return graph;
 }
 
-//! Bind data: the source operator plus its state; the function call is GetData.
-struct GGFunctionData : public TableFunctionData {
-	shared_ptr<GGGraph> graph;
-	unique_ptr<PhysicalOperator> source;
-	unique_ptr<GlobalSourceState> gstate;
-};
+static GGGraphSpec GraphSpecFromArguments(vector<Value> &inputs) {
+	const string vt = inputs[0].ToString(), vk = inputs[1].ToString(), et = inputs[2].ToString(),
+	             es = inputs[3].ToString(), ed = inputs[4].ToString();
+	GGGraphSpec spec;
+	spec.vertex_sql = "SELECT " + GGQuote(vk) + " FROM " + GGQuote(vt);
+	spec.edge_sql = "SELECT " + GGQuote(es) + ", " + GGQuote(ed) + ", rowid FROM " + GGQuote(et);
+	return spec;
+}
 
-struct GGOperatorData : public FunctionOperatorData {};
+struct GGOperatorData : public FunctionOperatorData {
+	GGOpened opened;
+};
 
 static unique_ptr<FunctionOperatorData> GGInit(ClientContext &context, const FunctionData *bind_data,
                                                const vector<column_t> &column_ids, TableFilterCollection *filters) {
-	return make_unique<GGOperatorData>();
+	auto &data = (GGFunctionData &)*bind_data;
+	auto state = make_unique<GGOperatorData>();
+	data.open(context, state->opened);
+	state->opened.gstate = state->opened.source->GetGlobalSourceState(context);
+	return move(state);
 }
 
 static void GGFunction(ClientContext &context, const FunctionData *bind_data_p, FunctionOperatorData *operator_state,
                        DataChunk *input, DataChunk &output) {
-	auto &data = (GGFunctionData &)*bind_data_p;
+	auto &state = (GGOperatorData &)*operator_state;
 	ThreadContext thread(context);
 	ExecutionContext ec(context, thread);
 	LocalSourceState lstate;
-	data.source->GetData(ec, output, *data.gstate, lstate);
+	state.opened.source->GetData(ec, output, *state.opened.gstate, lstate);
+}
+
+static string GGToString(const FunctionData *bind_data) {
+	return ((const GGFunctionData &)*bind_data).description;
+}
+
+TableFunction GGScanFunction(const string &name, vector<LogicalType> arguments, table_function_bind_t bind) {
+	TableFunction function(name, move(arguments), GGFunction, bind, GGInit);
+	function.to_string = GGToString;
+	return function;
 }
 
 static vector<int64_t> QueryInt64Column(ClientContext &context, const string &sql, const char *what) {
@@ -140,24 +162,24 @@ static unique_ptr<FunctionData> FilteredPathsBind(ClientContext &context, vector
 	if (hops < 1 || hops + 1 > GG_MAX_HOPS) {
 		throw BinderException("gg_same_neighbour_paths: need 1 <= hops <= " + to_string(GG_MAX_HOPS - 1));
 	}
+	const string vertices_sql = inputs[0].ToString(), sources_sql = inputs[1].ToString();
+	const string path_sql = "SELECT " + GGQuote(inputs[3].ToString()) + ", " + GGQuote(inputs[4].ToString()) +
+	                        " FROM " + GGQuote(inputs[2].ToString());
+	const string filter_sql = "SELECT " + GGQuote(inputs[6].ToString()) + ", " + GGQuote(inputs[7].ToString()) +
+	                          " FROM " + GGQuote(inputs[5].ToString());
 	auto data = make_unique<GGFunctionData>();
-	data->graph = make_shared<GGGraph>(0);
-	PhysicalGGVertexSink vsink(data->graph, {LogicalType::BIGINT}, 0);
-	RunSinkPipeline(context, inputs[0].ToString(), vsink);
-	PhysicalGGEdgeSink psink(data->graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0);
-	RunSinkPipeline(context,
-	                "SELECT " + Quote(inputs[3].ToString()) + ", " + Quote(inputs[4].ToString()) + " FROM " +
-	                    Quote(inputs[2].ToString()),
-	                psink);
-	PhysicalGGEdgeSink fsink(data->graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, true);
-	RunSinkPipeline(context,
-	                "SELECT " + Quote(inputs[6].ToString()) + ", " + Quote(inputs[7].ToString()) + " FROM " +
-	                    Quote(inputs[5].ToString()),
-	                fsink);
-	auto sources = QueryInt64Column(context, inputs[1].ToString(), "gg_same_neighbour_paths: sources");
-	data->source = make_unique<PhysicalGGFilteredPaths>(data->graph, (int)hops, move(sources), 0);
-	data->gstate = data->source->GetGlobalSourceState(context);
-	return_types = data->source->GetTypes();
+	data->open = [=](ClientContext &ctx, GGOpened &opened) {
+		opened.graph = make_shared<GGGraph>(0);
+		PhysicalGGVertexSink vsink(opened.graph, {LogicalType::BIGINT}, 0);
+		RunSinkPipeline(ctx, vertices_sql, vsink);
+		PhysicalGGEdgeSink psink(opened.graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0);
+		RunSinkPipeline(ctx, path_sql, psink);
+		PhysicalGGEdgeSink fsink(opened.graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, true);
+		RunSinkPipeline(ctx, filter_sql, fsink);
+		auto sources = QueryInt64Column(ctx, sources_sql, "gg_same_neighbour_paths: sources");
+		opened.source = make_unique<PhysicalGGFilteredPaths>(opened.graph, (int)hops, move(sources), 0);
+	};
+	return_types = vector<LogicalType>(hops + 2, LogicalType::BIGINT);
 	names.push_back("w");
 	for (int64_t c = 0; c <= hops; c++) {
 		names.push_back("v" + to_string(c));
@@ -176,12 +198,14 @@ static unique_ptr<FunctionData> KhopBindInternal(ClientContext &context, vector<
                                                  bool count_only) {
 	const auto k_min = inputs[5].GetValue<int64_t>(), k_max = inputs[6].GetValue<int64_t>();
 	CheckHops(k_min, k_max);
+	const auto spec = GraphSpecFromArguments(inputs);
 	auto data = make_unique<GGFunctionData>();
-	data->graph = BuildGraph(context, inputs);
-	data->source = make_unique<PhysicalGGPathExpand>(data->graph, (int)k_min, (int)k_max, count_only,
-	                                                 vector<int64_t>(), true, 0);
-	data->gstate = data->source->GetGlobalSourceState(context);
-	return_types = data->source->GetTypes();
+	data->open = [=](ClientContext &ctx, GGOpened &opened) {
+		opened.graph = GGBuildGraph(ctx, spec);
+		opened.source = make_unique<PhysicalGGPathExpand>(opened.graph, (int)k_min, (int)k_max, count_only,
+		                                                  vector<int64_t>(), true, 0);
+	};
+	return_types = PhysicalGGPathExpand::OutputTypes((int)k_max, count_only);
 	names.push_back("hops");
 	if (count_only) {
 		names.push_back("rows");
@@ -215,12 +239,16 @@ static unique_ptr<FunctionData> ShortestBind(ClientContext &context, vector<Valu
                                              vector<LogicalType> &input_table_types,
                                              vector<string> &input_table_names, vector<LogicalType> &return_types,
                                              vector<string> &names) {
+	const auto spec = GraphSpecFromArguments(inputs);
+	const string sources_sql = inputs[5].ToString();
+	const auto max_hops = inputs[6].GetValue<int64_t>();
 	auto data = make_unique<GGFunctionData>();
-	data->graph = BuildGraph(context, inputs);
-	auto sources = QueryInt64Column(context, inputs[5].ToString(), "gg_shortest_path: sources");
-	data->source = make_unique<PhysicalGGShortestPath>(data->graph, move(sources), (int)inputs[6].GetValue<int64_t>(), 0);
-	data->gstate = data->source->GetGlobalSourceState(context);
-	return_types = data->source->GetTypes();
+	data->open = [=](ClientContext &ctx, GGOpened &opened) {
+		opened.graph = GGBuildGraph(ctx, spec);
+		auto sources = QueryInt64Column(ctx, sources_sql, "gg_shortest_path: sources");
+		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), (int)max_hops, 0);
+	};
+	return_types = {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER};
 	names = {"startPerson", "friend", "hopCount"};
 	return move(data);
 }
@@ -235,14 +263,14 @@ static void LoadInternal(DatabaseInstance &db) {
 	sp_args.push_back(LogicalType::VARCHAR);
 	sp_args.push_back(LogicalType::BIGINT);
 
-	TableFunction khop("gg_khop", khop_args, GGFunction, KhopBind, GGInit);
-	TableFunction khop_count("gg_khop_count", khop_args, GGFunction, KhopCountBind, GGInit);
-	TableFunction shortest("gg_shortest_path", sp_args, GGFunction, ShortestBind, GGInit);
-	TableFunction filtered("gg_same_neighbour_paths",
-	                       {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
-	                        LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
-	                        LogicalType::BIGINT},
-	                       GGFunction, FilteredPathsBind, GGInit);
+	auto khop = GGScanFunction("gg_khop", khop_args, KhopBind);
+	auto khop_count = GGScanFunction("gg_khop_count", khop_args, KhopCountBind);
+	auto shortest = GGScanFunction("gg_shortest_path", sp_args, ShortestBind);
+	auto filtered = GGScanFunction("gg_same_neighbour_paths",
+	                               {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
+	                                LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
+	                                LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::BIGINT},
+	                               FilteredPathsBind);
 	CreateTableFunctionInfo khop_info(khop), khop_count_info(khop_count), shortest_info(shortest),
 	    filtered_info(filtered);
 
@@ -253,6 +281,7 @@ static void LoadInternal(DatabaseInstance &db) {
 	catalog.CreateTableFunction(*con.context, &khop_count_info);
 	catalog.CreateTableFunction(*con.context, &shortest_info);
 	catalog.CreateTableFunction(*con.context, &filtered_info);
+	GGRegisterPlanRules(*con.context);
 	con.Commit();
 }
 

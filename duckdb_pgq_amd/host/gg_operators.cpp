@@ -134,15 +134,18 @@ SinkFinalizeType PhysicalGGVertexSink::Finalize(Pipeline &pipeline, Event &event
 }
 
 PhysicalGGEdgeSink::PhysicalGGEdgeSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
-                                       idx_t estimated_cardinality, bool as_filter_p)
+                                       idx_t estimated_cardinality, bool as_filter_p, bool derive_vertices_p)
     : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), graph(move(graph_p)),
-      as_filter(as_filter_p) {
+      as_filter(as_filter_p), derive_vertices(derive_vertices_p) {
 }
 
 unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext &context) const {
 	if (as_filter) {
 		// second edge table over the same staged vertices: drop the first table's staged rows only
 		GGGraph::Check(gg_staging_clear_edges(graph->ctx), "gg_staging_clear_edges");
+	} else if (derive_vertices) {
+		// no vertex sink ran before this one: start from empty staging
+		GGGraph::Check(gg_staging_clear(graph->ctx), "gg_staging_clear");
 	}
 	return make_unique<GGSinkGlobalState>();
 }
@@ -175,6 +178,9 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
 	if (target) {
 		gg_csr_destroy(target);
 		target = nullptr;
+	}
+	if (derive_vertices) {
+		GGGraph::Check(gg_vertices_from_edges(graph->ctx, nullptr), "gg_vertices_from_edges");
 	}
 	GGGraph::Check(gg_csr_build(graph->ctx, &target), "gg_csr_build");
 	return SinkFinalizeType::READY;

@@ -75,12 +75,15 @@ public:
 class PhysicalGGEdgeSink : public PhysicalOperator {
 public:
 	//! as_filter: the rows are a SECOND edge table over the already staged vertex set; Finalize builds
-	//! GGGraph::filter_csr instead of GGGraph::csr
+	//! GGGraph::filter_csr instead of GGGraph::csr.
+	//! derive_vertices: there is no vertex sink — the pattern is a join chain over the edge table alone
+	//! (k1.dst = k2.src), so the vertex set is the distinct endpoint ids (gg_vertices_from_edges).
 	PhysicalGGEdgeSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality,
-	                   bool as_filter = false);
+	                   bool as_filter = false, bool derive_vertices = false);
 
 	shared_ptr<GGGraph> graph;
 	bool as_filter;
+	bool derive_vertices;
 
 public:
 	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;

@@ -1,0 +1,104 @@
+/* gg_plan_hook.c — plan-level substitution without touching the reference's sources.
+ *
+ * The maintainers' route to let MATCH-shaped plans use the GPU operators is a three-line call-out in
+ * PhysicalPlanGenerator::CreatePlan(LogicalComparisonJoin &) / (LogicalAggregate &)
+ * (src/execution/physical_plan/plan_comparison_join.cpp:146, plan_aggregate.cpp:20 of the reference;
+ * INTEGRATION.md §3).  The reference tree is read-only here, so this shim supplies the same call-out from
+ * the outside: it DEFINES those two member functions under their Itanium-mangled names.  Loaded before
+ * libduckdb (LD_PRELOAD, or dlopen(RTLD_GLOBAL) from the host process), the dynamic linker binds
+ * libduckdb's own PLT calls to the definitions below; each one offers the logical operator to the rule
+ * the extension registered (gg_plan_rule.cpp) and otherwise forwards to libduckdb's original.
+ *
+ * Deliberately plain C with no duckdb header: the shim must load before libduckdb does, so it cannot have
+ * undefined references to its vtables.  The calling convention is spelled out instead (x86-64 SysV):
+ * a function returning std::unique_ptr<PhysicalOperator> takes the address of the return slot as a hidden
+ * first argument and returns that address; `this` and the operator reference follow.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <link.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gg_plan_hook.h"
+
+#define SYM_JOIN "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_21LogicalComparisonJoinE"
+#define SYM_AGGR "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_16LogicalAggregateE"
+
+typedef void *(*create_plan_fn)(void *ret_slot, void *generator, void *logical_op);
+
+static gg_plan_rule_fn g_rule[GG_PLAN_HOOK_KINDS];
+static create_plan_fn g_orig[GG_PLAN_HOOK_KINDS];
+static const char *const g_sym[GG_PLAN_HOOK_KINDS] = {SYM_JOIN, SYM_AGGR};
+
+void *gg_hook_create_plan_join(void *ret_slot, void *generator, void *op) __asm__(SYM_JOIN);
+void *gg_hook_create_plan_aggregate(void *ret_slot, void *generator, void *op) __asm__(SYM_AGGR);
+
+struct find_ctx {
+  const char *sym;
+  void *self;
+  void *found;
+};
+
+/* walk the loaded objects for another definition of `sym` (libduckdb may have been dlopen'ed RTLD_LOCAL,
+ * where RTLD_NEXT does not reach it) */
+static int find_in_object(struct dl_phdr_info *info, size_t size, void *data) {
+  struct find_ctx *c = (struct find_ctx *)data;
+  (void)size;
+  if (!info->dlpi_name || !info->dlpi_name[0]) return 0;
+  void *h = dlopen(info->dlpi_name, RTLD_LAZY | RTLD_NOLOAD);
+  if (!h) return 0;
+  void *p = dlsym(h, c->sym);
+  dlclose(h);
+  if (p && p != c->self) {
+    c->found = p;
+    return 1;
+  }
+  return 0;
+}
+
+static create_plan_fn original(int kind, void *self) {
+  if (g_orig[kind]) return g_orig[kind];
+  void *p = dlsym(RTLD_NEXT, g_sym[kind]);
+  if (!p || p == self) {
+    struct find_ctx c = {g_sym[kind], self, NULL};
+    dl_iterate_phdr(find_in_object, &c);
+    p = c.found;
+  }
+  if (!p) {
+    fprintf(stderr, "gg_plan_hook: no original definition of %s is loaded\n", g_sym[kind]);
+    return NULL;
+  }
+  g_orig[kind] = (create_plan_fn)p;
+  return g_orig[kind];
+}
+
+static void *dispatch(int kind, void *self, void *ret_slot, void *generator, void *op) {
+  gg_plan_rule_fn rule = g_rule[kind];
+  if (rule && rule(ret_slot, generator, op)) return ret_slot; /* the rule constructed the plan in place */
+  create_plan_fn orig = original(kind, self);
+  if (!orig) {
+    *(void **)ret_slot = NULL; /* empty unique_ptr: the caller will fail on it rather than run wild */
+    return ret_slot;
+  }
+  return orig(ret_slot, generator, op);
+}
+
+void *gg_hook_create_plan_join(void *ret_slot, void *generator, void *op) {
+  return dispatch(GG_PLAN_HOOK_JOIN, (void *)gg_hook_create_plan_join, ret_slot, generator, op);
+}
+
+void *gg_hook_create_plan_aggregate(void *ret_slot, void *generator, void *op) {
+  return dispatch(GG_PLAN_HOOK_AGGREGATE, (void *)gg_hook_create_plan_aggregate, ret_slot, generator, op);
+}
+
+int gg_plan_hook_register(int kind, gg_plan_rule_fn rule) {
+  if (kind < 0 || kind >= GG_PLAN_HOOK_KINDS) return -1;
+  g_rule[kind] = rule;
+  return 0;
+}
+
+int gg_plan_hook_registered(int kind) {
+  return kind >= 0 && kind < GG_PLAN_HOOK_KINDS && g_rule[kind] != NULL;
+}

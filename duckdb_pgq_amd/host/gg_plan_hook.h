@@ -1,0 +1,22 @@
+/* gg_plan_hook.h — contract between the interposition shim (gg_plan_hook.c, libgg_plan_hook.so) and the
+ * planner rule of the extension (gg_plan_rule.cpp). */
+#ifndef GG_PLAN_HOOK_H
+#define GG_PLAN_HOOK_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GG_PLAN_HOOK_JOIN = 0, GG_PLAN_HOOK_AGGREGATE = 1, GG_PLAN_HOOK_KINDS = 2 };
+
+/* A rule looks at the logical operator about to be planned.  To take it over it constructs a
+ * std::unique_ptr<duckdb::PhysicalOperator> in *ret_slot (placement new) and returns non-zero; returning
+ * zero leaves ret_slot untouched and the reference's own CreatePlan runs. */
+typedef int (*gg_plan_rule_fn)(void *ret_slot, void *physical_plan_generator, void *logical_operator);
+
+int gg_plan_hook_register(int kind, gg_plan_rule_fn rule);
+int gg_plan_hook_registered(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

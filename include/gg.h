@@ -162,6 +162,13 @@ int gg_result_filter_common_neighbour(gg_ctx *ctx, const gg_result *res, int hop
                                       gg_result **out);
 /* Forget the staged edge rows but keep the staged vertex table (several edge tables, one vertex set). */
 int gg_staging_clear_edges(gg_ctx *ctx);
+/* Replace the staged vertex table by the distinct endpoint ids of the staged edge rows, in ascending
+ * (signed) order — the vertex set a join chain over the edge table ALONE ranges over
+ * (`knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id`, benchmark/ldbc/queries/
+ * interactive-complex-3.sql:9-11: no vertex table in the pattern, so every id that occurs is a vertex
+ * and no edge row is dropped).  Computed on the device (hash set + radix sort); *n_vertices (nullable)
+ * receives the number of distinct ids. */
+int gg_vertices_from_edges(gg_ctx *ctx, uint64_t *n_vertices);
 
 /* ---- 64-lane bitset BFS (shortest path length) --------------------------------------------- */
 typedef struct gg_bfs_stats {

@@ -17,6 +17,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBDUCKDB = os.path.join(HERE, "_ref", "libduckdb.so")
 LIBGGREF = os.path.join(HERE, "_ref", "libggref.so")
+# interposition shim of the product's planner rules (duckdb_pgq_amd/host/gg_plan_hook.c): a pass-through
+# until the extension registers its rules, but it has to be in the global scope BEFORE libduckdb
+PLAN_HOOK = os.path.join(os.path.dirname(HERE), "duckdb_pgq_amd", "libgg_plan_hook.so")
 
 
 def available() -> bool:
@@ -37,6 +40,7 @@ class RefDuckDB:
     def __init__(self, threads: int | None = None):
         if not available():
             raise RuntimeError("oracle/_ref is not built (make -C oracle ref, needs /root/reference)")
+        self.hook = C.CDLL(PLAN_HOOK, mode=C.RTLD_GLOBAL) if os.path.exists(PLAN_HOOK) else None
         self.L = C.CDLL(LIBDUCKDB, mode=C.RTLD_GLOBAL)
         self.G = C.CDLL(LIBGGREF)
         self.L.duckdb_value_int64.restype = C.c_int64
@@ -81,6 +85,23 @@ class RefDuckDB:
                     out[i, c] = self.L.duckdb_value_int64(C.byref(r), c, i)
         self.L.duckdb_destroy_result(C.byref(r))
         return out
+
+    def explain(self, sql: str) -> str:
+        """Physical plan of sql as text (EXPLAIN's second column)."""
+        r = _Result()
+        self.L.duckdb_value_varchar.restype = C.c_void_p
+        self.L.duckdb_value_varchar.argtypes = [C.POINTER(_Result), C.c_uint64, C.c_uint64]
+        if self.L.duckdb_query(self.con, ("EXPLAIN " + sql).encode(), C.byref(r)) != 0:
+            msg = r.error_message.decode() if r.error_message else "?"
+            self.L.duckdb_destroy_result(C.byref(r))
+            raise RuntimeError(f"reference query failed: {msg}")
+        parts = []
+        for i in range(r.row_count):
+            p = self.L.duckdb_value_varchar(C.byref(r), r.column_count - 1, i)
+            parts.append(C.string_at(p).decode())
+            self.L.duckdb_free(C.c_void_p(p))
+        self.L.duckdb_destroy_result(C.byref(r))
+        return "\n".join(parts)
 
     def load_table(self, name: str, columns: dict):
         """CREATE TABLE name(col BIGINT NOT NULL, ...) and append the given int64 arrays."""

@@ -531,3 +531,48 @@ def test_build_without_edge_rowid(gg, orc):
         g.close()
     finally:
         gg.set_edge_rowid(True)
+
+
+@pytest.mark.parametrize("V,E,seed", [(1, 3, 1), (7, 30, 2), (500, 9000, 3), (70000, 300000, 4), (200000, 150000, 5)])
+def test_vertices_from_edges_is_the_sorted_distinct_endpoint_set(gg, orc, V, E, seed):
+    """Join chains over an edge table alone: vertex table := distinct endpoints, ascending (gg.h)."""
+    _, src, dst = datagen.small_graph(V, E, seed)
+    gg.staging_clear()
+    gg.append_edges(src, dst)
+    n = gg.vertices_from_edges()
+    expect = np.unique(np.concatenate([src, dst]))
+    assert n == expect.size
+    csr = gg.build_csr()
+    rc, g = orc.csr_build(expect, src, dst, None)
+    assert rc == 0
+    assert_csr_equal(csr, g)  # vid column == np.unique, no edge dropped
+    assert csr.dropped == 0 and csr.E == src.size
+    k_max = 3 if E <= 30000 else 2
+    assert gg.expand_khop(csr, 1, k_max) == g.khop(1, k_max)
+    csr.close()
+    g.close()
+
+
+def test_vertices_from_edges_extreme_ids_and_empty(gg, orc):
+    i64 = np.iinfo(np.int64)
+    src = np.array([i64.min, -1, 0, i64.max, 5, i64.min, 1 << 32, -(1 << 32)], np.int64)
+    dst = np.array([i64.max, 0, -1, i64.min, 5, 7, (1 << 32) + 1, -(1 << 32) - 1], np.int64)
+    gg.staging_clear()
+    gg.append_edges(src, dst)
+    n = gg.vertices_from_edges()
+    expect = np.unique(np.concatenate([src, dst]))
+    assert n == expect.size
+    csr = gg.build_csr()
+    _, _, _, vid = csr.export()
+    assert np.array_equal(vid, expect)
+    csr.close()
+    # only the sentinel id
+    gg.staging_clear()
+    gg.append_edges(np.array([i64.min], np.int64), np.array([i64.min], np.int64))
+    assert gg.vertices_from_edges() == 1
+    csr = gg.build_csr()
+    assert csr.V == 1 and csr.E == 1
+    csr.close()
+    # no edges at all
+    gg.staging_clear()
+    assert gg.vertices_from_edges() == 0
