@@ -795,8 +795,8 @@ int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
 
 // ---- vertex table from the edge endpoints (gg_vertices_from_edges) ---------------------------------
 // distinct ids via an open-addressing key set (8-byte slots), compacted and then sorted ascending with
-// two stable 32-bit radix sorts (low half, then sign-flipped high half), so the dense numbering does not
-// depend on insertion races.
+// three stable radix sorts over 22/22/20-bit chunks of the sign-flipped id, so the dense numbering does
+// not depend on insertion races.
 namespace gg {
 
 struct SetStatus {
@@ -881,6 +881,16 @@ __global__ __launch_bounds__(256) void k_set_compact(const int64_t *__restrict__
   }
 }
 
+// sort key of one LSD round: 22-bit chunk `round` (0,1) or the top 20 bits (2) of the sign-flipped id.
+// Chunks stay below 2^22, clear of the radix kernels' 0xFFFFFFFF "dropped" marker.
+__global__ __launch_bounds__(256) void k_set_chunk(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
+                                                   uint64_t n, int round, uint32_t *__restrict__ key) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t x = ((uint64_t)hi[i] << 32) | (uint64_t)lo[i];
+  key[i] = (uint32_t)(x >> (22 * round)) & 0x3FFFFFu;
+}
+
 __global__ __launch_bounds__(256) void k_set_emit(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
                                                   uint64_t n, uint32_t has_min, int64_t *__restrict__ vid) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -932,22 +942,27 @@ extern "C" int gg_vertices_from_edges(gg_ctx *ctx, uint64_t *n_vertices) {
   }
   GG_TRY(grow_column(ctx, ctx->c_vid, 0, V));
   if (n) {
-    uint32_t *lo = nullptr, *hi = nullptr, *lo1 = nullptr, *hi1 = nullptr, *lo2 = nullptr, *hi2 = nullptr;
+    uint32_t *lo[2] = {nullptr, nullptr}, *hi[2] = {nullptr, nullptr}, *key = nullptr, *key_sorted = nullptr;
     unsigned long long *cursor = nullptr, *tot = nullptr;
-    for (uint32_t **p : {&lo, &hi, &lo1, &hi1, &lo2, &hi2}) GG_TRY(ctx->dev_alloc((void **)p, n * sizeof(uint32_t)));
+    for (uint32_t **p : {&lo[0], &lo[1], &hi[0], &hi[1], &key, &key_sorted})
+      GG_TRY(ctx->dev_alloc((void **)p, n * sizeof(uint32_t)));
     GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
     GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(unsigned long long)));
     GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s));
     GG_LAUNCH(ctx, "set_compact", k_set_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, set, cap, cursor,
-              lo, hi);
-    // pass 0 of each sort reads its element count from the device: `cursor` holds exactly n by then
-    GG_HIP(hipMemcpyAsync(tot, cursor, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
-    RadixIO by_lo{lo, hi, nullptr, lo1, hi1, nullptr};
-    GG_TRY(radix_sort_stable(ctx, by_lo, n, false, false, 32, nullptr, 0, tot, true));
-    GG_HIP(hipMemcpyAsync(tot, cursor, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
-    RadixIO by_hi{hi1, lo1, nullptr, hi2, lo2, nullptr};
-    GG_TRY(radix_sort_stable(ctx, by_hi, n, false, false, 32, nullptr, 0, tot, true));
-    GG_LAUNCH(ctx, "set_emit", k_set_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lo2, hi2, n,
+              lo[0], hi[0]);
+    // three stable LSD rounds over (22, 22, 20)-bit chunks, the two id halves riding along as payloads
+    int cur = 0;
+    for (int round = 0; round < 3; round++) {
+      GG_LAUNCH(ctx, "set_chunk", k_set_chunk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lo[cur], hi[cur], n,
+                round, key);
+      // pass 0 of a sort reads its element count from the device: `cursor` holds exactly n
+      GG_HIP(hipMemcpyAsync(tot, cursor, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+      RadixIO io{key, lo[cur], hi[cur], key_sorted, lo[cur ^ 1], hi[cur ^ 1]};
+      GG_TRY(radix_sort_stable(ctx, io, n, true, false, round == 2 ? 20 : 22, nullptr, 0, tot, true));
+      cur ^= 1;
+    }
+    GG_LAUNCH(ctx, "set_emit", k_set_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lo[cur], hi[cur], n,
               (uint32_t)has_min, ctx->c_vid.dev);
   } else {
     const int64_t only = HT_EMPTY;  // has_min with nothing else

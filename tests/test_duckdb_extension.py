@@ -176,7 +176,9 @@ def test_plan_rule_join_chains_give_the_reference_result(db):
     sql = _chain(2, "DISTINCT k2.k_person2id") + f" AND k1.k_person1id = {s} ORDER BY 1"
     cpu, gpu = _both_plans(d, sql)
     assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu)
-    cpu, gpu = _both_plans(d, _chain(2, "count(*)") + " AND k1.k_person1id = -12345")  # not a vertex
+    absent = int(np.sort(vid)[5]) + 1  # inside the column's min/max statistics, but nobody's id
+    assert absent not in set(vid.tolist())
+    cpu, gpu = _both_plans(d, _chain(2, "count(*)") + f" AND k1.k_person1id = {absent}")
     assert cpu[0, 0] == 0 and np.array_equal(cpu, gpu)
 
     # grouped aggregate above a substituted join
