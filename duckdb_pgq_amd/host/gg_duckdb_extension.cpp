@@ -135,7 +135,7 @@ TableFunction GGScanFunction(const string &name, vector<LogicalType> arguments, 
 	return function;
 }
 
-static vector<int64_t> QueryInt64Column(ClientContext &context, const string &sql, const char *what) {
+vector<int64_t> GGQueryInt64Column(ClientContext &context, const string &sql, const char *what) {
 	Connection con(*context.db);
 	auto result = con.Query(sql);
 	if (!result->success) {
@@ -176,7 +176,7 @@ static unique_ptr<FunctionData> FilteredPathsBind(ClientContext &context, vector
 		RunSinkPipeline(ctx, path_sql, psink);
 		PhysicalGGEdgeSink fsink(opened.graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, true);
 		RunSinkPipeline(ctx, filter_sql, fsink);
-		auto sources = QueryInt64Column(ctx, sources_sql, "gg_same_neighbour_paths: sources");
+		auto sources = GGQueryInt64Column(ctx, sources_sql, "gg_same_neighbour_paths: sources");
 		opened.source = make_unique<PhysicalGGFilteredPaths>(opened.graph, (int)hops, move(sources), 0);
 	};
 	return_types = vector<LogicalType>(hops + 2, LogicalType::BIGINT);
@@ -245,7 +245,7 @@ static unique_ptr<FunctionData> ShortestBind(ClientContext &context, vector<Valu
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &ctx, GGOpened &opened) {
 		opened.graph = GGBuildGraph(ctx, spec);
-		auto sources = QueryInt64Column(ctx, sources_sql, "gg_shortest_path: sources");
+		auto sources = GGQueryInt64Column(ctx, sources_sql, "gg_shortest_path: sources");
 		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), (int)max_hops, 0);
 	};
 	return_types = {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER};

@@ -36,6 +36,9 @@ struct GGGraphSpec {
 };
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec);
 
+//! first column of `sql` (run on a side connection) as int64, NULLs skipped
+vector<int64_t> GGQueryInt64Column(ClientContext &context, const string &sql, const char *what);
+
 //! "identifier" with embedded quotes doubled
 string GGQuote(const string &ident);
 

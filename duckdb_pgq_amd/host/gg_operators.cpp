@@ -384,10 +384,10 @@ public:
 };
 
 PhysicalGGShortestPath::PhysicalGGShortestPath(shared_ptr<GGGraph> graph_p, vector<int64_t> sources_p,
-                                               int max_hops_p, idx_t estimated_cardinality)
+                                               int max_hops_p, idx_t estimated_cardinality, bool lone_sources_p)
     : PhysicalOperator(PhysicalOperatorType::INVALID,
                        {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER}, estimated_cardinality),
-      graph(move(graph_p)), sources(move(sources_p)), max_hops(max_hops_p) {
+      graph(move(graph_p)), sources(move(sources_p)), max_hops(max_hops_p), lone_sources(lone_sources_p) {
 }
 
 unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(ClientContext &context) const {
@@ -420,13 +420,20 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 		GGGraph::Check(gg_bfs64(graph->ctx, graph->csr, uniq.data() + base, n, max_hops, nullptr, 0, dist.data(), nullptr),
 		               "gg_bfs64");
 		for (int i = 0; i < n; i++) {
+			bool reached_any = false;
 			for (uint64_t v = 0; v < V; v++) {
 				int32_t d = dist[(size_t)i * V + v];
 				if (d >= 0) {
 					state->start.push_back(uniq[base + i]);
 					state->frnd.push_back(vid[v]);
 					state->hop.push_back(d);
+					reached_any = true;
 				}
+			}
+			if (!reached_any && lone_sources) { // not a vertex of the graph: only its own seed row
+				state->start.push_back(uniq[base + i]);
+				state->frnd.push_back(uniq[base + i]);
+				state->hop.push_back(0);
 			}
 		}
 	}

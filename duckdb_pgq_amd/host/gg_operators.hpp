@@ -165,12 +165,15 @@ public:
 //! Sources are processed in batches of 64 bit lanes.
 class PhysicalGGShortestPath : public PhysicalOperator {
 public:
+	//! lone_sources: a source that is not a vertex of the graph (it has no edge in an edge-only vertex
+	//! set) still reaches itself at hop 0 — the seed row of the recursive CTE does not depend on the edges
 	PhysicalGGShortestPath(shared_ptr<GGGraph> graph, vector<int64_t> sources, int max_hops,
-	                       idx_t estimated_cardinality);
+	                       idx_t estimated_cardinality, bool lone_sources = false);
 
 	shared_ptr<GGGraph> graph;
 	vector<int64_t> sources;
 	int max_hops;
+	bool lone_sources;
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;

@@ -12,7 +12,9 @@
 //   join rule       the subtree's output columns are the walk's vertices -> materialised k-hop expansion
 //                   under a projection that restores the join's column layout;
 //   aggregate rule  ungrouped count(*) directly over such a subtree -> the count-only expansion (nothing
-//                   is materialised), one output row.
+//                   is materialised), one output row;
+//   aggregate rule 2  min(hop) GROUP BY (start, friend) over the `friends` recursive CTE of
+//                   bi-10-shortestpath.sql -> the 64-lane bitset BFS (see PlanShortestPath below).
 //
 // A pattern is accepted only when the substitution is exact for every database state:
 //   * every leaf is a plain sequential scan, every join INNER with only column = column conditions; the
@@ -49,12 +51,24 @@
 #include "duckdb/planner/constraints/bound_not_null_constraint.hpp"
 #include "duckdb/planner/constraints/bound_unique_constraint.hpp"
 #include "duckdb/planner/expression/bound_aggregate_expression.hpp"
+#include "duckdb/planner/expression/bound_case_expression.hpp"
+#include "duckdb/planner/expression/bound_comparison_expression.hpp"
+#include "duckdb/planner/expression/bound_conjunction_expression.hpp"
+#include "duckdb/planner/expression/bound_constant_expression.hpp"
+#include "duckdb/planner/expression/bound_function_expression.hpp"
+#include "duckdb/planner/expression/bound_operator_expression.hpp"
 #include "duckdb/planner/expression/bound_cast_expression.hpp"
 #include "duckdb/planner/expression/bound_reference_expression.hpp"
 #include "duckdb/planner/filter/conjunction_filter.hpp"
 #include "duckdb/planner/filter/constant_filter.hpp"
+#include "duckdb/common/types/chunk_collection.hpp"
 #include "duckdb/planner/operator/logical_aggregate.hpp"
+#include "duckdb/planner/operator/logical_chunk_get.hpp"
 #include "duckdb/planner/operator/logical_comparison_join.hpp"
+#include "duckdb/planner/operator/logical_cteref.hpp"
+#include "duckdb/planner/operator/logical_filter.hpp"
+#include "duckdb/planner/operator/logical_projection.hpp"
+#include "duckdb/planner/operator/logical_recursive_cte.hpp"
 #include "duckdb/planner/operator/logical_get.hpp"
 #include "gg_extension.hpp"
 #include "gg_plan_hook.h"
@@ -157,6 +171,67 @@ bool IsEqualityWithConstant(TableFilter &filter, int64_t &value) {
 			found = true;
 		}
 		return found;
+	}
+	default:
+		return false;
+	}
+}
+
+//! A pushed-down filter over an integer column as SQL text; false if the filter is of an unknown kind.
+bool FilterToSQL(TableFilter &filter, const string &column, string &out) {
+	switch (filter.filter_type) {
+	case TableFilterType::IS_NOT_NULL:
+		out = column + " IS NOT NULL";
+		return true;
+	case TableFilterType::CONSTANT_COMPARISON: {
+		auto &constant = (ConstantFilter &)filter;
+		if (constant.constant.is_null || !constant.constant.type().IsIntegral()) {
+			return false;
+		}
+		const char *op;
+		switch (constant.comparison_type) {
+		case ExpressionType::COMPARE_EQUAL:
+			op = " = ";
+			break;
+		case ExpressionType::COMPARE_NOTEQUAL:
+			op = " <> ";
+			break;
+		case ExpressionType::COMPARE_LESSTHAN:
+			op = " < ";
+			break;
+		case ExpressionType::COMPARE_LESSTHANOREQUALTO:
+			op = " <= ";
+			break;
+		case ExpressionType::COMPARE_GREATERTHAN:
+			op = " > ";
+			break;
+		case ExpressionType::COMPARE_GREATERTHANOREQUALTO:
+			op = " >= ";
+			break;
+		default:
+			return false;
+		}
+		out = column + op + to_string(constant.constant.GetValue<int64_t>());
+		return true;
+	}
+	case TableFilterType::CONJUNCTION_AND:
+	case TableFilterType::CONJUNCTION_OR: {
+		const bool is_and = filter.filter_type == TableFilterType::CONJUNCTION_AND;
+		auto &children = is_and ? ((ConjunctionAndFilter &)filter).child_filters
+		                        : ((ConjunctionOrFilter &)filter).child_filters;
+		if (children.empty()) {
+			return false;
+		}
+		out = "(";
+		for (idx_t i = 0; i < children.size(); i++) {
+			string child;
+			if (!FilterToSQL(*children[i], column, child)) {
+				return false;
+			}
+			out += (i ? (is_and ? " AND " : " OR ") : "") + child;
+		}
+		out += ")";
+		return true;
 	}
 	default:
 		return false;
@@ -629,6 +704,541 @@ unique_ptr<PhysicalOperator> PlanCountOverJoinChain(LogicalAggregate &op) {
 	return move(projection);
 }
 
+
+//===--------------------------------------------------------------------===//
+// Aggregate rule 2: min(hop) GROUP BY (start, friend) over the friends recursive CTE -> 64-lane BFS
+//===--------------------------------------------------------------------===//
+// benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31 (friends / friends_shortest):
+//
+//   WITH RECURSIVE friends(startPerson, hopCount, friend) AS (
+//       SELECT p_personid, 0, p_personid FROM person WHERE p_personid = <id>          -- seed
+//     UNION
+//       SELECT f.startPerson, f.hopCount+1, <k.k_person2id>                            -- step
+//         FROM friends f, knows k [, person p]
+//        WHERE f.friend = k.k_person1id [AND k.k_person2id = p.p_personid] AND f.hopCount < <K>)
+//   SELECT startPerson, min(hopCount), friend FROM friends GROUP BY startPerson, friend
+//
+// The reference runs PhysicalRecursiveCTE (hash-join rebuild per level + UNION dedupe table) under a
+// PhysicalHashAggregate; min over the levels at which a vertex shows up is its BFS distance, so the whole
+// subtree is one PhysicalGGShortestPath.  The CTE alone is NOT replaced: it also holds the longer walks.
+// Column order of the CTE, the seed predicate (none, `= c`, `IN (...)`, ORs of `= c`) and the optional
+// validating join with the vertex table are read off the plan; anything else is declined.
+
+//! a column somewhere below: (table index of the producing leaf, column id there)
+struct PlanColumn {
+	idx_t table_index = INVALID_INDEX;
+	idx_t column = INVALID_INDEX;
+	bool operator==(const PlanColumn &o) const {
+		return table_index == o.table_index && column == o.column;
+	}
+};
+
+struct StepInput {
+	LogicalCTERef *cte = nullptr;
+	int64_t max_hops = -1; // from `hop < K` on the CTE scan
+	idx_t bound_column = INVALID_INDEX;
+	vector<LogicalGet *> scans;
+	vector<std::pair<PlanColumn, PlanColumn>> equalities;
+};
+
+bool IntegerConstant(Expression &expr, int64_t &value) {
+	if (expr.type != ExpressionType::VALUE_CONSTANT) {
+		return false;
+	}
+	auto &constant = ((BoundConstantExpression &)expr).value;
+	if (constant.is_null || !constant.type().IsIntegral()) {
+		return false;
+	}
+	value = constant.GetValue<int64_t>();
+	return true;
+}
+
+bool ReferenceIndex(Expression &expr, idx_t &index) {
+	if (expr.type != ExpressionType::BOUND_REF) {
+		return false;
+	}
+	index = ((BoundReferenceExpression &)expr).index;
+	return true;
+}
+
+//! binding of a leaf -> PlanColumn (GET: table column id; CTE scan: column position)
+bool ResolvePlanColumn(StepInput &in, const ColumnBinding &binding, PlanColumn &out) {
+	if (in.cte && in.cte->table_index == binding.table_index) {
+		out.table_index = binding.table_index;
+		out.column = binding.column_index;
+		return true;
+	}
+	for (auto get : in.scans) {
+		if (get->table_index == binding.table_index) {
+			if (binding.column_index >= get->column_ids.size() ||
+			    get->column_ids[binding.column_index] == COLUMN_IDENTIFIER_ROW_ID) {
+				return false;
+			}
+			out.table_index = binding.table_index;
+			out.column = get->column_ids[binding.column_index];
+			return true;
+		}
+	}
+	return false;
+}
+
+bool CollectStep(LogicalOperator &op, idx_t cte_index, StepInput &in) {
+	switch (op.type) {
+	case LogicalOperatorType::LOGICAL_CTE_REF: {
+		auto &ref = (LogicalCTERef &)op;
+		if (in.cte || ref.cte_index != cte_index) {
+			return false;
+		}
+		in.cte = &ref;
+		return true;
+	}
+	case LogicalOperatorType::LOGICAL_FILTER: {
+		// only `hop < K` (or <=) directly on the CTE scan
+		auto &filter = (LogicalFilter &)op;
+		if (filter.children.size() != 1 || filter.children[0]->type != LogicalOperatorType::LOGICAL_CTE_REF ||
+		    filter.expressions.size() != 1 || !filter.projection_map.empty() ||
+		    !CollectStep(*filter.children[0], cte_index, in)) {
+			return false;
+		}
+		auto &expr = *filter.expressions[0];
+		if (expr.type != ExpressionType::COMPARE_LESSTHAN && expr.type != ExpressionType::COMPARE_LESSTHANOREQUALTO) {
+			return false;
+		}
+		auto &cmp = (BoundComparisonExpression &)expr;
+		int64_t bound;
+		if (!ReferenceIndex(*cmp.left, in.bound_column) || !IntegerConstant(*cmp.right, bound)) {
+			return false;
+		}
+		in.max_hops = expr.type == ExpressionType::COMPARE_LESSTHAN ? bound : bound + 1;
+		return in.max_hops >= 0 && in.max_hops < (1 << 30);
+	}
+	case LogicalOperatorType::LOGICAL_GET: {
+		auto &get = (LogicalGet &)op;
+		if (!get.children.empty() || get.function.name != "seq_scan" || !get.table_filters.filters.empty() ||
+		    !get.bind_data || ((TableScanBindData &)*get.bind_data).is_index_scan) {
+			return false;
+		}
+		in.scans.push_back(&get);
+		return true;
+	}
+	case LogicalOperatorType::LOGICAL_COMPARISON_JOIN: {
+		auto &join = (LogicalComparisonJoin &)op;
+		if (join.join_type != JoinType::INNER || join.children.size() != 2 ||
+		    !CollectStep(*join.children[0], cte_index, in) || !CollectStep(*join.children[1], cte_index, in)) {
+			return false;
+		}
+		auto left_bindings = join.children[0]->GetColumnBindings();
+		auto right_bindings = join.children[1]->GetColumnBindings();
+		for (auto &cond : join.conditions) {
+			idx_t li, ri;
+			PlanColumn l, r;
+			if (cond.comparison != ExpressionType::COMPARE_EQUAL || cond.null_values_are_equal ||
+			    !ReferenceIndex(*cond.left, li) || !ReferenceIndex(*cond.right, ri) || li >= left_bindings.size() ||
+			    ri >= right_bindings.size() || !ResolvePlanColumn(in, left_bindings[li], l) ||
+			    !ResolvePlanColumn(in, right_bindings[ri], r)) {
+				return false;
+			}
+			in.equalities.emplace_back(l, r);
+		}
+		return true;
+	}
+	default:
+		return false;
+	}
+}
+
+//! The seed's predicate over the key: nothing, `key = c`, `key IN (c...)`, `key = c1 OR key = c2 ...`
+bool SeedConstants(Expression &expr, idx_t key_index, vector<int64_t> &out) {
+	idx_t index;
+	int64_t value;
+	switch (expr.type) {
+	case ExpressionType::COMPARE_EQUAL: {
+		auto &cmp = (BoundComparisonExpression &)expr;
+		if (ReferenceIndex(*cmp.left, index) && index == key_index && IntegerConstant(*cmp.right, value)) {
+			out.push_back(value);
+			return true;
+		}
+		if (ReferenceIndex(*cmp.right, index) && index == key_index && IntegerConstant(*cmp.left, value)) {
+			out.push_back(value);
+			return true;
+		}
+		return false;
+	}
+	case ExpressionType::COMPARE_IN: {
+		auto &in = (BoundOperatorExpression &)expr;
+		if (in.children.size() < 2 || !ReferenceIndex(*in.children[0], index) || index != key_index) {
+			return false;
+		}
+		for (idx_t i = 1; i < in.children.size(); i++) {
+			if (!IntegerConstant(*in.children[i], value)) {
+				return false;
+			}
+			out.push_back(value);
+		}
+		return true;
+	}
+	case ExpressionType::CONJUNCTION_OR: {
+		for (auto &child : ((BoundConjunctionExpression &)expr).children) {
+			if (!SeedConstants(*child, key_index, out)) {
+				return false;
+			}
+		}
+		return true;
+	}
+	default:
+		return false;
+	}
+}
+
+unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
+	// ---- the aggregate: GROUP BY two columns, min over a third
+	idx_t group_ref[2], hop_ref;
+	if (op.groups.size() != 2 || op.expressions.size() != 1 || !op.grouping_functions.empty() ||
+	    op.grouping_sets.size() > 1 || op.children.size() != 1 || !ReferenceIndex(*op.groups[0], group_ref[0]) ||
+	    !ReferenceIndex(*op.groups[1], group_ref[1]) ||
+	    op.expressions[0]->GetExpressionClass() != ExpressionClass::BOUND_AGGREGATE) {
+		return nullptr;
+	}
+	auto &aggr = (BoundAggregateExpression &)*op.expressions[0];
+	if (aggr.function.name != "min" || aggr.distinct || aggr.filter || aggr.children.size() != 1 ||
+	    !ReferenceIndex(*aggr.children[0], hop_ref)) {
+		return nullptr;
+	}
+	// ---- pure column projections down to the recursive CTE
+	auto node = op.children[0].get();
+	while (node->type == LogicalOperatorType::LOGICAL_PROJECTION && node->children.size() == 1) {
+		for (idx_t *ref : {&group_ref[0], &group_ref[1], &hop_ref}) {
+			if (*ref >= node->expressions.size() || !ReferenceIndex(*node->expressions[*ref], *ref)) {
+				return nullptr;
+			}
+		}
+		node = node->children[0].get();
+	}
+	if (node->type != LogicalOperatorType::LOGICAL_RECURSIVE_CTE) {
+		return nullptr;
+	}
+	auto &cte = (LogicalRecursiveCTE &)*node;
+	if (cte.union_all || cte.column_count != 3 || group_ref[0] == group_ref[1] || hop_ref == group_ref[0] ||
+	    hop_ref == group_ref[1] || group_ref[0] > 2 || group_ref[1] > 2 || hop_ref > 2) {
+		return nullptr;
+	}
+	const idx_t hop_col = hop_ref;
+
+	// ---- seed: SELECT key, 0, key FROM vertex_table [WHERE key ...]
+	auto &seed = *cte.children[0];
+	if (seed.type != LogicalOperatorType::LOGICAL_PROJECTION || seed.expressions.size() != 3 ||
+	    seed.children.size() != 1) {
+		return nullptr;
+	}
+	int64_t zero;
+	idx_t key_ref[2];
+	if (!IntegerConstant(*seed.expressions[hop_col], zero) || zero != 0 ||
+	    seed.expressions[hop_col]->return_type != LogicalType::INTEGER ||
+	    !ReferenceIndex(*seed.expressions[group_ref[0]], key_ref[0]) ||
+	    !ReferenceIndex(*seed.expressions[group_ref[1]], key_ref[1]) || key_ref[0] != key_ref[1]) {
+		return nullptr;
+	}
+	auto seed_child = seed.children[0].get();
+	bool all_vertices = true;
+	vector<int64_t> seed_constants;
+	idx_t key_index = key_ref[0];
+	// pure column projections (the IN-clause rewrite leaves one that drops its mark column)
+	while (seed_child->type == LogicalOperatorType::LOGICAL_PROJECTION && seed_child->children.size() == 1) {
+		if (key_index >= seed_child->expressions.size() ||
+		    !ReferenceIndex(*seed_child->expressions[key_index], key_index)) {
+			return nullptr;
+		}
+		seed_child = seed_child->children[0].get();
+	}
+	if (seed_child->type == LogicalOperatorType::LOGICAL_FILTER) {
+		auto &filter = (LogicalFilter &)*seed_child;
+		if (filter.expressions.size() != 1 || filter.children.size() != 1) {
+			return nullptr;
+		}
+		if (!filter.projection_map.empty()) {
+			if (key_index >= filter.projection_map.size()) {
+				return nullptr;
+			}
+			key_index = filter.projection_map[key_index];
+		}
+		all_vertices = false;
+		seed_child = filter.children[0].get();
+		idx_t mark_index;
+		if (seed_child->type == LogicalOperatorType::LOGICAL_COMPARISON_JOIN &&
+		    ReferenceIndex(*filter.expressions[0], mark_index)) {
+			// a long IN list: InClauseRewriter turned it into a MARK join against a constant chunk
+			// (src/optimizer/in_clause_rewriter.cpp): FILTER(mark) <- MARK JOIN(scan, CHUNK_GET)
+			auto &mark_join = (LogicalComparisonJoin &)*seed_child;
+			idx_t left_ref, right_ref;
+			if (mark_join.join_type != JoinType::MARK || mark_join.children.size() != 2 ||
+			    mark_join.conditions.size() != 1 || !mark_join.left_projection_map.empty() ||
+			    mark_join.conditions[0].comparison != ExpressionType::COMPARE_EQUAL ||
+			    mark_join.children[1]->type != LogicalOperatorType::LOGICAL_CHUNK_GET ||
+			    mark_index != mark_join.children[0]->GetColumnBindings().size() ||
+			    !ReferenceIndex(*mark_join.conditions[0].left, left_ref) || left_ref != key_index ||
+			    !ReferenceIndex(*mark_join.conditions[0].right, right_ref) || right_ref != 0) {
+				return nullptr;
+			}
+			auto &chunk_get = (LogicalChunkGet &)*mark_join.children[1];
+			if (!chunk_get.collection || chunk_get.collection->ColumnCount() != 1 ||
+			    !chunk_get.chunk_types[0].IsIntegral()) {
+				return nullptr;
+			}
+			for (idx_t r = 0; r < chunk_get.collection->Count(); r++) {
+				auto value = chunk_get.collection->GetValue(0, r);
+				if (!value.is_null) { // `key IN (..., NULL)` selects the same rows as without the NULL
+					seed_constants.push_back(value.GetValue<int64_t>());
+				}
+			}
+			seed_child = mark_join.children[0].get();
+		} else if (!SeedConstants(*filter.expressions[0], key_index, seed_constants)) {
+			return nullptr;
+		}
+	}
+	if (seed_child->type != LogicalOperatorType::LOGICAL_GET) {
+		return nullptr;
+	}
+	auto &seed_get = (LogicalGet &)*seed_child;
+	if (!seed_get.children.empty() || seed_get.function.name != "seq_scan" || !seed_get.bind_data ||
+	    key_index >= seed_get.column_ids.size()) {
+		return nullptr;
+	}
+	// `key = c` on an indexed key turns the scan into an index scan but keeps the filter above it
+	// (TableScanPushdownComplexFilter, src/function/table/table_scan.cpp): fine, the seed is re-read by key
+	if (((TableScanBindData &)*seed_get.bind_data).is_index_scan && all_vertices) {
+		return nullptr;
+	}
+	auto vertex_table = ((TableScanBindData &)*seed_get.bind_data).table;
+	const auto vertex_key = seed_get.column_ids[key_index];
+	if (vertex_key == COLUMN_IDENTIFIER_ROW_ID || !ColumnIsIntegerKey(*vertex_table, vertex_key)) {
+		return nullptr;
+	}
+	// filters pushed into the seed's scan (`key = c`, or the bounds the optimizer derives from an IN list)
+	vector<string> seed_predicates;
+	for (auto &entry : seed_get.table_filters.filters) {
+		string predicate;
+		if (entry.first != vertex_key ||
+		    !FilterToSQL(*entry.second, GGQuote(vertex_table->columns[vertex_key].name), predicate)) {
+			return nullptr;
+		}
+		seed_predicates.push_back(predicate);
+	}
+
+	// ---- step: SELECT f.start, f.hop + 1, <next vertex> FROM friends f JOIN edge [JOIN vertex] ...
+	auto &step = *cte.children[1];
+	if (step.type != LogicalOperatorType::LOGICAL_PROJECTION || step.expressions.size() != 3 ||
+	    step.children.size() != 1) {
+		return nullptr;
+	}
+	StepInput in;
+	if (!CollectStep(*step.children[0], cte.table_index, in) || !in.cte || in.max_hops < 0 ||
+	    in.bound_column != hop_col || in.scans.empty() || in.scans.size() > 2) {
+		return nullptr;
+	}
+	auto step_bindings = step.children[0]->GetColumnBindings();
+	auto column_of = [&](Expression &expr, PlanColumn &out) {
+		idx_t index;
+		return ReferenceIndex(expr, index) && index < step_bindings.size() &&
+		       ResolvePlanColumn(in, step_bindings[index], out);
+	};
+	// hop + 1
+	{
+		auto &expr = *step.expressions[hop_col];
+		if (expr.GetExpressionClass() != ExpressionClass::BOUND_FUNCTION) {
+			return nullptr;
+		}
+		auto &plus = (BoundFunctionExpression &)expr;
+		int64_t one;
+		PlanColumn hop;
+		if (plus.function.name != "+" || plus.children.size() != 2) {
+			return nullptr;
+		}
+		const bool forward = column_of(*plus.children[0], hop) && IntegerConstant(*plus.children[1], one);
+		const bool backward = !forward && column_of(*plus.children[1], hop) && IntegerConstant(*plus.children[0], one);
+		if ((!forward && !backward) || one != 1 || hop.table_index != in.cte->table_index || hop.column != hop_col) {
+			return nullptr;
+		}
+	}
+	// which group column is passed through (start) and which advances (friend)
+	idx_t start_col = INVALID_INDEX, friend_col = INVALID_INDEX;
+	for (int g = 0; g < 2; g++) {
+		PlanColumn passed;
+		if (column_of(*step.expressions[group_ref[g]], passed) && passed.table_index == in.cte->table_index &&
+		    passed.column == group_ref[g]) {
+			start_col = group_ref[g];
+			friend_col = group_ref[1 - g];
+		}
+	}
+	if (start_col == INVALID_INDEX) {
+		return nullptr;
+	}
+	// leaves: one edge scan, optionally one scan of the vertex table validating the new vertex
+	LogicalGet *edge_get = nullptr, *validate_get = nullptr;
+	for (auto get : in.scans) {
+		auto table = ((TableScanBindData &)*get->bind_data).table;
+		if (table == vertex_table && in.scans.size() == 2 && !validate_get) {
+			validate_get = get;
+		} else if (!edge_get) {
+			edge_get = get;
+		} else {
+			return nullptr;
+		}
+	}
+	if (!edge_get || (in.scans.size() == 2 && !validate_get)) {
+		return nullptr;
+	}
+	auto edge_table = ((TableScanBindData &)*edge_get->bind_data).table;
+	// equalities: f.friend = e.src  [and e.dst = p.key]
+	PlanColumn cte_friend;
+	cte_friend.table_index = in.cte->table_index;
+	cte_friend.column = friend_col;
+	column_t src = INVALID_INDEX, dst = INVALID_INDEX;
+	bool validated = false;
+	for (auto &eq : in.equalities) {
+		for (int flip = 0; flip < 2; flip++) {
+			auto &a = flip ? eq.second : eq.first;
+			auto &b = flip ? eq.first : eq.second;
+			if (a == cte_friend && b.table_index == edge_get->table_index && src == INVALID_INDEX) {
+				src = b.column;
+				goto next_equality;
+			}
+			if (validate_get && a.table_index == edge_get->table_index && b.table_index == validate_get->table_index &&
+			    b.column == vertex_key && !validated) {
+				dst = a.column;
+				validated = true;
+				goto next_equality;
+			}
+		}
+		return nullptr; // an equality that is not part of the pattern
+	next_equality:;
+	}
+	if (src == INVALID_INDEX || (validate_get != nullptr) != validated) {
+		return nullptr;
+	}
+	// the advancing column: e.dst, the validated p.key, or bi-10's CASE WHEN f.friend = e.src THEN e.dst ELSE e.src
+	{
+		auto &expr = *step.expressions[friend_col];
+		PlanColumn next;
+		if (column_of(expr, next)) {
+			if (validate_get && next.table_index == validate_get->table_index && next.column == vertex_key) {
+				// p.key == e.dst by the join
+			} else if (next.table_index == edge_get->table_index && (dst == INVALID_INDEX || dst == next.column)) {
+				dst = next.column;
+			} else {
+				return nullptr;
+			}
+		} else if (expr.GetExpressionClass() == ExpressionClass::BOUND_CASE) {
+			auto &bound_case = (BoundCaseExpression &)expr;
+			if (bound_case.check->type != ExpressionType::COMPARE_EQUAL) {
+				return nullptr;
+			}
+			auto &check = (BoundComparisonExpression &)*bound_case.check;
+			PlanColumn l, r, if_true, if_false;
+			if (!column_of(*check.left, l) || !column_of(*check.right, r) || !column_of(*bound_case.result_if_true, if_true) ||
+			    !column_of(*bound_case.result_if_false, if_false)) {
+				return nullptr;
+			}
+			PlanColumn edge_src;
+			edge_src.table_index = edge_get->table_index;
+			edge_src.column = src;
+			// the check repeats the join condition, so it always holds and the CASE is its THEN branch
+			// (RemoveUnusedColumns may already have rewritten e.src into the equal f.friend)
+			auto is_join_key = [&](const PlanColumn &c) { return c == cte_friend || c == edge_src; };
+			if (!is_join_key(l) || !is_join_key(r) || !is_join_key(if_false) ||
+			    if_true.table_index != edge_get->table_index || if_true.column == src ||
+			    (dst != INVALID_INDEX && dst != if_true.column)) {
+				return nullptr;
+			}
+			dst = if_true.column;
+		} else {
+			return nullptr;
+		}
+	}
+	if (dst == INVALID_INDEX || dst == src || src >= edge_table->columns.size() || dst >= edge_table->columns.size() ||
+	    !ColumnIsIntegerKey(*edge_table, src) || !ColumnIsIntegerKey(*edge_table, dst)) {
+		return nullptr;
+	}
+	if (validated) {
+		if (!ColumnIsUnique(*vertex_table, vertex_key)) {
+			return nullptr;
+		}
+	} else if (!ColumnIsNotNull(*edge_table, dst)) {
+		return nullptr; // a NULL destination would surface as a NULL friend on the CPU side
+	}
+	// ---- output layout of the aggregate: (group 0, group 1, min)
+	if (op.types.size() != 3 || op.types[2] != LogicalType::INTEGER) {
+		return nullptr;
+	}
+	vector<unique_ptr<Expression>> select_list;
+	for (int g = 0; g < 2; g++) {
+		// scan columns: (startPerson BIGINT, friend BIGINT, hopCount INTEGER)
+		unique_ptr<Expression> ref =
+		    make_unique<BoundReferenceExpression>(LogicalType::BIGINT, group_ref[g] == start_col ? 0 : 1);
+		if (op.types[g] != LogicalType::BIGINT) {
+			if (op.types[g] != LogicalType::INTEGER) {
+				return nullptr;
+			}
+			ref = make_unique<BoundCastExpression>(move(ref), op.types[g]);
+		}
+		select_list.push_back(move(ref));
+	}
+	select_list.push_back(make_unique<BoundReferenceExpression>(LogicalType::INTEGER, 2));
+
+	// ---- the scan
+	const string key_name = GGQuote(vertex_table->columns[vertex_key].name);
+	GGGraphSpec spec;
+	if (validated) {
+		spec.vertex_sql = "SELECT " + key_name + " FROM " + QualifiedName(*vertex_table);
+	}
+	spec.edge_sql = "SELECT " + GGQuote(edge_table->columns[src].name) + ", " + GGQuote(edge_table->columns[dst].name) +
+	                " FROM " + QualifiedName(*edge_table);
+	// the seeds are rows of the vertex table: constants that are nobody's key start nothing
+	string sources_sql = "SELECT " + key_name + " FROM " + QualifiedName(*vertex_table);
+	if (!all_vertices) {
+		string in_list = key_name + " IN (";
+		for (idx_t i = 0; i < seed_constants.size(); i++) {
+			in_list += (i ? ", " : "") + to_string(seed_constants[i]);
+		}
+		seed_predicates.push_back(in_list + ")");
+	}
+	for (idx_t i = 0; i < seed_predicates.size(); i++) {
+		sources_sql += (i ? " AND " : " WHERE ") + seed_predicates[i];
+	}
+	const int max_hops = (int)in.max_hops;
+	const bool lone_sources = !validated;
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = GGBuildGraph(context, spec);
+		auto sources = GGQueryInt64Column(context, sources_sql, "shortest path seed");
+		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), max_hops, 0, lone_sources);
+	};
+	data->description = edge_table->name + ": " + edge_table->columns[src].name + " -> " + edge_table->columns[dst].name +
+	                    "\nmin hops <= " + to_string(max_hops) + "\nvertices: " +
+	                    (validated ? vertex_table->name + "." + vertex_table->columns[vertex_key].name
+	                               : string("endpoint ids")) +
+	                    "\nfrom " +
+	                    (seed_predicates.empty() ? "every " + vertex_table->name
+	                     : all_vertices          ? vertex_table->name + " where " + seed_predicates[0]
+	                                             : to_string(seed_constants.size()) +
+	                                          (seed_constants.size() == 1 ? " id" : " ids"));
+	vector<LogicalType> types = {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER};
+	vector<column_t> column_ids = {0, 1, 2};
+	vector<string> names = {"startPerson", "friend", "hopCount"};
+	g_rules_fired++;
+	auto scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_shortest_path_bfs"), move(data),
+	                                           move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
+	projection->children.push_back(move(scan));
+	return move(projection);
+}
+
+unique_ptr<PhysicalOperator> PlanAggregate(LogicalAggregate &op) {
+	if (auto plan = PlanCountOverJoinChain(op)) {
+		return plan;
+	}
+	return PlanShortestPath(op);
+}
+
 template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
 int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 	if (!g_rules_enabled) {
@@ -670,7 +1280,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 		return;
 	}
 	reg(GG_PLAN_HOOK_JOIN, RuleEntry<LogicalComparisonJoin, PlanJoinChain>);
-	reg(GG_PLAN_HOOK_AGGREGATE, RuleEntry<LogicalAggregate, PlanCountOverJoinChain>);
+	reg(GG_PLAN_HOOK_AGGREGATE, RuleEntry<LogicalAggregate, PlanAggregate>);
 	auto env = std::getenv("GG_PLAN_RULE");
 	if (env && env[0] == '1') {
 		g_rules_enabled = true;

@@ -2,6 +2,7 @@
 operators next to its own CPU operators on the SAME tables in the SAME database; results must be equal
 as sorted relations.  Needs the prebuilt extension (built where /root/reference exists) and a GPU."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -201,3 +202,53 @@ def test_plan_rule_sees_table_changes_between_executions(db):
     assert int(d.execute(sql)[0, 0]) == 3
     d.execute("PRAGMA disable_gpu_graph")
     assert int(d.execute(sql)[0, 0]) == 3
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_plan_rule_friends_cte_gives_the_reference_result(db):
+    """bi-10's friends / friends_shortest (recursive CTE + min) with the rules off (PhysicalRecursiveCTE +
+    hash aggregate) and on (64-lane BFS): same relation."""
+    d, vid = db
+    d.execute("CREATE TABLE IF NOT EXISTS person_pk (p_personid BIGINT PRIMARY KEY)")
+    if int(d.execute("SELECT count(*) FROM person_pk")[0, 0]) == 0:
+        d.execute("INSERT INTO person_pk SELECT p_personid FROM person")
+
+    def both(sql):
+        d.execute("PRAGMA disable_gpu_graph")
+        assert "REC_CTE" in d.explain(sql)
+        cpu = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        assert "GG_SHORTEST_PATH_BFS" in d.explain(sql), d.explain(sql)
+        gpu = d.execute(sql)
+        d.execute("PRAGMA disable_gpu_graph")
+        return sort_rows(cpu), sort_rows(gpu)
+
+    s = int(vid[11])
+    # the literal text of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31 (edge-only step, CASE expression)
+    bi10 = f"""WITH RECURSIVE friends(startPerson, hopCount, friend) AS (
+        SELECT p_personid, 0, p_personid FROM person WHERE 1=1 AND p_personid = {s}
+      UNION
+        SELECT f.startPerson, f.hopCount+1,
+               CASE WHEN f.friend = k.k_person1id then k.k_person2id ELSE k.k_person1id END
+          FROM friends f, knows k WHERE 1=1 AND f.friend = k.k_person1id AND f.hopCount < 3)
+      , friends_shortest AS (
+        SELECT startPerson, min(hopCount) AS hopCount, friend FROM friends GROUP BY startPerson, friend)
+    SELECT startPerson, hopCount, friend FROM friends_shortest"""
+    cpu, gpu = both(bi10)
+    assert cpu.shape[0] > 100 and np.array_equal(cpu, gpu)
+    # dangling destination ids (-6 in the fixture) are reachable in the edge-only form; a seed without any
+    # edge still yields its own (s, 0, s) row
+    d.execute("CREATE TABLE loner (p_personid BIGINT NOT NULL)")
+    d.execute("INSERT INTO loner VALUES (987654321)")
+    cpu, gpu = both(bi10.replace("FROM person WHERE 1=1 AND p_personid = " + str(s), "FROM loner"))
+    assert cpu.tolist() == [[987654321, 0, 987654321]] and np.array_equal(cpu, gpu)
+
+    # the oracle's validated formulation, > 64 seeds (two bit-lane batches), then every person as a seed
+    sources = datagen.pick_sources(vid, 70, 5)
+    keyed = lambda q: re.sub(r"\bperson\b", "person_pk", q)
+    sql = keyed(R.sql_shortest(sources, 3))
+    cpu, gpu = both(sql)
+    assert np.array_equal(cpu, gpu) and not (cpu[:, 1] < 0).any()
+    every = keyed(R.sql_shortest([0], 2)).replace("WHERE p_personid IN (0)", "")
+    cpu, gpu = both(every)
+    assert cpu.shape[0] > vid.size and np.array_equal(cpu, gpu)

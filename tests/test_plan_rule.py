@@ -113,3 +113,58 @@ def test_sub_chain_of_a_larger_join_and_grouped_aggregate(db):
     plan = db.explain("SELECT count(*) FROM (SELECT k2.k_person2id AS f FROM knows k1, knows k2 "
                       "WHERE k1.k_person2id = k2.k_person1id) w, knows_nullable x WHERE x.a = w.f")
     assert "GG_PATH_EXPAND" in plan and plan.count("HASH_JOIN") == 1
+
+
+# ---- recursive CTE + min(hop)  ->  64-lane BFS --------------------------------------------------------
+def friends(seed_where="WHERE p_personid = 2", union="UNION", step_from="friends f, knows k",
+            step_where="f.friend = k.k_person1id AND f.hopCount < 5", nxt="k.k_person2id", inc="f.hopCount+1",
+            agg="min(hopCount)", vertex="person"):
+    return f"""WITH RECURSIVE friends(startPerson, hopCount, friend) AS (
+        SELECT p_personid, 0, p_personid FROM {vertex} {seed_where}
+      {union}
+        SELECT f.startPerson, {inc}, {nxt} FROM {step_from} WHERE {step_where})
+    SELECT startPerson, {agg} AS hopCount, friend FROM friends GROUP BY startPerson, friend"""
+
+
+BI10_CASE = "CASE WHEN f.friend = k.k_person1id then k.k_person2id ELSE k.k_person1id END"
+
+BFS_TAKEN = [
+    (friends(), "from 1 id"),
+    # the literal friends / friends_shortest text of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31
+    (friends(seed_where="WHERE 1=1 AND p_personid = 2", nxt=BI10_CASE,
+             step_where="1=1 AND f.friend = k.k_person1id AND f.hopCount < 5"), "vertices: endpoint ids"),
+    (friends(seed_where="WHERE p_personid IN (1, 3)"), "from 2 ids"),
+    (friends(seed_where="WHERE p_personid IN (" + ", ".join(str(i * 3 + 1) for i in range(40)) + ")"), "from 40 ids"),
+    (friends(seed_where="WHERE p_personid IN (1, 2)"), "from person where"),   # consecutive values: becomes a pushed-down range
+    (friends(seed_where=""), "from every person"),
+    (friends(step_where="f.friend = k.k_person1id AND f.hopCount <= 2"), "min hops <= 3"),
+    # the oracle's formulation: the new vertex validated against the vertex table
+    (R.sql_shortest([1, 2], 4), "vertices: person.p_personid"),
+]
+
+BFS_LEFT_ALONE = [
+    friends(union="UNION ALL"),                                   # bag semantics: not a fixpoint of sets
+    friends(step_where="f.friend = k.k_person1id"),               # no hop bound
+    friends(inc="f.hopCount+2"),
+    friends(agg="max(hopCount)"),
+    friends(nxt="k.k_person1id"),                                 # does not advance along the edge
+    friends(step_where="f.friend = k.k_person1id AND f.hopCount < 5 AND k.k_weight > 0"),
+    friends(step_from="friends f, knows_nullable k", step_where="f.friend = k.a AND f.hopCount < 5", nxt="k.b"),
+    friends(step_from="friends f, knows k, person_nokey p",
+            step_where="f.friend = k.k_person1id AND k.k_person2id = p.p_personid AND f.hopCount < 5"),
+]
+
+
+@pytest.mark.parametrize("sql,detail", BFS_TAKEN)
+def test_friends_cte_with_min_hop_becomes_bfs(db, sql, detail):
+    db.execute("PRAGMA enable_gpu_graph")
+    plan = db.explain(sql)
+    assert "GG_SHORTEST_PATH_BFS" in plan and "REC_CTE" not in plan and "HASH_GROUP_BY" not in plan, plan
+    assert detail in " ".join(plan.replace("│", " ").split()), plan
+
+
+@pytest.mark.parametrize("sql", BFS_LEFT_ALONE)
+def test_other_recursive_ctes_are_left_alone(db, sql):
+    db.execute("PRAGMA enable_gpu_graph")
+    plan = db.explain(sql)
+    assert "GG_" not in plan and "REC_CTE" in plan, plan
