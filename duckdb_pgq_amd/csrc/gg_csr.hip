@@ -39,6 +39,11 @@ __device__ __forceinline__ bool owns(int64_t id, uint32_t part, uint32_t n_parts
   return n_parts <= 1 || (uint32_t)((((((uint64_t)id * DIG_GOLD) >> 32)) * (uint64_t)n_parts) >> 32) == part;
 }
 
+__global__ __launch_bounds__(256) void k_rowid_iota(int64_t *__restrict__ out, int64_t first, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = first + (int64_t)i;
+}
+
 __global__ __launch_bounds__(256) void k_ht_init(HtSlot *__restrict__ ht, uint64_t cap) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cap) {
@@ -710,6 +715,11 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
             (const uint64_t *)kept_rev_dev, st);
   csr->has_rowid = !shard && ctx->keep_edge_rowid;
   if (ctx->rowid_explicit && E && csr->has_rowid) {
+    // rows staged without rowids never wrote the rowid column: their rowid is their position
+    GG_TRY(grow_column(ctx, ctx->c_rowid, ctx->c_rowid.cap < E ? ctx->c_rowid.cap : (size_t)E, (size_t)E));
+    for (auto &range : ctx->implicit_rowid_ranges)
+      GG_LAUNCH(ctx, "rowid_iota", k_rowid_iota, dim3((unsigned)((range.second + 255) / 256)), dim3(256), 0,
+                ctx->c_rowid.dev + range.first, (int64_t)range.first, range.second);
     GG_TRY(ctx->dev_alloc((void **)&csr->eid, E * sizeof(int64_t)));
     GG_LAUNCH(ctx, "gather_rowid", k_gather_rowid, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, csr->epos,
               ctx->c_rowid.dev, (const unsigned long long *)kept_dev, csr->eid);

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -69,17 +71,34 @@ struct gg_ctx {
   hipStream_t stream = nullptr;
   int num_cus = 256;
 
-  // ---- staging (guarded by mu) ----
+  // ---- staging (guarded by mu unless noted) ----
   std::mutex mu;
+  std::condition_variable cv;                    // an edge block became FREE
   gg::Column c_vid, c_src, c_dst, c_rowid;
-  uint64_t n_vertices = 0, n_edges = 0;          // rows resident or in flight to the device
+  uint64_t n_vertices = 0, n_edges = 0;          // rows resident, in flight to the device or reserved in a block
   bool rowid_explicit = false;                   // some append passed explicit rowids
+  // rows appended without rowids, as merged (first row, count) ranges: their rowid is their position and
+  // is only written (on the device, at build time) if some other append did pass rowids
+  std::vector<std::pair<uint64_t, uint64_t>> implicit_rowid_ranges;
   static constexpr size_t STAGE_ROWS = 1u << 20; // rows per pinned staging block
   int64_t *pin_v[2] = {nullptr, nullptr};        // vertex ids
-  int64_t *pin_e[2] = {nullptr, nullptr};        // edge block: [src | dst | rowid] each STAGE_ROWS
-  hipEvent_t pin_v_free[2] = {nullptr, nullptr}, pin_e_free[2] = {nullptr, nullptr};
-  int cur_v = 0, cur_e = 0;
-  size_t fill_v = 0, fill_e = 0;
+  hipEvent_t pin_v_free[2] = {nullptr, nullptr};
+  int cur_v = 0;
+  size_t fill_v = 0;
+  // Edge blocks: [src | dst | rowid], each STAGE_ROWS.  Appenders reserve a row range under mu and copy
+  // into the block OUTSIDE the lock (concurrent Sink calls overlap their memcpys); whoever reserves the
+  // last row closes the block, opens the other one for everybody else, waits for the block's other
+  // writers and sends it to the device.
+  struct EdgeBlock {
+    int64_t *pin = nullptr;
+    hipEvent_t free_ev = nullptr;  // recorded after the block's H2D copies
+    size_t fill = 0;               // rows reserved
+    uint64_t base = 0;             // position of the block's first row in the staged columns
+    std::atomic<int> writers{0};   // reservations whose memcpy has not finished (not guarded by mu)
+    bool has_rowid = false;        // some reservation in the block carries explicit rowids
+    enum State { OPEN, CLOSED, FREE } state = FREE;
+  } eblk[2];
+  int cur_e = 0;                                 // the OPEN block
 
   // ---- caching device allocator ----
   std::vector<gg::DevBlock> blocks;

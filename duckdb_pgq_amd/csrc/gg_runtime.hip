@@ -2,6 +2,9 @@
 // HIP for gfx950; host side of the C-ABI declared in include/gg.h.
 #include "gg_internal.h"
 
+#include <atomic>
+#include <thread>
+
 namespace gg {
 
 static thread_local char g_err[512] = "";
@@ -199,10 +202,11 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   GG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) {
     GG_HIP(hipHostMalloc((void **)&ctx->pin_v[i], gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
-    GG_HIP(hipHostMalloc((void **)&ctx->pin_e[i], 3 * gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
+    GG_HIP(hipHostMalloc((void **)&ctx->eblk[i].pin, 3 * gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
     GG_HIP(hipEventCreateWithFlags(&ctx->pin_v_free[i], hipEventDisableTiming));
-    GG_HIP(hipEventCreateWithFlags(&ctx->pin_e_free[i], hipEventDisableTiming));
+    GG_HIP(hipEventCreateWithFlags(&ctx->eblk[i].free_ev, hipEventDisableTiming));
   }
+  ctx->eblk[0].state = gg_ctx::EdgeBlock::OPEN;
   GG_HIP(hipHostMalloc((void **)&ctx->pin_scratch, 64 * sizeof(uint64_t), hipHostMallocDefault));
   *out = ctx;
   return GG_OK;
@@ -217,9 +221,9 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
     if (b.ptr) (void)hipFree(b.ptr);
   for (int i = 0; i < 2; i++) {
     if (ctx->pin_v[i]) (void)hipHostFree(ctx->pin_v[i]);
-    if (ctx->pin_e[i]) (void)hipHostFree(ctx->pin_e[i]);
+    if (ctx->eblk[i].pin) (void)hipHostFree(ctx->eblk[i].pin);
     if (ctx->pin_v_free[i]) (void)hipEventDestroy(ctx->pin_v_free[i]);
-    if (ctx->pin_e_free[i]) (void)hipEventDestroy(ctx->pin_e_free[i]);
+    if (ctx->eblk[i].free_ev) (void)hipEventDestroy(ctx->eblk[i].free_ev);
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
   // staged columns are plain hipMalloc (they grow by doubling, outside the block cache)
@@ -268,23 +272,36 @@ static int flush_vertices(gg_ctx *ctx) {
   return GG_OK;
 }
 
-static int flush_edges(gg_ctx *ctx) {
-  if (ctx->fill_e == 0) return GG_OK;
-  size_t live = ctx->n_edges - ctx->fill_e;
-  GG_TRY(grow_column(ctx, ctx->c_src, live, ctx->n_edges));
-  GG_TRY(grow_column(ctx, ctx->c_dst, live, ctx->n_edges));
-  GG_TRY(grow_column(ctx, ctx->c_rowid, live, ctx->n_edges));
-  int b = ctx->cur_e;
+// send the reserved rows of an edge block to the device; caller holds mu and the block has no writer left.
+// Blocks are flushed in the order they were opened, so b.base rows are already resident.
+static int flush_edge_block(gg_ctx *ctx, gg_ctx::EdgeBlock &b) {
+  if (b.fill == 0) return GG_OK;
+  const size_t live = (size_t)b.base, need = live + b.fill;
+  GG_TRY(grow_column(ctx, ctx->c_src, live, need));
+  GG_TRY(grow_column(ctx, ctx->c_dst, live, need));
   const size_t S = gg_ctx::STAGE_ROWS;
-  size_t bytes = ctx->fill_e * sizeof(int64_t);
-  GG_HIP(hipMemcpyAsync(ctx->c_src.dev + live, ctx->pin_e[b], bytes, hipMemcpyHostToDevice, ctx->stream));
-  GG_HIP(hipMemcpyAsync(ctx->c_dst.dev + live, ctx->pin_e[b] + S, bytes, hipMemcpyHostToDevice, ctx->stream));
-  GG_HIP(hipMemcpyAsync(ctx->c_rowid.dev + live, ctx->pin_e[b] + 2 * S, bytes, hipMemcpyHostToDevice, ctx->stream));
-  GG_HIP(hipEventRecord(ctx->pin_e_free[b], ctx->stream));
-  ctx->cur_e ^= 1;
-  ctx->fill_e = 0;
-  GG_HIP(hipEventSynchronize(ctx->pin_e_free[ctx->cur_e]));
+  const size_t bytes = b.fill * sizeof(int64_t);
+  GG_HIP(hipMemcpyAsync(ctx->c_src.dev + live, b.pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+  GG_HIP(hipMemcpyAsync(ctx->c_dst.dev + live, b.pin + S, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (b.has_rowid) {  // rows without explicit rowids are filled in on the device if ever needed
+    GG_TRY(grow_column(ctx, ctx->c_rowid, live, need));
+    GG_HIP(hipMemcpyAsync(ctx->c_rowid.dev + live, b.pin + 2 * S, bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  GG_HIP(hipEventRecord(b.free_ev, ctx->stream));
   return GG_OK;
+}
+
+static void reset_edge_blocks(gg_ctx *ctx) {
+  for (auto &b : ctx->eblk) {
+    b.fill = 0;
+    b.base = 0;
+    b.has_rowid = false;
+    b.state = gg_ctx::EdgeBlock::FREE;
+  }
+  ctx->cur_e = 0;
+  ctx->eblk[0].state = gg_ctx::EdgeBlock::OPEN;
+  ctx->implicit_rowid_ranges.clear();
+  ctx->rowid_explicit = false;
 }
 
 extern "C" int gg_vertices_append(gg_ctx *ctx, const int64_t *id, uint64_t n) {
@@ -311,34 +328,70 @@ extern "C" int gg_vertices_append(gg_ctx *ctx, const int64_t *id, uint64_t n) {
 extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *dst, const int64_t *rowid,
                                uint64_t n) {
   if (!ctx || ((!src || !dst) && n)) return GG_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  GG_HIP(hipSetDevice(ctx->device));
-  if (ctx->n_edges + n >= (uint64_t)INVALID_U32) {
-    set_error("edge table larger than 2^32-2 rows is not supported");
-    return GG_ERR_TOO_LARGE;
-  }
   const size_t S = gg_ctx::STAGE_ROWS;
   while (n) {
-    size_t room = S - ctx->fill_e;
-    size_t take = n < room ? (size_t)n : room;
-    int64_t *blk = ctx->pin_e[ctx->cur_e];
-    memcpy(blk + ctx->fill_e, src, take * sizeof(int64_t));
-    memcpy(blk + S + ctx->fill_e, dst, take * sizeof(int64_t));
-    if (rowid) {
-      memcpy(blk + 2 * S + ctx->fill_e, rowid, take * sizeof(int64_t));
-      rowid += take;
-      ctx->rowid_explicit = true;
-    } else {
-      int64_t base = (int64_t)ctx->n_edges;
-      int64_t *r = blk + 2 * S + ctx->fill_e;
-      for (size_t i = 0; i < take; i++) r[i] = base + (int64_t)i;
+    // ---- reserve rows in the open block (short critical section)
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (ctx->n_edges + n >= (uint64_t)INVALID_U32) {
+      set_error("edge table larger than 2^32-2 rows is not supported");
+      return GG_ERR_TOO_LARGE;
     }
-    ctx->fill_e += take;
+    gg_ctx::EdgeBlock &b = ctx->eblk[ctx->cur_e];
+    const size_t room = S - b.fill;
+    const size_t take = n < room ? (size_t)n : room;
+    const size_t off = b.fill;
+    if (off == 0) b.base = ctx->n_edges;
+    const uint64_t first_row = b.base + off;
+    b.fill += take;
     ctx->n_edges += take;
+    b.writers.fetch_add(1, std::memory_order_relaxed);
+    if (rowid) {
+      b.has_rowid = true;
+      ctx->rowid_explicit = true;
+    } else if (!ctx->implicit_rowid_ranges.empty() &&
+               ctx->implicit_rowid_ranges.back().first + ctx->implicit_rowid_ranges.back().second == first_row) {
+      ctx->implicit_rowid_ranges.back().second += take;
+    } else {
+      ctx->implicit_rowid_ranges.emplace_back(first_row, (uint64_t)take);
+    }
+    const bool closer = b.fill == S;
+    if (closer) {
+      // the block is full: open the other one for everybody else.  It must have been flushed (FREE) and
+      // its copies must have left the pinned memory.
+      gg_ctx::EdgeBlock &o = ctx->eblk[ctx->cur_e ^ 1];
+      ctx->cv.wait(lk, [&] { return o.state == gg_ctx::EdgeBlock::FREE; });
+      if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(o.free_ev) != hipSuccess) {
+        b.writers.fetch_sub(1, std::memory_order_release);
+        set_error("HIP error while waiting for a staging block");
+        return GG_ERR_HIP;
+      }
+      o.fill = 0;
+      o.has_rowid = false;
+      o.state = gg_ctx::EdgeBlock::OPEN;
+      b.state = gg_ctx::EdgeBlock::CLOSED;
+      ctx->cur_e ^= 1;
+    }
+    lk.unlock();
+    // ---- copy outside the lock: concurrent Sink calls overlap here
+    memcpy(b.pin + off, src, take * sizeof(int64_t));
+    memcpy(b.pin + S + off, dst, take * sizeof(int64_t));
+    if (rowid) {
+      memcpy(b.pin + 2 * S + off, rowid, take * sizeof(int64_t));
+      rowid += take;
+    }
+    b.writers.fetch_sub(1, std::memory_order_release);
     src += take;
     dst += take;
     n -= take;
-    if (ctx->fill_e == S) GG_TRY(flush_edges(ctx));
+    if (closer) {
+      while (b.writers.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+      lk.lock();
+      int rc = hipSetDevice(ctx->device) == hipSuccess ? flush_edge_block(ctx, b) : GG_ERR_HIP;
+      b.state = gg_ctx::EdgeBlock::FREE;  // also on error: nobody may wait for this block forever
+      lk.unlock();
+      ctx->cv.notify_all();
+      if (rc != GG_OK) return rc;
+    }
   }
   return GG_OK;
 }
@@ -348,8 +401,14 @@ extern "C" int gg_staging_sync(gg_ctx *ctx) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   GG_HIP(hipSetDevice(ctx->device));
   GG_TRY(flush_vertices(ctx));
-  GG_TRY(flush_edges(ctx));
+  // the open block, partially filled (appends running concurrently with a sync are outside the contract,
+  // but never leave a half-copied reservation behind)
+  gg_ctx::EdgeBlock &b = ctx->eblk[ctx->cur_e];
+  while (b.writers.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  GG_TRY(flush_edge_block(ctx, b));
   GG_HIP(hipStreamSynchronize(ctx->stream));
+  b.fill = 0;  // the pinned memory is free again; the block stays open
+  b.has_rowid = false;
   return GG_OK;
 }
 
@@ -367,8 +426,8 @@ extern "C" int gg_staging_clear(gg_ctx *ctx) {
   GG_HIP(hipSetDevice(ctx->device));
   GG_HIP(hipStreamSynchronize(ctx->stream));
   ctx->n_vertices = ctx->n_edges = 0;
-  ctx->fill_v = ctx->fill_e = 0;
-  ctx->rowid_explicit = false;
+  ctx->fill_v = 0;
+  reset_edge_blocks(ctx);
   return GG_OK;
 }
 
@@ -378,8 +437,7 @@ extern "C" int gg_staging_clear_edges(gg_ctx *ctx) {
   GG_HIP(hipSetDevice(ctx->device));
   GG_HIP(hipStreamSynchronize(ctx->stream));
   ctx->n_edges = 0;
-  ctx->fill_e = 0;
-  ctx->rowid_explicit = false;
+  reset_edge_blocks(ctx);
   return GG_OK;
 }
 

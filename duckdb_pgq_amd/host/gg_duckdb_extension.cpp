@@ -28,21 +28,11 @@
 #include "duckdb/function/table_function.hpp"
 #include "duckdb/main/client_context.hpp"
 #include "duckdb/main/connection.hpp"
-#include "duckdb/parallel/event.hpp"
-#include "duckdb/parallel/pipeline.hpp"
 #include "duckdb/parallel/thread_context.hpp"
 #include "duckdb/parser/parsed_data/create_table_function_info.hpp"
 #include "gg_extension.hpp"
 
 namespace duckdb {
-
-class GGNoopEvent : public Event {
-public:
-	explicit GGNoopEvent(Executor &executor) : Event(executor) {
-	}
-	void Schedule() override {
-	}
-};
 
 string GGQuote(const string &ident) {
 	string out = "\"";
@@ -56,51 +46,37 @@ string GGQuote(const string &ident) {
 	return out + "\"";
 }
 
-//! Run `sql` on a side connection and push its chunks through `sink` the way a pipeline would.
-static void RunSinkPipeline(ClientContext &context, const string &sql, PhysicalOperator &sink) {
-	Connection con(*context.db);
-	auto result = con.SendQuery(sql);
-	if (!result->success) {
-		throw BinderException("gg: scanning the base table failed: " + result->error);
-	}
-	ThreadContext thread(context);
-	ExecutionContext ec(context, thread);
-	sink.sink_state = sink.GetGlobalSinkState(context);
-	auto lstate = sink.GetLocalSinkState(ec);
-	while (true) {
-		auto chunk = result->Fetch();
-		if (!chunk || chunk->size() == 0) {
-			break;
-		}
-		sink.Sink(ec, *sink.sink_state, *lstate, *chunk);
-	}
-	sink.Combine(ec, *sink.sink_state, *lstate);
-	Pipeline pipeline(context.executor);
-	GGNoopEvent event(context.executor);
-	sink.Finalize(pipeline, event, context, *sink.sink_state);
-}
-
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec) {
 	auto graph = make_shared<GGGraph>(0);
-	const bool derive = spec.vertex_sql.empty();
+	const bool derive = spec.vertices.Empty();
 	if (!derive) {
 		PhysicalGGVertexSink vsink(graph, {LogicalType::BIGINT}, 0);
-		RunSinkPipeline(context, spec.vertex_sql, vsink);
+		GGRunSinkPipeline(context, spec.vertices, vsink);
 	}
-	// the sink takes (src, dst[, rowid]); rowid comes out of the scan as a sequence vector
-	// (row_group.cpp:335) and is Orrified there
-	PhysicalGGEdgeSink esink(graph, {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::BIGINT}, 0, false, derive);
-	RunSinkPipeline(context, spec.edge_sql, esink);
+	PhysicalGGEdgeSink esink(graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, false, derive);
+	GGRunSinkPipeline(context, spec.edges, esink);
 	return graph;
 }
 
-static GGGraphSpec GraphSpecFromArguments(vector<Value> &inputs) {
-	const string vt = inputs[0].ToString(), vk = inputs[1].ToString(), et = inputs[2].ToString(),
-	             es = inputs[3].ToString(), ed = inputs[4].ToString();
-	GGGraphSpec spec;
-	spec.vertex_sql = "SELECT " + GGQuote(vk) + " FROM " + GGQuote(vt);
-	spec.edge_sql = "SELECT " + GGQuote(es) + ", " + GGQuote(ed) + ", rowid FROM " + GGQuote(et);
-	return spec;
+//! (vertex_table, vertex_key, edge_table, src_col, dst_col) arguments -> scans, resolved at execution time
+struct GraphArguments {
+	string vertex_table, vertex_key, edge_table, edge_src, edge_dst;
+	explicit GraphArguments(vector<Value> &inputs)
+	    : vertex_table(inputs[0].ToString()), vertex_key(inputs[1].ToString()), edge_table(inputs[2].ToString()),
+	      edge_src(inputs[3].ToString()), edge_dst(inputs[4].ToString()) {
+	}
+	GGGraphSpec Resolve(ClientContext &context) const {
+		GGGraphSpec spec;
+		spec.vertices = GGTableSource(context, vertex_table, {vertex_key}, false);
+		spec.edges = GGTableSource(context, edge_table, {edge_src, edge_dst}, false);
+		return spec;
+	}
+};
+
+static GGScanSource Statement(const string &sql) {
+	GGScanSource source;
+	source.sql = sql;
+	return source;
 }
 
 struct GGOperatorData : public FunctionOperatorData {
@@ -163,19 +139,18 @@ static unique_ptr<FunctionData> FilteredPathsBind(ClientContext &context, vector
 		throw BinderException("gg_same_neighbour_paths: need 1 <= hops <= " + to_string(GG_MAX_HOPS - 1));
 	}
 	const string vertices_sql = inputs[0].ToString(), sources_sql = inputs[1].ToString();
-	const string path_sql = "SELECT " + GGQuote(inputs[3].ToString()) + ", " + GGQuote(inputs[4].ToString()) +
-	                        " FROM " + GGQuote(inputs[2].ToString());
-	const string filter_sql = "SELECT " + GGQuote(inputs[6].ToString()) + ", " + GGQuote(inputs[7].ToString()) +
-	                          " FROM " + GGQuote(inputs[5].ToString());
+	const string path_table = inputs[2].ToString(), path_src = inputs[3].ToString(), path_dst = inputs[4].ToString();
+	const string filter_table = inputs[5].ToString(), filter_src = inputs[6].ToString(),
+	             filter_dst = inputs[7].ToString();
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &ctx, GGOpened &opened) {
 		opened.graph = make_shared<GGGraph>(0);
 		PhysicalGGVertexSink vsink(opened.graph, {LogicalType::BIGINT}, 0);
-		RunSinkPipeline(ctx, vertices_sql, vsink);
+		GGRunSinkPipeline(ctx, Statement(vertices_sql), vsink);
 		PhysicalGGEdgeSink psink(opened.graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0);
-		RunSinkPipeline(ctx, path_sql, psink);
+		GGRunSinkPipeline(ctx, GGTableSource(ctx, path_table, {path_src, path_dst}, false), psink);
 		PhysicalGGEdgeSink fsink(opened.graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, true);
-		RunSinkPipeline(ctx, filter_sql, fsink);
+		GGRunSinkPipeline(ctx, GGTableSource(ctx, filter_table, {filter_src, filter_dst}, false), fsink);
 		auto sources = GGQueryInt64Column(ctx, sources_sql, "gg_same_neighbour_paths: sources");
 		opened.source = make_unique<PhysicalGGFilteredPaths>(opened.graph, (int)hops, move(sources), 0);
 	};
@@ -198,10 +173,10 @@ static unique_ptr<FunctionData> KhopBindInternal(ClientContext &context, vector<
                                                  bool count_only) {
 	const auto k_min = inputs[5].GetValue<int64_t>(), k_max = inputs[6].GetValue<int64_t>();
 	CheckHops(k_min, k_max);
-	const auto spec = GraphSpecFromArguments(inputs);
+	const GraphArguments graph(inputs);
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &ctx, GGOpened &opened) {
-		opened.graph = GGBuildGraph(ctx, spec);
+		opened.graph = GGBuildGraph(ctx, graph.Resolve(ctx));
 		opened.source = make_unique<PhysicalGGPathExpand>(opened.graph, (int)k_min, (int)k_max, count_only,
 		                                                  vector<int64_t>(), true, 0);
 	};
@@ -239,12 +214,12 @@ static unique_ptr<FunctionData> ShortestBind(ClientContext &context, vector<Valu
                                              vector<LogicalType> &input_table_types,
                                              vector<string> &input_table_names, vector<LogicalType> &return_types,
                                              vector<string> &names) {
-	const auto spec = GraphSpecFromArguments(inputs);
+	const GraphArguments graph(inputs);
 	const string sources_sql = inputs[5].ToString();
 	const auto max_hops = inputs[6].GetValue<int64_t>();
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &ctx, GGOpened &opened) {
-		opened.graph = GGBuildGraph(ctx, spec);
+		opened.graph = GGBuildGraph(ctx, graph.Resolve(ctx));
 		auto sources = GGQueryInt64Column(ctx, sources_sql, "gg_shortest_path: sources");
 		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), (int)max_hops, 0);
 	};

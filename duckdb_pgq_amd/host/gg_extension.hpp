@@ -29,11 +29,33 @@ struct GGFunctionData : public TableFunctionData {
 TableFunction GGScanFunction(const string &name, vector<LogicalType> arguments = {},
                              table_function_bind_t bind = nullptr);
 
-//! The base-table scans a graph is built from (SQL run on a side connection, one chunk per Sink call).
-struct GGGraphSpec {
-	string vertex_sql; // SELECT key FROM vertex table; empty: vertex set = distinct endpoint ids of the edges
-	string edge_sql;   // SELECT src, dst[, rowid] FROM edge table
+class TableCatalogEntry;
+
+//! One base-table scan feeding a sink: either the table's storage read directly — row-group morsels on the
+//! reference's worker threads, in the query's own transaction (gg_ingest.cpp) — or, for anything that is
+//! not a plain table (views, arbitrary SQL), a statement run on a side connection.
+struct GGScanSource {
+	TableCatalogEntry *table = nullptr;
+	vector<column_t> columns; // table column ids (COLUMN_IDENTIFIER_ROW_ID allowed)
+	string sql;               // used when table is null
+	bool Empty() const {
+		return !table && sql.empty();
+	}
 };
+
+//! The scans a graph is built from.
+struct GGGraphSpec {
+	GGScanSource vertices; // key column; empty: vertex set = distinct endpoint ids of the edges
+	GGScanSource edges;    // (src, dst[, rowid])
+};
+
+//! Push every row of `source` through `sink` the way a pipeline would: GetGlobalSinkState, Sink per
+//! <=1024-row chunk (concurrently for table sources), Combine, Finalize.
+void GGRunSinkPipeline(ClientContext &context, const GGScanSource &source, PhysicalOperator &sink);
+
+//! (schema.)table resolved in the catalog, or a SQL fallback `SELECT columns FROM name` for views
+GGScanSource GGTableSource(ClientContext &context, const string &table_name, const vector<string> &columns,
+                           bool with_rowid);
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec);
 
 //! first column of `sql` (run on a side connection) as int64, NULLs skipped

@@ -19,6 +19,9 @@ void GGGraph::Check(int rc, const char *what) {
 
 GGGraph::GGGraph(int device) {
 	Check(gg_ctx_create(device, &ctx), "gg_ctx_create");
+	// none of the operators below returns edge ids: build without the edge-rowid payload, as the
+	// reference's hash-join build side carries only the columns the query references
+	Check(gg_ctx_set_edge_rowid(ctx, 0), "gg_ctx_set_edge_rowid");
 }
 
 GGGraph::~GGGraph() {
@@ -87,6 +90,28 @@ idx_t GGExtractKeys(DataChunk &input, const vector<idx_t> &cols, vector<vector<i
 	return kept;
 }
 
+idx_t GGKeyColumns(DataChunk &input, const vector<idx_t> &cols, vector<vector<int64_t>> &scratch,
+                   vector<const int64_t *> &keys) {
+	keys.resize(cols.size());
+	bool direct = true;
+	for (idx_t c = 0; c < cols.size() && direct; c++) {
+		auto &vec = input.data[cols[c]];
+		direct = vec.GetVectorType() == VectorType::FLAT_VECTOR && vec.GetType().InternalType() == PhysicalType::INT64 &&
+		         FlatVector::Validity(vec).AllValid();
+	}
+	if (direct) {
+		for (idx_t c = 0; c < cols.size(); c++) {
+			keys[c] = FlatVector::GetData<int64_t>(input.data[cols[c]]);
+		}
+		return input.size();
+	}
+	const idx_t kept = GGExtractKeys(input, cols, scratch);
+	for (idx_t c = 0; c < cols.size(); c++) {
+		keys[c] = scratch[c].data();
+	}
+	return kept;
+}
+
 //===--------------------------------------------------------------------===//
 // Sinks
 //===--------------------------------------------------------------------===//
@@ -98,6 +123,7 @@ public:
 class GGSinkLocalState : public LocalSinkState {
 public:
 	vector<vector<int64_t>> columns; // per-thread conversion buffers, reused across chunks
+	vector<const int64_t *> keys;    // what is handed to gg_*_append: the chunk's own vectors or `columns`
 };
 
 PhysicalGGVertexSink::PhysicalGGVertexSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
@@ -118,9 +144,9 @@ SinkResultType PhysicalGGVertexSink::Sink(ExecutionContext &context, GlobalSinkS
                                           LocalSinkState &lstate_p, DataChunk &input) const {
 	auto &gstate = (GGSinkGlobalState &)gstate_p;
 	auto &lstate = (GGSinkLocalState &)lstate_p;
-	idx_t n = GGExtractKeys(input, {0}, lstate.columns);
+	idx_t n = GGKeyColumns(input, {0}, lstate.columns, lstate.keys);
 	// thread-safe append (gg.h): one call per DataChunk, like JoinHashTable::Build per Sink call
-	GGGraph::Check(gg_vertices_append(graph->ctx, lstate.columns[0].data(), n), "gg_vertices_append");
+	GGGraph::Check(gg_vertices_append(graph->ctx, lstate.keys[0], n), "gg_vertices_append");
 	gstate.rows += n;
 	return SinkResultType::NEED_MORE_INPUT;
 }
@@ -159,9 +185,9 @@ SinkResultType PhysicalGGEdgeSink::Sink(ExecutionContext &context, GlobalSinkSta
 	auto &gstate = (GGSinkGlobalState &)gstate_p;
 	auto &lstate = (GGSinkLocalState &)lstate_p;
 	const bool has_rowid = input.ColumnCount() >= 3;
-	idx_t n = has_rowid ? GGExtractKeys(input, {0, 1, 2}, lstate.columns) : GGExtractKeys(input, {0, 1}, lstate.columns);
-	GGGraph::Check(gg_edges_append(graph->ctx, lstate.columns[0].data(), lstate.columns[1].data(),
-	                               has_rowid ? lstate.columns[2].data() : nullptr, n),
+	idx_t n = has_rowid ? GGKeyColumns(input, {0, 1, 2}, lstate.columns, lstate.keys)
+	                    : GGKeyColumns(input, {0, 1}, lstate.columns, lstate.keys);
+	GGGraph::Check(gg_edges_append(graph->ctx, lstate.keys[0], lstate.keys[1], has_rowid ? lstate.keys[2] : nullptr, n),
 	               "gg_edges_append");
 	gstate.rows += n;
 	return SinkResultType::NEED_MORE_INPUT;

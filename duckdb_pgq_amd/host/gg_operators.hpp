@@ -45,6 +45,11 @@ struct GGGraph {
 //! type via Orrify); rows whose key is NULL in ANY of the given columns are skipped, as
 //! JoinHashTable::PrepareKeys does for join keys (src/execution/join_hashtable.cpp:126-148).
 idx_t GGExtractKeys(DataChunk &input, const vector<idx_t> &cols, vector<vector<int64_t>> &out);
+//! Same, without the copy where possible: if every requested column is a flat, all-valid BIGINT vector
+//! (what DataTable::Scan produces for NOT NULL BIGINT columns) `keys[c]` points into the chunk itself,
+//! otherwise into `scratch` filled by GGExtractKeys.  Returns the number of rows behind each pointer.
+idx_t GGKeyColumns(DataChunk &input, const vector<idx_t> &cols, vector<vector<int64_t>> &scratch,
+                   vector<const int64_t *> &keys);
 
 class PhysicalGGVertexSink : public PhysicalOperator {
 public:

@@ -567,15 +567,22 @@ string QualifiedName(TableCatalogEntry &table) {
 	return GGQuote(table.schema->name) + "." + GGQuote(table.name);
 }
 
+thread_local extern vector<CatalogEntry *> g_plan_tables;
+
+GGScanSource TableColumns(TableCatalogEntry *table, vector<column_t> columns) {
+	g_plan_tables.push_back(table);
+	GGScanSource source;
+	source.table = table;
+	source.columns = move(columns);
+	return source;
+}
+
 GGGraphSpec GraphSpecOf(const WalkPattern &pattern) {
 	GGGraphSpec spec;
 	if (pattern.vertex_table) {
-		spec.vertex_sql = "SELECT " + GGQuote(pattern.vertex_table->columns[pattern.vertex_key].name) + " FROM " +
-		                  QualifiedName(*pattern.vertex_table);
+		spec.vertices = TableColumns(pattern.vertex_table, {pattern.vertex_key});
 	}
-	spec.edge_sql = "SELECT " + GGQuote(pattern.edge_table->columns[pattern.src_column].name) + ", " +
-	                GGQuote(pattern.edge_table->columns[pattern.dst_column].name) + " FROM " +
-	                QualifiedName(*pattern.edge_table);
+	spec.edges = TableColumns(pattern.edge_table, {pattern.src_column, pattern.dst_column});
 	return spec;
 }
 
@@ -1188,10 +1195,10 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	const string key_name = GGQuote(vertex_table->columns[vertex_key].name);
 	GGGraphSpec spec;
 	if (validated) {
-		spec.vertex_sql = "SELECT " + key_name + " FROM " + QualifiedName(*vertex_table);
+		spec.vertices = TableColumns(vertex_table, {vertex_key});
 	}
-	spec.edge_sql = "SELECT " + GGQuote(edge_table->columns[src].name) + ", " + GGQuote(edge_table->columns[dst].name) +
-	                " FROM " + QualifiedName(*edge_table);
+	spec.edges = TableColumns(edge_table, {src, dst});
+	g_plan_tables.push_back(vertex_table); // the seed rows are read from it by key
 	// the seeds are rows of the vertex table: constants that are nobody's key start nothing
 	string sources_sql = "SELECT " + key_name + " FROM " + QualifiedName(*vertex_table);
 	if (!all_vertices) {
@@ -1239,12 +1246,17 @@ unique_ptr<PhysicalOperator> PlanAggregate(LogicalAggregate &op) {
 	return PlanShortestPath(op);
 }
 
+//! tables the substituted plan reads, registered with the generator like LogicalGet's dependency
+//! callback does (plan_get.cpp:50-52), so a prepared statement notices when one of them is dropped
+thread_local vector<CatalogEntry *> g_plan_tables;
+
 template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
 int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 	if (!g_rules_enabled) {
 		return 0;
 	}
 	unique_ptr<PhysicalOperator> plan;
+	g_plan_tables.clear();
 	try {
 		plan = RULE(*(OP *)logical_operator);
 	} catch (std::exception &) {
@@ -1252,6 +1264,9 @@ int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 	}
 	if (!plan) {
 		return 0;
+	}
+	for (auto table : g_plan_tables) {
+		((PhysicalPlanGenerator *)generator)->dependencies.insert(table);
 	}
 	new (ret_slot) unique_ptr<PhysicalOperator>(move(plan));
 	return 1;
