@@ -222,13 +222,47 @@ __global__ __launch_bounds__(256) void k_bfs_widen(const DistT *__restrict__ dis
   }
 }
 
+// reached (lane, vertex) cells per vertex: count, then (after an exclusive scan) fill
+// (source id, vertex id, distance) rows.  One thread per vertex reads its 64 cells (one 64/128-byte line).
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_pairs_count(const DistT *__restrict__ dist, uint64_t V, int n_src,
+                                                         uint32_t *__restrict__ counts) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  uint32_t c = 0;
+  for (int s = 0; s < n_src; s++) c += dist[v * 64 + s] != (DistT)~(DistT)0;
+  counts[v] = c;
+}
+
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_pairs_fill(const DistT *__restrict__ dist, uint64_t V, int n_src,
+                                                        const uint32_t *__restrict__ offsets,
+                                                        const int64_t *__restrict__ src_ids,
+                                                        const int64_t *__restrict__ vid, int64_t *__restrict__ out_src,
+                                                        int64_t *__restrict__ out_vtx, int64_t *__restrict__ out_dist) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  uint64_t pos = offsets[v];
+  const int64_t id = vid[v];
+  for (int s = 0; s < n_src; s++) {
+    const DistT d = dist[v * 64 + s];
+    if (d != (DistT)~(DistT)0) {
+      out_src[pos] = src_ids[s];
+      out_vtx[pos] = id;
+      out_dist[pos] = (int64_t)d;
+      pos++;
+    }
+  }
+}
+
 }  // namespace gg
 
 // One BFS with DistT distance cells.  *overflow is set (and nothing is returned) if the frontier is
 // still non-empty at the deepest level DistT can record.
 template <typename DistT>
 static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops, const int64_t *dst_ids,
-                   uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats, bool *overflow) {
+                   uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats, bool *overflow,
+                   gg_result *pairs = nullptr /* filled with (source, vertex, distance) rows if non-null */) {
   constexpr int MAX_LEVEL = sizeof(DistT) == 1 ? 254 : 65534;
   *overflow = false;
   GG_HIP(hipSetDevice(ctx->device));
@@ -317,6 +351,30 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   st.reached_pairs = reached;
 
   int rc = GG_OK;
+  if (pairs && !*overflow && reached) {
+    if (reached >= (uint64_t)INVALID_U32) {
+      set_error("gg_bfs64_pairs: more than 2^32-2 reached pairs in one batch");
+      rc = GG_ERR_TOO_LARGE;
+    }
+    uint32_t *counts = nullptr;
+    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&counts, V * sizeof(uint32_t));
+    for (int c = 0; c < 3 && rc == GG_OK; c++) rc = ctx->dev_alloc((void **)&pairs->cols[2][c], reached * sizeof(int64_t));
+    if (rc == GG_OK) {
+      hipLaunchKernelGGL((k_bfs_pairs_count<DistT>), dim3(vgrid), dim3(256), 0, s, (const DistT *)dist8, V, n_src, counts);
+      rc = scan_exclusive_u32(ctx, counts, counts, V, nullptr);
+    }
+    if (rc == GG_OK) {
+      hipLaunchKernelGGL((k_bfs_pairs_fill<DistT>), dim3(vgrid), dim3(256), 0, s, (const DistT *)dist8, V, n_src,
+                         (const uint32_t *)counts, (const int64_t *)ids_dev, (const int64_t *)csr->vid,
+                         pairs->cols[2][0], pairs->cols[2][1], pairs->cols[2][2]);
+      if (hipGetLastError() != hipSuccess) rc = GG_ERR_HIP;
+    }
+    if (rc == GG_OK) {
+      for (int c = 0; c < 3; c++) ctx->keep(pairs->cols[2][c]);
+      pairs->rows[2] = reached;
+    }
+    ctx->dev_free(counts);
+  }
   if (out_dist && !*overflow) {
     int64_t *dst_dev = nullptr;
     uint32_t *dst_dense = nullptr;
@@ -360,8 +418,35 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   return rc;
 }
 
+static int bfs_dispatch(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, int n_src, int max_hops,
+                        const int64_t *dst_ids, uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats,
+                        gg_result *pairs);
+
 extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, int n_src, int max_hops,
                         const int64_t *dst_ids, uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats) {
+  return bfs_dispatch(ctx, csr_c, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, nullptr);
+}
+
+extern "C" int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
+                              gg_bfs_stats *stats, gg_result **out_result) {
+  if (!out_result) return GG_ERR_INVALID_ARG;
+  *out_result = nullptr;
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  gg_result *res = new gg_result();
+  res->ctx = ctx;
+  res->k_min = res->k_max = 2;  // a 3-column table: fetch it as table 2
+  int rc = bfs_dispatch(ctx, csr, src_ids, n_src, max_hops, nullptr, 0, nullptr, stats, res);
+  if (rc != GG_OK) {
+    gg_result_destroy(res);
+    return rc;
+  }
+  *out_result = res;
+  return GG_OK;
+}
+
+static int bfs_dispatch(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, int n_src, int max_hops,
+                        const int64_t *dst_ids, uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats,
+                        gg_result *pairs) {
   gg_csr *csr = const_cast<gg_csr *>(csr_c);
   ApiScope scope(ctx);
   if (!ctx || !csr || csr->ctx != ctx || n_src < 0 || n_src > GG_BFS_LANES || (n_src && !src_ids) ||
@@ -376,14 +461,14 @@ extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids
   // one byte per (vertex, lane) covers 254 levels; deeper searches rerun with two-byte cells
   bool overflow = false;
   if (max_hops < 0 || max_hops > 254) {
-    int rc = bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow);
+    int rc = bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow, pairs);
     if (rc != GG_OK || !overflow) return rc;
-    rc = bfs_run<uint16_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow);
+    rc = bfs_run<uint16_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow, pairs);
     if (rc == GG_OK && overflow) {
       set_error("gg_bfs64: search deeper than 65534 levels is not supported");
       return GG_ERR_TOO_LARGE;
     }
     return rc;
   }
-  return bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow);
+  return bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow, pairs);
 }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gg_debug_force_frontier",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
-    "gg_bfs64",
+    "gg_bfs64", "gg_bfs64_pairs",
     "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
 
@@ -99,6 +99,7 @@ def load_library(path: str | None = None):
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
+    lib.gg_bfs64_pairs.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
     lib.gg_profile_enable.argtypes = [P, C.c_int]
     lib.gg_profile_reset.argtypes = [P]
     lib.gg_profile_count.argtypes = [P, C.POINTER(C.c_int)]
@@ -317,6 +318,26 @@ class GG:
             rc = self.lib.gg_bfs64(self.ctx, csr.handle, ps, s.size, max_hops, pt, t.size, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st))
         self._chk(rc)
         return out, {"levels": st.levels, "traversed_edges": st.traversed_edges, "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
+
+    def bfs64_pairs(self, csr: Csr, sources, max_hops: int):
+        """Reached (source id, vertex id, distance) rows of one <=64-source batch, compacted on the device."""
+        i64p = C.POINTER(C.c_int64)
+        s, ps = _i64(sources)
+        st, res = BfsStats(), C.c_void_p()
+        self._chk(self.lib.gg_bfs64_pairs(self.ctx, csr.handle, ps, s.size, max_hops, C.byref(st), C.byref(res)))
+        try:
+            n = C.c_uint64()
+            self._chk(self.lib.gg_result_rows(res, 2, C.byref(n)))
+            out = np.empty((3, n.value), np.int64)
+            if n.value:
+                ptrs = (i64p * 3)(*[out[c].ctypes.data_as(i64p) for c in range(3)])
+                got = C.c_uint32()
+                self._chk(self.lib.gg_result_fetch(res, 2, 0, n.value, ptrs, C.byref(got)))  # one bulk copy
+                assert got.value == n.value
+        finally:
+            self.lib.gg_result_destroy(res)
+        return out.T.copy(), {"levels": st.levels, "traversed_edges": st.traversed_edges,
+                              "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
 
     # ---- profiling
     def profile(self, on: bool):

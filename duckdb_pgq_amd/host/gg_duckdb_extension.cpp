@@ -22,6 +22,10 @@
 // the base-table scans and the device work happen when the scan is initialised, i.e. at execution time.
 // The same machinery serves the planner rules of gg_plan_rule.cpp, which put these scans in place of
 // hash-join chains over an edge table (plan-level substitution).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "duckdb.hpp"
 #include "duckdb/catalog/catalog.hpp"
 #include "duckdb/common/exception.hpp"
@@ -46,15 +50,37 @@ string GGQuote(const string &ident) {
 	return out + "\"";
 }
 
+//! GG_TIMING=1 in the environment: phase times of every scan on stderr
+static bool TimingEnabled() {
+	static const bool enabled = std::getenv("GG_TIMING") != nullptr;
+	return enabled;
+}
+
+struct PhaseTimer {
+	std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+	void Lap(const char *what) {
+		if (!TimingEnabled()) {
+			return;
+		}
+		auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[gg] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+		last = now;
+	}
+};
+
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec) {
+	PhaseTimer timer;
 	auto graph = make_shared<GGGraph>(0);
+	timer.Lap("device context");
 	const bool derive = spec.vertices.Empty();
 	if (!derive) {
 		PhysicalGGVertexSink vsink(graph, {LogicalType::BIGINT}, 0);
 		GGRunSinkPipeline(context, spec.vertices, vsink);
+		timer.Lap("vertex table ingest");
 	}
 	PhysicalGGEdgeSink esink(graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, false, derive);
 	GGRunSinkPipeline(context, spec.edges, esink);
+	timer.Lap("edge ingest + CSR build");
 	return graph;
 }
 
@@ -87,8 +113,10 @@ static unique_ptr<FunctionOperatorData> GGInit(ClientContext &context, const Fun
                                                const vector<column_t> &column_ids, TableFilterCollection *filters) {
 	auto &data = (GGFunctionData &)*bind_data;
 	auto state = make_unique<GGOperatorData>();
+	PhaseTimer timer;
 	data.open(context, state->opened);
 	state->opened.gstate = state->opened.source->GetGlobalSourceState(context);
+	timer.Lap("scan opened (total)");
 	return move(state);
 }
 

@@ -11,6 +11,9 @@
 // (duckdb_pgq_amd/csrc/gg_runtime.hip).  Anything that is not a plain table falls back to a statement on
 // a side connection, pulled chunk by chunk.
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 #include "duckdb.hpp"
@@ -162,15 +165,24 @@ void IngestStatement(ClientContext &context, const string &sql, PhysicalOperator
 } // namespace
 
 void GGRunSinkPipeline(ClientContext &context, const GGScanSource &source, PhysicalOperator &sink) {
+	static const bool timing = std::getenv("GG_TIMING") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
 	sink.sink_state = sink.GetGlobalSinkState(context);
 	if (source.table) {
 		IngestTable(context, source, sink);
 	} else {
 		IngestStatement(context, source.sql, sink);
 	}
+	auto t1 = std::chrono::steady_clock::now();
 	Pipeline pipeline(context.executor);
 	GGNoopEvent event(context.executor);
 	sink.Finalize(pipeline, event, context, *sink.sink_state);
+	if (timing) {
+		auto t2 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[gg]   %-20s scan+sink %8.3f ms, finalize %8.3f ms\n", sink.GetName().c_str(),
+		        std::chrono::duration<double, std::milli>(t1 - t0).count(),
+		        std::chrono::duration<double, std::milli>(t2 - t1).count());
+	}
 }
 
 GGScanSource GGTableSource(ClientContext &context, const string &table_name, const vector<string> &columns,

@@ -17,8 +17,41 @@ void GGGraph::Check(int rc, const char *what) {
 	}
 }
 
-GGGraph::GGGraph(int device) {
-	Check(gg_ctx_create(device, &ctx), "gg_ctx_create");
+//! Idle device contexts.  Creating one costs tens of milliseconds (pinned staging blocks, stream) and its
+//! block cache makes the next build allocation-free, so queries hand them back instead of destroying them.
+struct GGContextPool {
+	std::mutex lock;
+	vector<std::pair<int, gg_ctx *>> idle;
+	// (idle contexts are deliberately not destroyed at process exit: the HIP runtime may be gone by then)
+	gg_ctx *Acquire(int device) {
+		lock_guard<mutex> guard(lock);
+		for (idx_t i = 0; i < idle.size(); i++) {
+			if (idle[i].first == device) {
+				auto ctx = idle[i].second;
+				idle.erase(idle.begin() + i);
+				return ctx;
+			}
+		}
+		return nullptr;
+	}
+	void Release(int device, gg_ctx *ctx) {
+		lock_guard<mutex> guard(lock);
+		if (idle.size() < 4) {
+			idle.emplace_back(device, ctx);
+		} else {
+			gg_ctx_destroy(ctx);
+		}
+	}
+};
+static GGContextPool g_context_pool;
+
+GGGraph::GGGraph(int device_p) : device(device_p) {
+	ctx = g_context_pool.Acquire(device);
+	if (ctx) {
+		Check(gg_staging_clear(ctx), "gg_staging_clear");
+	} else {
+		Check(gg_ctx_create(device, &ctx), "gg_ctx_create");
+	}
 	// none of the operators below returns edge ids: build without the edge-rowid payload, as the
 	// reference's hash-join build side carries only the columns the query references
 	Check(gg_ctx_set_edge_rowid(ctx, 0), "gg_ctx_set_edge_rowid");
@@ -32,7 +65,7 @@ GGGraph::~GGGraph() {
 		gg_csr_destroy(csr);
 	}
 	if (ctx) {
-		gg_ctx_destroy(ctx);
+		g_context_pool.Release(device, ctx);
 	}
 }
 
@@ -228,10 +261,16 @@ public:
 
 	gg_khop_stats stats;
 	gg_result *result = nullptr;
-	// scan position: (current hop length, row offset inside it); GetData claims slices under the lock
+	// scan position: (current hop length, row offset inside it); GetData serves <=1024-row chunks out of a
+	// host slab that is refilled from the device result SLAB_ROWS rows at a time (one copy per column
+	// instead of one per chunk)
+	static constexpr idx_t SLAB_ROWS = 1u << 18;
 	mutex lock;
 	int hop = 0;
-	idx_t offset = 0;
+	idx_t offset = 0;      // next device row of `hop` to fetch
+	vector<int64_t> slab[GG_MAX_HOPS + 1];
+	int slab_hop = 0;
+	idx_t slab_rows = 0, slab_pos = 0;
 	idx_t max_threads = 1;
 };
 
@@ -295,11 +334,11 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 		chunk.SetCardinality(n);
 		return;
 	}
-	// claim the next <=1024-row slice of the current hop-length table
-	int hop;
-	idx_t offset;
-	{
-		lock_guard<mutex> guard(gstate.lock);
+	if (context.client.interrupted) { // cancellation is polled between device calls
+		throw InterruptException();
+	}
+	lock_guard<mutex> guard(gstate.lock);
+	if (gstate.slab_pos >= gstate.slab_rows) { // refill the slab from the next non-empty hop-length table
 		while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
 			gstate.hop++;
 			gstate.offset = 0;
@@ -307,24 +346,35 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 		if (gstate.hop > k_max) {
 			return;
 		}
-		hop = gstate.hop;
-		offset = gstate.offset;
-		gstate.offset += STANDARD_VECTOR_SIZE;
+		const idx_t want = MinValue<idx_t>(GGExpandGlobalState::SLAB_ROWS, gstate.stats.rows[gstate.hop] - gstate.offset);
+		int64_t *cols[GG_MAX_HOPS + 1];
+		for (int c = 0; c <= gstate.hop; c++) {
+			gstate.slab[c].resize(want);
+			cols[c] = gstate.slab[c].data();
+		}
+		uint32_t got = 0;
+		{
+			lock_guard<mutex> device_guard(graph->lock);
+			GGGraph::Check(gg_result_fetch(gstate.result, gstate.hop, gstate.offset, (uint32_t)want, cols, &got),
+			               "gg_result_fetch");
+		}
+		gstate.slab_hop = gstate.hop;
+		gstate.slab_rows = got;
+		gstate.slab_pos = 0;
+		gstate.offset += got;
+		if (got == 0) {
+			return;
+		}
 	}
-	if (context.client.interrupted) { // cancellation is polled between device calls
-		throw InterruptException();
-	}
-	int64_t *cols[GG_MAX_HOPS + 1];
+	const int hop = gstate.slab_hop;
+	const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.slab_rows - gstate.slab_pos);
 	for (int c = 0; c <= hop; c++) {
-		cols[c] = FlatVector::GetData<int64_t>(chunk.data[1 + c]); // flat vectors, written in place
+		memcpy(FlatVector::GetData<int64_t>(chunk.data[1 + c]), gstate.slab[c].data() + gstate.slab_pos,
+		       n * sizeof(int64_t));
 	}
-	uint32_t n = 0;
-	{
-		lock_guard<mutex> guard(graph->lock);
-		GGGraph::Check(gg_result_fetch(gstate.result, hop, offset, STANDARD_VECTOR_SIZE, cols, &n), "gg_result_fetch");
-	}
+	gstate.slab_pos += n;
 	auto hops = FlatVector::GetData<int32_t>(chunk.data[0]);
-	for (uint32_t i = 0; i < n; i++) {
+	for (idx_t i = 0; i < n; i++) {
 		hops[i] = hop;
 	}
 	for (int c = hop + 1; c <= k_max; c++) { // shorter walks: trailing vertices are NULL
@@ -404,8 +454,7 @@ void PhysicalGGFilteredPaths::GetData(ExecutionContext &context, DataChunk &chun
 //===--------------------------------------------------------------------===//
 class GGShortestGlobalState : public GlobalSourceState {
 public:
-	vector<int64_t> start, frnd;
-	vector<int32_t> hop;
+	vector<int64_t> start, frnd, hop; // (source, vertex, distance) rows of all batches
 	idx_t offset = 0;
 };
 
@@ -422,10 +471,6 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 	if (!graph->csr) {
 		throw InternalException("GG_SHORTEST_PATH scheduled before the CSR was built");
 	}
-	uint64_t V = 0;
-	GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
-	vector<int64_t> vid(V);
-	GGGraph::Check(gg_csr_export(graph->csr, nullptr, nullptr, nullptr, vid.data()), "gg_csr_export");
 	// UNION semantics: a source listed twice yields its rows once
 	vector<int64_t> uniq;
 	{
@@ -436,30 +481,47 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 			}
 		}
 	}
-	vector<int32_t> dist;
 	for (idx_t base = 0; base < uniq.size(); base += GG_BFS_LANES) { // 64 bit lanes per batch
 		if (context.interrupted) {
 			throw InterruptException();
 		}
-		int n = (int)MinValue<idx_t>(GG_BFS_LANES, uniq.size() - base);
-		dist.resize((size_t)n * V);
-		GGGraph::Check(gg_bfs64(graph->ctx, graph->csr, uniq.data() + base, n, max_hops, nullptr, 0, dist.data(), nullptr),
-		               "gg_bfs64");
-		for (int i = 0; i < n; i++) {
-			bool reached_any = false;
-			for (uint64_t v = 0; v < V; v++) {
-				int32_t d = dist[(size_t)i * V + v];
-				if (d >= 0) {
-					state->start.push_back(uniq[base + i]);
-					state->frnd.push_back(vid[v]);
-					state->hop.push_back(d);
-					reached_any = true;
+		const int n = (int)MinValue<idx_t>(GG_BFS_LANES, uniq.size() - base);
+		// the reached (source, vertex, distance) rows are compacted on the device and come back in one copy
+		gg_result *pairs = nullptr;
+		GGGraph::Check(gg_bfs64_pairs(graph->ctx, graph->csr, uniq.data() + base, n, max_hops, nullptr, &pairs),
+		               "gg_bfs64_pairs");
+		uint64_t rows = 0;
+		int rc = gg_result_rows(pairs, 2, &rows);
+		const idx_t before = state->start.size();
+		if (rc == GG_OK && rows) {
+			state->start.resize(before + rows);
+			state->frnd.resize(before + rows);
+			state->hop.resize(before + rows);
+			int64_t *cols[3] = {state->start.data() + before, state->frnd.data() + before, state->hop.data() + before};
+			for (uint64_t done = 0; rc == GG_OK && done < rows;) {
+				int64_t *at[3] = {cols[0] + done, cols[1] + done, cols[2] + done};
+				uint32_t got = 0;
+				rc = gg_result_fetch(pairs, 2, done, (uint32_t)MinValue<uint64_t>(rows - done, 1u << 30), at, &got);
+				done += got;
+			}
+		}
+		gg_result_destroy(pairs);
+		GGGraph::Check(rc, "gg_result_fetch");
+		if (lone_sources) {
+			// a source that is not a vertex of the graph reached nothing: only its own seed row.  Every
+			// source that IS a vertex has its (s, s, 0) row among the fetched ones.
+			unordered_set<int64_t> known;
+			for (idx_t r = before; r < state->start.size(); r++) {
+				if (state->hop[r] == 0) {
+					known.insert(state->start[r]);
 				}
 			}
-			if (!reached_any && lone_sources) { // not a vertex of the graph: only its own seed row
-				state->start.push_back(uniq[base + i]);
-				state->frnd.push_back(uniq[base + i]);
-				state->hop.push_back(0);
+			for (int i = 0; i < n; i++) {
+				if (!known.count(uniq[base + i])) {
+					state->start.push_back(uniq[base + i]);
+					state->frnd.push_back(uniq[base + i]);
+					state->hop.push_back(0);
+				}
 			}
 		}
 	}
@@ -475,7 +537,10 @@ void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk
 	}
 	memcpy(FlatVector::GetData<int64_t>(chunk.data[0]), gstate.start.data() + gstate.offset, n * sizeof(int64_t));
 	memcpy(FlatVector::GetData<int64_t>(chunk.data[1]), gstate.frnd.data() + gstate.offset, n * sizeof(int64_t));
-	memcpy(FlatVector::GetData<int32_t>(chunk.data[2]), gstate.hop.data() + gstate.offset, n * sizeof(int32_t));
+	auto hops = FlatVector::GetData<int32_t>(chunk.data[2]);
+	for (idx_t i = 0; i < n; i++) {
+		hops[i] = (int32_t)gstate.hop[gstate.offset + i];
+	}
 	gstate.offset += n;
 	chunk.SetCardinality(n);
 }

@@ -35,7 +35,8 @@ struct GGGraph {
 	//! Turn a non-zero gg status into the exception the reference's operators would throw.
 	static void Check(int rc, const char *what);
 
-	gg_ctx *ctx = nullptr;
+	int device = 0;
+	gg_ctx *ctx = nullptr;        // taken from / returned to a pool of idle contexts
 	gg_csr *csr = nullptr;        // path graph
 	gg_csr *filter_csr = nullptr; // optional second edge table over the same vertex set (same-neighbour filter)
 	std::mutex lock; // gg calls other than the appends are externally serialised (gg.h)

@@ -188,6 +188,13 @@ typedef struct gg_bfs_stats {
  * with the recursion bound `f.hopCount < max_hops` (bi-10-shortestpath.sql:8-31). */
 int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops, const int64_t *dst_ids,
              uint64_t n_dst, int32_t *out_dist, gg_bfs_stats *stats);
+/* gg_bfs64 with the answer compacted on the device: one row (source id, vertex id, distance) per reached
+ * pair — the friends_shortest relation of bi-10-shortestpath.sql:26-31 for this batch of sources — instead
+ * of the dense n_src x V matrix.  The rows are table 2 of *out_result: gg_result_rows(res, 2, &n),
+ * gg_result_fetch(res, 2, offset, n, cols[3], &got); row order is unspecified.  Sources that are not
+ * vertices contribute no row. */
+int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
+                   gg_bfs_stats *stats, gg_result **out_result);
 
 /* ---- in-library kernel timing (HIP events on the library's own stream) ---------------------- */
 /* Testing knob: force gg_expand_khop to use the frontier kernels even where the product kernel

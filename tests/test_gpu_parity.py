@@ -576,3 +576,20 @@ def test_vertices_from_edges_extreme_ids_and_empty(gg, orc):
     # no edges at all
     gg.staging_clear()
     assert gg.vertices_from_edges() == 0
+
+
+@pytest.mark.parametrize("V,E,seed,n_src,max_hops", [(50, 200, 1, 7, 3), (3000, 40000, 4, 64, -1), (3000, 40000, 5, 64, 2),
+                                                     (10, 0, 6, 3, 4)])
+def test_bfs64_pairs_is_the_compacted_distance_matrix(gg, orc, V, E, seed, n_src, max_hops):
+    vid, src, dst = datagen.small_graph(V, E, seed)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = datagen.pick_sources(vid, n_src, seed)
+    sources = np.concatenate([sources, np.array([-77], np.int64)])[:64]  # one id that is not a vertex
+    dist, st = gg.bfs64(csr, sources, max_hops)
+    pairs, st2 = gg.bfs64_pairs(csr, sources, max_hops)
+    assert st == st2 and pairs.shape[0] == st["reached_pairs"]
+    lane, v = np.nonzero(dist >= 0)
+    expect = np.stack([sources[lane], vid[v], dist[lane, v].astype(np.int64)], axis=1)
+    assert np.array_equal(sort_rows(pairs), sort_rows(expect))
+    csr.close()
+    g.close()
