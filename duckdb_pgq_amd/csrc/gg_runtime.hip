@@ -336,6 +336,8 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
       set_error("edge table larger than 2^32-2 rows is not supported");
       return GG_ERR_TOO_LARGE;
     }
+    // a full open block means its closer is still waiting to switch blocks: wait for the switch
+    ctx->cv.wait(lk, [&] { return ctx->eblk[ctx->cur_e].fill < S; });
     gg_ctx::EdgeBlock &b = ctx->eblk[ctx->cur_e];
     const size_t room = S - b.fill;
     const size_t take = n < room ? (size_t)n : room;
@@ -372,6 +374,7 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
       ctx->cur_e ^= 1;
     }
     lk.unlock();
+    if (closer) ctx->cv.notify_all();  // appenders waiting for a block with room
     // ---- copy outside the lock: concurrent Sink calls overlap here
     memcpy(b.pin + off, src, take * sizeof(int64_t));
     memcpy(b.pin + S + off, dst, take * sizeof(int64_t));

@@ -593,3 +593,55 @@ def test_bfs64_pairs_is_the_compacted_distance_matrix(gg, orc, V, E, seed, n_src
     assert np.array_equal(sort_rows(pairs), sort_rows(expect))
     csr.close()
     g.close()
+
+
+@pytest.mark.parametrize("with_rowid", [False, True, "mixed"])
+def test_concurrent_appends_across_many_staging_blocks(gg, orc, with_rowid):
+    """16 threads push 3.3 M edge rows (more than three 1 M-row pinned blocks) in chunks of uneven size, so
+    blocks fill, close, flush and reopen while other threads are still copying into them.  Every row must
+    arrive exactly once (rows without rowid get their append position, which is then a permutation)."""
+    import threading
+
+    vid, src, dst = datagen.ldbc_knows(3000, 3_300_000, 77)
+    rowid = np.arange(src.size, dtype=np.int64) + 10_000_000
+    gg.staging_clear()
+    gg.set_edge_rowid(True)
+    gg.append_vertices(vid)
+    nthreads = 16
+    bounds = np.linspace(0, src.size, nthreads + 1).astype(int)
+    errs = []
+
+    def work(t):
+        try:
+            step = [1024, 777, 4096, 1][t % 4] if t % 4 != 3 else 50_000
+            use_rowid = with_rowid is True or (with_rowid == "mixed" and t % 2 == 0)
+            for o in range(bounds[t], bounds[t + 1], step):
+                e = min(o + step, bounds[t + 1])
+                gg.append_edges(src[o:e], dst[o:e], rowid[o:e] if use_rowid else None)
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    assert gg.staging_counts() == (vid.size, src.size)
+    csr = gg.build_csr()
+    off, nbr, eid, _ = csr.export()
+    rc, g = orc.csr_build(vid, src, dst, rowid)
+    o_off, o_nbr, o_eid, _ = g.arrays()
+    assert csr.E == g.E and np.array_equal(off, o_off)
+    row = np.repeat(np.arange(csr.V), np.diff(off))
+    assert np.array_equal(np.sort(row * csr.V + nbr), np.sort(row * csr.V + o_nbr))  # same multiset of edges
+    if with_rowid is True:
+        k, ko = np.lexsort((eid, row)), np.lexsort((o_eid, row))
+        assert np.array_equal(eid[k], o_eid[ko]) and np.array_equal(nbr[k], o_nbr[ko])
+    elif with_rowid is False:
+        assert np.array_equal(np.sort(eid), np.arange(csr.E))  # implicit rowids: a permutation of positions
+    else:
+        explicit = eid >= 10_000_000
+        assert explicit.sum() == sum(bounds[t + 1] - bounds[t] for t in range(0, nthreads, 2))
+        assert np.unique(eid).size == eid.size
+    assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
+    csr.close()
+    g.close()
