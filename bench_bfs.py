@@ -2,8 +2,10 @@
 """bench_bfs.py — secondary benchmark: LDBC SNB shortest_path(Person, Person), 64-source bitset BFS
 (BASELINE.json configs[2]).  Not the driver's bench line (that is bench.py); results go to profiles/.
 
-A step = one 64-source batch run to fixpoint on a prebuilt CSR (distances stay in HBM).  With N ranks,
-each rank takes different source batches (source-batch sharding: no communication, weak scaling).
+A step = one 64-source batch run to fixpoint on a prebuilt CSR (distances stay in HBM).  With N ranks
+(python -m torch.distributed.run --nproc-per-node N bench_bfs.py), every rank holds the whole CSR and takes
+different source batches (source-batch sharding, SURVEY.md §8e: no data-path communication, weak scaling);
+one all-reduce adds up the traversed edges and takes the slowest rank's time.
 CPU baseline: the C oracle's bitset BFS on one batch; and, where oracle/_ref exists, the reference's
 recursive CTE (bi-10 friends/friends_shortest) on a bounded hop count.
 """
@@ -26,13 +28,24 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     import duckdb_pgq_amd as pkg
+    from duckdb_pgq_amd import sharding
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(os.environ.get("GG_BENCH_BACKEND", "nccl"))
 
     vid, src, dst = pkg.datagen.ldbc(args.workload)
-    gg = pkg.GG(0)
+    gg = pkg.GG(int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)
     gg.append_vertices(vid)
     gg.append_edges(src, dst)
     csr = gg.build_csr()
-    batches = [pkg.datagen.pick_sources(vid, 64, 0x5EED, batch=b) for b in range(args.batches)]
+    batches = [pkg.datagen.pick_sources(vid, 64, 0x5EED, batch=b)
+               for b in sharding.source_batches(rank, world, args.batches)]
     gg.bfs64(csr, batches[0], args.max_hops, fetch=False)  # warm-up
     gg.profile_reset()
     gg.profile(True)
@@ -44,6 +57,17 @@ def main():
         act += st["active_vertices"]
         lv += st["levels"]
     dt = time.perf_counter() - t0
+    if dist is not None:  # whole-job numbers: edges add up, the slowest rank sets the time
+        import torch
+
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        sums = torch.tensor([te, act, lv], dtype=torch.int64, device=dev)
+        slowest = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        te_job, dt = int(sums[0]), float(slowest[0])
+    else:
+        te_job = te
     gg.profile(False)
     prof = gg.profile_get()
     V = csr.V
@@ -51,13 +75,14 @@ def main():
     kern_ms = sum(v[1] for k, v in prof.items() if k.startswith("bfs_"))
     line = {
         "metric": "traversed edges/sec, 64-source bitset BFS (shortest path)", "workload": args.workload,
-        "batches": args.batches, "max_hops": args.max_hops, "value": te / dt, "unit": "traversed edges/s",
+        "n_gpus": world, "scaling": "weak", "batches_per_gpu": args.batches, "max_hops": args.max_hops,
+        "value": te_job / dt, "unit": "traversed edges/s",
         "ms_per_batch": dt / args.batches * 1e3, "levels_per_batch": lv / args.batches,
         "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / (kern_ms * 1e-3) / 8e12, "kernel_ms_per_batch": kern_ms / args.batches},
         "kernels": {k: {"launches": v[0], "us_per_batch": v[1] * 1e3 / args.batches} for k, v in prof.items()},
     }
-    if not args.no_cpu:
+    if not args.no_cpu and rank == 0:
         from tests import oracle_lib
 
         orc = oracle_lib.load()
@@ -71,9 +96,13 @@ def main():
         line["cpu_port"] = {"value": ost["traversed_edges"] / cdt, "unit": "traversed edges/s", "cores": 1,
                             "sample": f"one 64-source batch, C oracle bitset BFS, {cdt:.2f}s"}
         g.close()
-    print(json.dumps(line))
+    if rank == 0:
+        print(json.dumps(line))
     csr.close()
     gg.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

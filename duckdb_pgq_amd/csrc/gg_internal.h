@@ -66,14 +66,31 @@ struct Column {
 
 }  // namespace gg
 
+namespace gg {
+// Guards the few words an edge-row reservation touches.  Sink threads take it once per DataChunk; with a
+// sleeping mutex 64+ of them form a convoy (measured: 40 M rows staged in 33 ms by 8 threads, 600 ms by
+// 256), so the hot path spins for its ~50 ns critical section and only block switches use mu/cv.
+struct SpinLock {
+  std::atomic_flag flag = ATOMIC_FLAG_INIT;
+  void lock() {
+    while (flag.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+  void unlock() { flag.clear(std::memory_order_release); }
+};
+}  // namespace gg
+
 struct gg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int num_cus = 256;
 
-  // ---- staging (guarded by mu unless noted) ----
+  // ---- staging ----
+  // mu: vertex staging, device columns, block flushes and everything slow.  edge_spin: the reservation
+  // state of the edge blocks (cur_e, fill, base, has_rowid, OPEN/CLOSED, n_edges, implicit ranges).
+  // Lock order: mu before edge_spin.
   std::mutex mu;
-  std::condition_variable cv;                    // an edge block became FREE
+  gg::SpinLock edge_spin;
+  std::condition_variable cv;                    // an edge block became FREE / the open block changed
   gg::Column c_vid, c_src, c_dst, c_rowid;
   uint64_t n_vertices = 0, n_edges = 0;          // rows resident, in flight to the device or reserved in a block
   bool rowid_explicit = false;                   // some append passed explicit rowids

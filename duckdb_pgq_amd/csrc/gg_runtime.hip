@@ -291,7 +291,8 @@ static int flush_edge_block(gg_ctx *ctx, gg_ctx::EdgeBlock &b) {
   return GG_OK;
 }
 
-static void reset_edge_blocks(gg_ctx *ctx) {
+static void reset_edge_blocks(gg_ctx *ctx) {  // caller holds mu
+  ctx->edge_spin.lock();
   for (auto &b : ctx->eblk) {
     b.fill = 0;
     b.base = 0;
@@ -302,6 +303,7 @@ static void reset_edge_blocks(gg_ctx *ctx) {
   ctx->eblk[0].state = gg_ctx::EdgeBlock::OPEN;
   ctx->implicit_rowid_ranges.clear();
   ctx->rowid_explicit = false;
+  ctx->edge_spin.unlock();
 }
 
 extern "C" int gg_vertices_append(gg_ctx *ctx, const int64_t *id, uint64_t n) {
@@ -330,15 +332,26 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
   if (!ctx || ((!src || !dst) && n)) return GG_ERR_INVALID_ARG;
   const size_t S = gg_ctx::STAGE_ROWS;
   while (n) {
-    // ---- reserve rows in the open block (short critical section)
-    std::unique_lock<std::mutex> lk(ctx->mu);
+    // ---- reserve rows in the open block (spin lock: a handful of words)
+    ctx->edge_spin.lock();
+    gg_ctx::EdgeBlock &b = ctx->eblk[ctx->cur_e];
+    if (b.fill == S) {
+      // full: its closer has not switched blocks yet (it may be waiting for the other block's copies)
+      ctx->edge_spin.unlock();
+      std::unique_lock<std::mutex> lk(ctx->mu);
+      ctx->cv.wait(lk, [&] {
+        ctx->edge_spin.lock();
+        const bool room = ctx->eblk[ctx->cur_e].fill < S;
+        ctx->edge_spin.unlock();
+        return room;
+      });
+      continue;
+    }
     if (ctx->n_edges + n >= (uint64_t)INVALID_U32) {
+      ctx->edge_spin.unlock();
       set_error("edge table larger than 2^32-2 rows is not supported");
       return GG_ERR_TOO_LARGE;
     }
-    // a full open block means its closer is still waiting to switch blocks: wait for the switch
-    ctx->cv.wait(lk, [&] { return ctx->eblk[ctx->cur_e].fill < S; });
-    gg_ctx::EdgeBlock &b = ctx->eblk[ctx->cur_e];
     const size_t room = S - b.fill;
     const size_t take = n < room ? (size_t)n : room;
     const size_t off = b.fill;
@@ -357,25 +370,35 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
       ctx->implicit_rowid_ranges.emplace_back(first_row, (uint64_t)take);
     }
     const bool closer = b.fill == S;
+    ctx->edge_spin.unlock();
+
     if (closer) {
       // the block is full: open the other one for everybody else.  It must have been flushed (FREE) and
       // its copies must have left the pinned memory.
-      gg_ctx::EdgeBlock &o = ctx->eblk[ctx->cur_e ^ 1];
+      gg_ctx::EdgeBlock &o = ctx->eblk[&b == &ctx->eblk[0] ? 1 : 0];
+      std::unique_lock<std::mutex> lk(ctx->mu);
       ctx->cv.wait(lk, [&] { return o.state == gg_ctx::EdgeBlock::FREE; });
-      if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(o.free_ev) != hipSuccess) {
-        b.writers.fetch_sub(1, std::memory_order_release);
-        set_error("HIP error while waiting for a staging block");
-        return GG_ERR_HIP;
-      }
+      const bool ok = hipSetDevice(ctx->device) == hipSuccess && hipEventSynchronize(o.free_ev) == hipSuccess;
+      ctx->edge_spin.lock();
       o.fill = 0;
       o.has_rowid = false;
       o.state = gg_ctx::EdgeBlock::OPEN;
       b.state = gg_ctx::EdgeBlock::CLOSED;
       ctx->cur_e ^= 1;
+      ctx->edge_spin.unlock();
+      lk.unlock();
+      ctx->cv.notify_all();  // appenders waiting for a block with room
+      if (!ok) {
+        b.writers.fetch_sub(1, std::memory_order_release);
+        lk.lock();
+        b.state = gg_ctx::EdgeBlock::FREE;  // nobody may wait for this block forever
+        lk.unlock();
+        ctx->cv.notify_all();
+        set_error("HIP error while waiting for a staging block");
+        return GG_ERR_HIP;
+      }
     }
-    lk.unlock();
-    if (closer) ctx->cv.notify_all();  // appenders waiting for a block with room
-    // ---- copy outside the lock: concurrent Sink calls overlap here
+    // ---- copy outside any lock: concurrent Sink calls overlap here
     memcpy(b.pin + off, src, take * sizeof(int64_t));
     memcpy(b.pin + S + off, dst, take * sizeof(int64_t));
     if (rowid) {
@@ -388,7 +411,7 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
     n -= take;
     if (closer) {
       while (b.writers.load(std::memory_order_acquire) != 0) std::this_thread::yield();
-      lk.lock();
+      std::unique_lock<std::mutex> lk(ctx->mu);
       int rc = hipSetDevice(ctx->device) == hipSuccess ? flush_edge_block(ctx, b) : GG_ERR_HIP;
       b.state = gg_ctx::EdgeBlock::FREE;  // also on error: nobody may wait for this block forever
       lk.unlock();
@@ -406,12 +429,16 @@ extern "C" int gg_staging_sync(gg_ctx *ctx) {
   GG_TRY(flush_vertices(ctx));
   // the open block, partially filled (appends running concurrently with a sync are outside the contract,
   // but never leave a half-copied reservation behind)
+  ctx->edge_spin.lock();
   gg_ctx::EdgeBlock &b = ctx->eblk[ctx->cur_e];
+  ctx->edge_spin.unlock();
   while (b.writers.load(std::memory_order_acquire) != 0) std::this_thread::yield();
   GG_TRY(flush_edge_block(ctx, b));
   GG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->edge_spin.lock();
   b.fill = 0;  // the pinned memory is free again; the block stays open
   b.has_rowid = false;
+  ctx->edge_spin.unlock();
   return GG_OK;
 }
 

@@ -64,3 +64,9 @@ def combine(vec, dist=None, device=None) -> list:
 
 def dsum(a: int, b: int) -> int:
     return ((a & MASK32) + (b & MASK32)) & MASK32
+
+
+def source_batches(rank: int, world: int, per_rank: int):
+    """Source-batch sharding of the 64-lane BFS: rank r runs batches r, r+world, ... —
+    `per_rank` of them, disjoint across ranks, together the first world*per_rank batches."""
+    return [rank + i * world for i in range(per_rank)]

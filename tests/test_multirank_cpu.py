@@ -97,3 +97,49 @@ def test_owner_partition_and_halves():
     a, b = 0xFFFFFFFF, 0x00000001
     parts = [x + y for x, y in zip(sharding.split_halves([0, 0, a, a, 0, 0]), sharding.split_halves([0, 0, b, b, 0, 0]))]
     assert sharding.join_halves(parts)[2] == 0
+
+
+def _bfs_worker(rank, world, port, q):
+    """Source-batch sharding of the 64-lane BFS (bench_bfs.py with N ranks): every rank runs its own
+    batches on the whole graph; one all-reduce adds the per-rank statistics.  Per-rank compute = the
+    oracle's bitset BFS."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.load()
+        vid, src, dst = datagen.small_graph(400, 3000, 91)
+        rc, g = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        per_rank = 2
+        stat = lambda b: g.bfs64(g.lookup(datagen.pick_sources(vid, 64, 0x5EED, batch=b)), -1)[1]
+        mine = sharding.source_batches(rank, world, per_rank)
+        te = sum(stat(b)["traversed_edges"] for b in mine)
+        pairs = sum(stat(b)["reached_pairs"] for b in mine)
+        t = torch.tensor([te, pairs], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        every = range(world * per_rank)
+        assert int(t[0]) == sum(stat(b)["traversed_edges"] for b in every)
+        assert int(t[1]) == sum(stat(b)["reached_pairs"] for b in every)
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bfs_source_batches_shard_over_gloo():
+    world = 2
+    all_batches = sorted(b for r in range(world) for b in sharding.source_batches(r, world, 3))
+    assert all_batches == list(range(6))  # disjoint, and together a prefix of the batch sequence
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bfs_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
