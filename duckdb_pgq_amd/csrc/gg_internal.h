@@ -117,6 +117,15 @@ struct gg_ctx {
   } eblk[2];
   int cur_e = 0;                                 // the OPEN block
 
+  // ---- pinned host buffers handed out by gg_host_alloc (guarded by host_mu) ----
+  struct HostBlock {
+    void *ptr;
+    size_t bytes;
+    bool in_use;
+  };
+  std::mutex host_mu;
+  std::vector<HostBlock> host_blocks;
+
   // ---- caching device allocator ----
   std::vector<gg::DevBlock> blocks;
   size_t bytes_allocated = 0;

@@ -226,6 +226,8 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
     if (ctx->eblk[i].free_ev) (void)hipEventDestroy(ctx->eblk[i].free_ev);
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
+  for (auto &h : ctx->host_blocks)
+    if (h.ptr) (void)hipHostFree(h.ptr);
   // staged columns are plain hipMalloc (they grow by doubling, outside the block cache)
   if (ctx->c_vid.dev) (void)hipFree(ctx->c_vid.dev);
   if (ctx->c_src.dev) (void)hipFree(ctx->c_src.dev);
@@ -233,6 +235,36 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
   if (ctx->c_rowid.dev) (void)hipFree(ctx->c_rowid.dev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+extern "C" int gg_host_alloc(gg_ctx *ctx, uint64_t bytes, void **out) {
+  if (!ctx || !out) return GG_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (bytes == 0) bytes = 1;
+  std::lock_guard<std::mutex> lk(ctx->host_mu);
+  size_t best = (size_t)-1;
+  for (size_t i = 0; i < ctx->host_blocks.size(); i++) {  // smallest idle block that is large enough
+    auto &h = ctx->host_blocks[i];
+    if (!h.in_use && h.bytes >= bytes && (best == (size_t)-1 || h.bytes < ctx->host_blocks[best].bytes)) best = i;
+  }
+  if (best != (size_t)-1) {
+    ctx->host_blocks[best].in_use = true;
+    *out = ctx->host_blocks[best].ptr;
+    return GG_OK;
+  }
+  GG_HIP(hipSetDevice(ctx->device));
+  void *p = nullptr;
+  GG_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  ctx->host_blocks.push_back({p, (size_t)bytes, true});
+  *out = p;
+  return GG_OK;
+}
+
+extern "C" void gg_host_free(gg_ctx *ctx, void *ptr) {
+  if (!ctx || !ptr) return;
+  std::lock_guard<std::mutex> lk(ctx->host_mu);
+  for (auto &h : ctx->host_blocks)
+    if (h.ptr == ptr) h.in_use = false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -608,3 +640,20 @@ int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t 
 }
 
 }  // namespace gg
+
+extern "C" int gg_csr_lookup(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids, uint64_t n, uint32_t *dense_out) {
+  if (!ctx || !csr || csr->ctx != ctx || ((!ids || !dense_out) && n)) return GG_ERR_INVALID_ARG;
+  if (n == 0) return GG_OK;
+  ApiScope scope(ctx);
+  GG_HIP(hipSetDevice(ctx->device));
+  int64_t *ids_dev = nullptr;
+  uint32_t *out_dev = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&ids_dev, n * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&out_dev, n * sizeof(uint32_t)));
+  GG_HIP(hipMemcpyAsync(ids_dev, ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));  // `ids` may be pageable: do not return before it was read
+  GG_TRY(gg::lookup_ids(ctx, csr, ids_dev, n, out_dev));
+  GG_HIP(hipMemcpyAsync(dense_out, out_dev, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  return GG_OK;
+}

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gg_debug_force_frontier",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
-    "gg_bfs64", "gg_bfs64_pairs",
+    "gg_bfs64", "gg_bfs64_pairs", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
     "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
 
@@ -99,6 +99,10 @@ def load_library(path: str | None = None):
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
+    lib.gg_host_alloc.argtypes = [P, u64, C.POINTER(C.c_void_p)]
+    lib.gg_host_free.argtypes = [P, C.c_void_p]
+    lib.gg_host_free.restype = None
+    lib.gg_csr_lookup.argtypes = [P, P, i64p, u64, C.POINTER(C.c_uint32)]
     lib.gg_bfs64_pairs.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
     lib.gg_profile_enable.argtypes = [P, C.c_int]
     lib.gg_profile_reset.argtypes = [P]
@@ -318,6 +322,19 @@ class GG:
             rc = self.lib.gg_bfs64(self.ctx, csr.handle, ps, s.size, max_hops, pt, t.size, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(st))
         self._chk(rc)
         return out, {"levels": st.levels, "traversed_edges": st.traversed_edges, "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
+
+    def lookup(self, csr: Csr, ids) -> np.ndarray:
+        """Dense index of each id (uint32, 0xFFFFFFFF = not a vertex)."""
+        a, pa = _i64(ids)
+        out = np.empty(a.size, np.uint32)
+        self._chk(self.lib.gg_csr_lookup(self.ctx, csr.handle, pa, a.size, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def host_buffer(self, n_int64: int) -> np.ndarray:
+        """An int64 array in page-locked memory owned by the context (for gg_result_fetch at PCIe rate)."""
+        p = C.c_void_p()
+        self._chk(self.lib.gg_host_alloc(self.ctx, 8 * max(1, n_int64), C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64)), shape=(max(1, n_int64),))[:n_int64]
 
     def bfs64_pairs(self, csr: Csr, sources, max_hops: int):
         """Reached (source id, vertex id, distance) rows of one <=64-source batch, compacted on the device."""

@@ -32,6 +32,7 @@
 #include "duckdb/function/table_function.hpp"
 #include "duckdb/main/client_context.hpp"
 #include "duckdb/main/connection.hpp"
+#include "duckdb/parallel/parallel_state.hpp"
 #include "duckdb/parallel/thread_context.hpp"
 #include "duckdb/parser/parsed_data/create_table_function_info.hpp"
 #include "gg_extension.hpp"
@@ -105,28 +106,78 @@ static GGScanSource Statement(const string &sql) {
 	return source;
 }
 
+//! Per-thread scan state: the thread's window onto the result (LocalSourceState of the source operator).
 struct GGOperatorData : public FunctionOperatorData {
+	explicit GGOperatorData(ClientContext &context) : thread(context), execution(context, thread) {
+	}
+	GGOpened *opened = nullptr;
+	GGOpened own; // sequential scans open the graph themselves; parallel ones share GGParallelState's
+	ThreadContext thread;
+	ExecutionContext execution;
+	unique_ptr<LocalSourceState> local;
+};
+
+//! Shared by the threads of a parallel scan: the opened graph and the source's global state.
+struct GGParallelState : public ParallelState {
 	GGOpened opened;
 };
 
+static void Open(ClientContext &context, const FunctionData *bind_data, GGOpened &opened) {
+	auto &data = (GGFunctionData &)*bind_data;
+	PhaseTimer timer;
+	data.open(context, opened);
+	opened.gstate = opened.source->GetGlobalSourceState(context);
+	timer.Lap("scan opened (total)");
+}
+
 static unique_ptr<FunctionOperatorData> GGInit(ClientContext &context, const FunctionData *bind_data,
                                                const vector<column_t> &column_ids, TableFilterCollection *filters) {
-	auto &data = (GGFunctionData &)*bind_data;
-	auto state = make_unique<GGOperatorData>();
-	PhaseTimer timer;
-	data.open(context, state->opened);
-	state->opened.gstate = state->opened.source->GetGlobalSourceState(context);
-	timer.Lap("scan opened (total)");
+	auto state = make_unique<GGOperatorData>(context);
+	Open(context, bind_data, state->own);
+	state->opened = &state->own;
+	state->local = state->opened->source->GetLocalSourceState(state->execution, *state->opened->gstate);
 	return move(state);
 }
 
 static void GGFunction(ClientContext &context, const FunctionData *bind_data_p, FunctionOperatorData *operator_state,
                        DataChunk *input, DataChunk &output) {
 	auto &state = (GGOperatorData &)*operator_state;
-	ThreadContext thread(context);
-	ExecutionContext ec(context, thread);
-	LocalSourceState lstate;
-	state.opened.source->GetData(ec, output, *state.opened.gstate, lstate);
+	state.opened->source->GetData(state.execution, output, *state.opened->gstate, *state.local);
+}
+
+// ---- parallel scan: the reference's pipeline tasks drain one device-resident result together, each
+// through its own pinned slab (PhysicalTableScan's parallel protocol, physical_table_scan.cpp:22-110)
+static idx_t GGMaxThreads(ClientContext &context, const FunctionData *bind_data) {
+	return ((const GGFunctionData &)*bind_data).parallel_result ? 8 : 1;
+}
+
+static unique_ptr<ParallelState> GGInitParallelState(ClientContext &context, const FunctionData *bind_data,
+                                                     const vector<column_t> &column_ids,
+                                                     TableFilterCollection *filters) {
+	auto state = make_unique<GGParallelState>();
+	Open(context, bind_data, state->opened);
+	return move(state);
+}
+
+static unique_ptr<FunctionOperatorData> GGParallelInit(ClientContext &context, const FunctionData *bind_data,
+                                                       ParallelState *parallel_state,
+                                                       const vector<column_t> &column_ids,
+                                                       TableFilterCollection *filters) {
+	auto state = make_unique<GGOperatorData>(context);
+	state->opened = &((GGParallelState &)*parallel_state).opened;
+	state->local = state->opened->source->GetLocalSourceState(state->execution, *state->opened->gstate);
+	return move(state);
+}
+
+static void GGParallelFunction(ClientContext &context, const FunctionData *bind_data,
+                               FunctionOperatorData *operator_state, DataChunk *input, DataChunk &output,
+                               ParallelState *parallel_state) {
+	GGFunction(context, bind_data, operator_state, input, output);
+}
+
+static bool GGParallelStateNext(ClientContext &context, const FunctionData *bind_data, FunctionOperatorData *state,
+                                ParallelState *parallel_state) {
+	return false; // GetData claims its own slabs; an empty chunk means the result is exhausted
 }
 
 static string GGToString(const FunctionData *bind_data) {
@@ -136,6 +187,11 @@ static string GGToString(const FunctionData *bind_data) {
 TableFunction GGScanFunction(const string &name, vector<LogicalType> arguments, table_function_bind_t bind) {
 	TableFunction function(name, move(arguments), GGFunction, bind, GGInit);
 	function.to_string = GGToString;
+	function.max_threads = GGMaxThreads;
+	function.init_parallel_state = GGInitParallelState;
+	function.parallel_function = GGParallelFunction;
+	function.parallel_init = GGParallelInit;
+	function.parallel_state_next = GGParallelStateNext;
 	return function;
 }
 
@@ -208,6 +264,7 @@ static unique_ptr<FunctionData> KhopBindInternal(ClientContext &context, vector<
 		opened.source = make_unique<PhysicalGGPathExpand>(opened.graph, (int)k_min, (int)k_max, count_only,
 		                                                  vector<int64_t>(), true, 0);
 	};
+	data->parallel_result = !count_only;
 	return_types = PhysicalGGPathExpand::OutputTypes((int)k_max, count_only);
 	names.push_back("hops");
 	if (count_only) {
@@ -251,6 +308,7 @@ static unique_ptr<FunctionData> ShortestBind(ClientContext &context, vector<Valu
 		auto sources = GGQueryInt64Column(ctx, sources_sql, "gg_shortest_path: sources");
 		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), (int)max_hops, 0);
 	};
+	data->parallel_result = true;
 	return_types = {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER};
 	names = {"startPerson", "friend", "hopCount"};
 	return move(data);

@@ -21,7 +21,8 @@ struct GGOpened {
 //! EXPLAIN or PREPARE), the point where the reference's hash-join build pipelines would run.
 struct GGFunctionData : public TableFunctionData {
 	std::function<void(ClientContext &, GGOpened &)> open;
-	string description; // what EXPLAIN prints under the operator name
+	string description;           // what EXPLAIN prints under the operator name
+	bool parallel_result = false; // the result is large: let several pipeline threads drain it
 };
 
 //! The table function whose init runs GGFunctionData::open and whose function is the source's GetData.

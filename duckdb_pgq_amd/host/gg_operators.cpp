@@ -146,6 +146,35 @@ idx_t GGKeyColumns(DataChunk &input, const vector<idx_t> &cols, vector<vector<in
 }
 
 //===--------------------------------------------------------------------===//
+// Result slab
+//===--------------------------------------------------------------------===//
+GGResultSlab::GGResultSlab(shared_ptr<GGGraph> graph_p) : graph(move(graph_p)) {
+}
+
+GGResultSlab::~GGResultSlab() {
+	if (memory) {
+		gg_host_free(graph->ctx, memory);
+	}
+}
+
+int64_t **GGResultSlab::Columns(idx_t columns) {
+	if (columns > capacity_columns) {
+		if (memory) {
+			gg_host_free(graph->ctx, memory);
+			memory = nullptr;
+		}
+		void *p = nullptr;
+		GGGraph::Check(gg_host_alloc(graph->ctx, columns * SLAB_ROWS * sizeof(int64_t), &p), "gg_host_alloc");
+		memory = (int64_t *)p;
+		capacity_columns = columns;
+	}
+	for (idx_t c = 0; c < columns; c++) {
+		column[c] = memory + c * SLAB_ROWS;
+	}
+	return column;
+}
+
+//===--------------------------------------------------------------------===//
 // Sinks
 //===--------------------------------------------------------------------===//
 class GGSinkGlobalState : public GlobalSinkState {
@@ -261,16 +290,11 @@ public:
 
 	gg_khop_stats stats;
 	gg_result *result = nullptr;
-	// scan position: (current hop length, row offset inside it); GetData serves <=1024-row chunks out of a
-	// host slab that is refilled from the device result SLAB_ROWS rows at a time (one copy per column
-	// instead of one per chunk)
-	static constexpr idx_t SLAB_ROWS = 1u << 18;
+	// scan position: (current hop length, next row of it nobody has claimed); pipeline threads claim
+	// GGResultSlab::SLAB_ROWS rows at a time under the lock and fetch them into their own slab
 	mutex lock;
 	int hop = 0;
-	idx_t offset = 0;      // next device row of `hop` to fetch
-	vector<int64_t> slab[GG_MAX_HOPS + 1];
-	int slab_hop = 0;
-	idx_t slab_rows = 0, slab_pos = 0;
+	idx_t offset = 0;
 	idx_t max_threads = 1;
 };
 
@@ -311,8 +335,13 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 	for (int h = k_min; h <= k_max; h++) {
 		total += state->stats.rows[h];
 	}
-	state->max_threads = count_only ? 1 : MaxValue<idx_t>(1, total / (STANDARD_VECTOR_SIZE * 64));
+	state->max_threads = count_only ? 1 : MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
 	return move(state);
+}
+
+unique_ptr<LocalSourceState> PhysicalGGPathExpand::GetLocalSourceState(ExecutionContext &context,
+                                                                       GlobalSourceState &gstate) const {
+	return make_unique<GGResultSlab>(graph);
 }
 
 void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
@@ -337,42 +366,39 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 	if (context.client.interrupted) { // cancellation is polled between device calls
 		throw InterruptException();
 	}
-	lock_guard<mutex> guard(gstate.lock);
-	if (gstate.slab_pos >= gstate.slab_rows) { // refill the slab from the next non-empty hop-length table
-		while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
-			gstate.hop++;
-			gstate.offset = 0;
-		}
-		if (gstate.hop > k_max) {
-			return;
-		}
-		const idx_t want = MinValue<idx_t>(GGExpandGlobalState::SLAB_ROWS, gstate.stats.rows[gstate.hop] - gstate.offset);
-		int64_t *cols[GG_MAX_HOPS + 1];
-		for (int c = 0; c <= gstate.hop; c++) {
-			gstate.slab[c].resize(want);
-			cols[c] = gstate.slab[c].data();
+	auto &slab = (GGResultSlab &)lstate;
+	if (slab.pos >= slab.rows) { // claim the next rows of the next non-empty hop-length table
+		idx_t offset, want;
+		{
+			lock_guard<mutex> guard(gstate.lock);
+			while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
+				gstate.hop++;
+				gstate.offset = 0;
+			}
+			if (gstate.hop > k_max) {
+				return;
+			}
+			slab.table = gstate.hop;
+			offset = gstate.offset;
+			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.stats.rows[gstate.hop] - gstate.offset);
+			gstate.offset += want;
 		}
 		uint32_t got = 0;
-		{
-			lock_guard<mutex> device_guard(graph->lock);
-			GGGraph::Check(gg_result_fetch(gstate.result, gstate.hop, gstate.offset, (uint32_t)want, cols, &got),
-			               "gg_result_fetch");
-		}
-		gstate.slab_hop = gstate.hop;
-		gstate.slab_rows = got;
-		gstate.slab_pos = 0;
-		gstate.offset += got;
+		GGGraph::Check(gg_result_fetch(gstate.result, slab.table, offset, (uint32_t)want, slab.Columns(slab.table + 1),
+		                               &got),
+		               "gg_result_fetch");
+		slab.rows = got;
+		slab.pos = 0;
 		if (got == 0) {
 			return;
 		}
 	}
-	const int hop = gstate.slab_hop;
-	const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.slab_rows - gstate.slab_pos);
+	const int hop = slab.table;
+	const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, slab.rows - slab.pos);
 	for (int c = 0; c <= hop; c++) {
-		memcpy(FlatVector::GetData<int64_t>(chunk.data[1 + c]), gstate.slab[c].data() + gstate.slab_pos,
-		       n * sizeof(int64_t));
+		memcpy(FlatVector::GetData<int64_t>(chunk.data[1 + c]), slab.column[c] + slab.pos, n * sizeof(int64_t));
 	}
-	gstate.slab_pos += n;
+	slab.pos += n;
 	auto hops = FlatVector::GetData<int32_t>(chunk.data[0]);
 	for (idx_t i = 0; i < n; i++) {
 		hops[i] = hop;
@@ -454,8 +480,23 @@ void PhysicalGGFilteredPaths::GetData(ExecutionContext &context, DataChunk &chun
 //===--------------------------------------------------------------------===//
 class GGShortestGlobalState : public GlobalSourceState {
 public:
-	vector<int64_t> start, frnd, hop; // (source, vertex, distance) rows of all batches
-	idx_t offset = 0;
+	~GGShortestGlobalState() override {
+		for (auto result : batches) {
+			gg_result_destroy(result);
+		}
+	}
+	idx_t MaxThreads() override {
+		return max_threads;
+	}
+	//! one device-resident (source, vertex, distance) table per 64-source batch
+	vector<gg_result *> batches;
+	vector<idx_t> batch_rows;
+	//! seed rows of sources that are not vertices of the graph (lone_sources): served once, at the end
+	vector<int64_t> lone;
+	mutex lock;
+	idx_t batch = 0, offset = 0; // next unclaimed rows
+	idx_t lone_offset = 0;
+	idx_t max_threads = 1;
 };
 
 PhysicalGGShortestPath::PhysicalGGShortestPath(shared_ptr<GGGraph> graph_p, vector<int64_t> sources_p,
@@ -481,67 +522,94 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 			}
 		}
 	}
+	if (lone_sources && !uniq.empty()) {
+		// a source that is not a vertex of the graph reaches nothing but keeps its own seed row
+		vector<uint32_t> dense(uniq.size());
+		GGGraph::Check(gg_csr_lookup(graph->ctx, graph->csr, uniq.data(), uniq.size(), dense.data()), "gg_csr_lookup");
+		for (idx_t i = 0; i < uniq.size(); i++) {
+			if (dense[i] == 0xFFFFFFFFu) {
+				state->lone.push_back(uniq[i]);
+			}
+		}
+	}
+	idx_t total = 0;
 	for (idx_t base = 0; base < uniq.size(); base += GG_BFS_LANES) { // 64 bit lanes per batch
 		if (context.interrupted) {
 			throw InterruptException();
 		}
 		const int n = (int)MinValue<idx_t>(GG_BFS_LANES, uniq.size() - base);
-		// the reached (source, vertex, distance) rows are compacted on the device and come back in one copy
+		// the reached (source, vertex, distance) rows are compacted on the device and stay there until
+		// the pipeline threads fetch them slab by slab
 		gg_result *pairs = nullptr;
 		GGGraph::Check(gg_bfs64_pairs(graph->ctx, graph->csr, uniq.data() + base, n, max_hops, nullptr, &pairs),
 		               "gg_bfs64_pairs");
+		state->batches.push_back(pairs);
 		uint64_t rows = 0;
-		int rc = gg_result_rows(pairs, 2, &rows);
-		const idx_t before = state->start.size();
-		if (rc == GG_OK && rows) {
-			state->start.resize(before + rows);
-			state->frnd.resize(before + rows);
-			state->hop.resize(before + rows);
-			int64_t *cols[3] = {state->start.data() + before, state->frnd.data() + before, state->hop.data() + before};
-			for (uint64_t done = 0; rc == GG_OK && done < rows;) {
-				int64_t *at[3] = {cols[0] + done, cols[1] + done, cols[2] + done};
-				uint32_t got = 0;
-				rc = gg_result_fetch(pairs, 2, done, (uint32_t)MinValue<uint64_t>(rows - done, 1u << 30), at, &got);
-				done += got;
-			}
-		}
-		gg_result_destroy(pairs);
-		GGGraph::Check(rc, "gg_result_fetch");
-		if (lone_sources) {
-			// a source that is not a vertex of the graph reached nothing: only its own seed row.  Every
-			// source that IS a vertex has its (s, s, 0) row among the fetched ones.
-			unordered_set<int64_t> known;
-			for (idx_t r = before; r < state->start.size(); r++) {
-				if (state->hop[r] == 0) {
-					known.insert(state->start[r]);
-				}
-			}
-			for (int i = 0; i < n; i++) {
-				if (!known.count(uniq[base + i])) {
-					state->start.push_back(uniq[base + i]);
-					state->frnd.push_back(uniq[base + i]);
-					state->hop.push_back(0);
-				}
-			}
-		}
+		GGGraph::Check(gg_result_rows(pairs, 2, &rows), "gg_result_rows");
+		state->batch_rows.push_back(rows);
+		total += rows;
 	}
+	state->max_threads = MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
 	return move(state);
+}
+
+unique_ptr<LocalSourceState> PhysicalGGShortestPath::GetLocalSourceState(ExecutionContext &context,
+                                                                         GlobalSourceState &gstate) const {
+	return make_unique<GGResultSlab>(graph);
 }
 
 void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
                                      LocalSourceState &lstate) const {
 	auto &gstate = (GGShortestGlobalState &)gstate_p;
-	idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.start.size() - gstate.offset);
-	if (n == 0) {
-		return;
+	auto &slab = (GGResultSlab &)lstate;
+	if (context.client.interrupted) {
+		throw InterruptException();
 	}
-	memcpy(FlatVector::GetData<int64_t>(chunk.data[0]), gstate.start.data() + gstate.offset, n * sizeof(int64_t));
-	memcpy(FlatVector::GetData<int64_t>(chunk.data[1]), gstate.frnd.data() + gstate.offset, n * sizeof(int64_t));
+	if (slab.pos >= slab.rows) {
+		idx_t batch, offset, want;
+		{
+			lock_guard<mutex> guard(gstate.lock);
+			while (gstate.batch < gstate.batches.size() && gstate.offset >= gstate.batch_rows[gstate.batch]) {
+				gstate.batch++;
+				gstate.offset = 0;
+			}
+			if (gstate.batch >= gstate.batches.size()) {
+				if (gstate.lone_offset >= gstate.lone.size()) {
+					return;
+				}
+				// last: the seed rows of the sources that are not vertices
+				const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.lone.size() - gstate.lone_offset);
+				for (idx_t i = 0; i < n; i++) {
+					FlatVector::GetData<int64_t>(chunk.data[0])[i] = gstate.lone[gstate.lone_offset + i];
+					FlatVector::GetData<int64_t>(chunk.data[1])[i] = gstate.lone[gstate.lone_offset + i];
+					FlatVector::GetData<int32_t>(chunk.data[2])[i] = 0;
+				}
+				gstate.lone_offset += n;
+				chunk.SetCardinality(n);
+				return;
+			}
+			batch = gstate.batch;
+			offset = gstate.offset;
+			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.batch_rows[batch] - offset);
+			gstate.offset += want;
+		}
+		uint32_t got = 0;
+		GGGraph::Check(gg_result_fetch(gstate.batches[batch], 2, offset, (uint32_t)want, slab.Columns(3), &got),
+		               "gg_result_fetch");
+		slab.rows = got;
+		slab.pos = 0;
+		if (got == 0) {
+			return;
+		}
+	}
+	const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, slab.rows - slab.pos);
+	memcpy(FlatVector::GetData<int64_t>(chunk.data[0]), slab.column[0] + slab.pos, n * sizeof(int64_t));
+	memcpy(FlatVector::GetData<int64_t>(chunk.data[1]), slab.column[1] + slab.pos, n * sizeof(int64_t));
 	auto hops = FlatVector::GetData<int32_t>(chunk.data[2]);
 	for (idx_t i = 0; i < n; i++) {
-		hops[i] = (int32_t)gstate.hop[gstate.offset + i];
+		hops[i] = (int32_t)slab.column[2][slab.pos + i];
 	}
-	gstate.offset += n;
+	slab.pos += n;
 	chunk.SetCardinality(n);
 }
 

@@ -52,6 +52,28 @@ idx_t GGExtractKeys(DataChunk &input, const vector<idx_t> &cols, vector<vector<i
 idx_t GGKeyColumns(DataChunk &input, const vector<idx_t> &cols, vector<vector<int64_t>> &scratch,
                    vector<const int64_t *> &keys);
 
+//! A thread's window onto a device-resident result table: up to SLAB_ROWS rows of up to GG_MAX_HOPS+1
+//! int64 columns in page-locked host memory (gg_host_alloc), refilled with one copy per column and served
+//! to the pipeline in <=1024-row DataChunks.  This is the LocalSourceState of the GG sources, so several
+//! pipeline threads drain one result concurrently, each through its own slab.
+class GGResultSlab : public LocalSourceState {
+public:
+	static constexpr idx_t SLAB_ROWS = 1u << 17;
+
+	explicit GGResultSlab(shared_ptr<GGGraph> graph);
+	~GGResultSlab() override;
+
+	//! make room for `columns` columns; returns the column base pointers
+	int64_t **Columns(idx_t columns);
+
+	shared_ptr<GGGraph> graph;
+	int64_t *memory = nullptr;
+	idx_t capacity_columns = 0;
+	int64_t *column[GG_MAX_HOPS + 1];
+	idx_t rows = 0, pos = 0; // filled rows, next row to serve
+	int table = 0;           // which table of the result the slab holds (hop length / batch)
+};
+
 class PhysicalGGVertexSink : public PhysicalOperator {
 public:
 	PhysicalGGVertexSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality);
@@ -128,6 +150,8 @@ public:
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	unique_ptr<LocalSourceState> GetLocalSourceState(ExecutionContext &context,
+	                                                 GlobalSourceState &gstate) const override;
 	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
 	             LocalSourceState &lstate) const override;
 	bool IsSource() const override {
@@ -183,9 +207,14 @@ public:
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	unique_ptr<LocalSourceState> GetLocalSourceState(ExecutionContext &context,
+	                                                 GlobalSourceState &gstate) const override;
 	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
 	             LocalSourceState &lstate) const override;
 	bool IsSource() const override {
+		return true;
+	}
+	bool ParallelSource() const override {
 		return true;
 	}
 	string GetName() const override {

@@ -604,6 +604,7 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	                                                pattern.vertex_table->columns[pattern.vertex_key].name
 	                                          : string("endpoint ids")) +
 	                    (all_sources ? string() : "\nfrom " + to_string(sources[0]));
+	data->parallel_result = !count_only;
 	auto types = PhysicalGGPathExpand::OutputTypes(hops, count_only);
 	vector<column_t> column_ids;
 	vector<string> names;
@@ -1228,6 +1229,7 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	                     : all_vertices          ? vertex_table->name + " where " + seed_predicates[0]
 	                                             : to_string(seed_constants.size()) +
 	                                          (seed_constants.size() == 1 ? " id" : " ids"));
+	data->parallel_result = true;
 	vector<LogicalType> types = {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::INTEGER};
 	vector<column_t> column_ids = {0, 1, 2};
 	vector<string> names = {"startPerson", "friend", "hopCount"};

@@ -75,6 +75,11 @@ const char *gg_last_error(void);
 int gg_device_count(int *out_count);
 int gg_ctx_create(int device, gg_ctx **out);
 void gg_ctx_destroy(gg_ctx *ctx);
+/* Page-locked host memory for result slabs: gg_result_fetch into such a buffer runs at PCIe rate (into
+ * pageable memory the runtime bounces through its own staging buffers, ~5 GB/s measured).  Freed buffers
+ * are kept by the context and reused; gg_ctx_destroy releases them.  Thread-safe. */
+int gg_host_alloc(gg_ctx *ctx, uint64_t bytes, void **out);
+void gg_host_free(gg_ctx *ctx, void *ptr);
 
 /* ---- staging: base-table columns -> HBM (Sink side) -------------------------------------- */
 /* Append n vertex ids (vertex-table key column, in table order). */
@@ -106,6 +111,10 @@ int gg_csr_build(gg_ctx *ctx, gg_csr **out);
  * counts add and the digests add lane-wise.  Other operations reject a shard (GG_ERR_STATE). */
 int gg_csr_build_shard(gg_ctx *ctx, int part, int n_parts, gg_csr **out);
 void gg_csr_destroy(gg_csr *csr);
+/* Probe the CSR's id dictionary: dense_out[i] = dense index (vertex-table position) of ids[i], or
+ * 0xFFFFFFFF if ids[i] is not a vertex — what probing the build side's hash table with n keys does in the
+ * reference (JoinHashTable::Probe, src/execution/join_hashtable.cpp:304-330). */
+int gg_csr_lookup(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids, uint64_t n, uint32_t *dense_out);
 int gg_csr_info(const gg_csr *csr, uint64_t *n_vertices, uint64_t *n_edges_kept, uint64_t *n_edges_dropped);
 /* Parity export.  off: V+1 entries; nbr: E_kept dense neighbour indices; eid: E_kept edge rowids
  * (may be NULL); vid: V vertex ids by dense index (may be NULL). */

@@ -645,3 +645,26 @@ def test_concurrent_appends_across_many_staging_blocks(gg, orc, with_rowid):
     assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
     csr.close()
     g.close()
+
+
+def test_csr_lookup_and_pinned_host_buffers(gg, orc):
+    vid, src, dst = datagen.small_graph(500, 4000, 9, dangling=6)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    ids = np.concatenate([vid[::7], np.array([-3, 12345678901, np.iinfo(np.int64).min], np.int64), vid[:3]])
+    got = gg.lookup(csr, ids)
+    expect = np.asarray(g.lookup(ids), np.int64)
+    assert np.array_equal(got.astype(np.int64), np.where(expect < 0, 0xFFFFFFFF, expect))
+    assert gg.lookup(csr, np.zeros(0, np.int64)).size == 0
+    # page-locked buffers: distinct while in use, reused after free
+    a, b = gg.host_buffer(100_000), gg.host_buffer(100_000)
+    a[:] = 1
+    b[:] = 2
+    assert a.sum() == 100_000 and b.sum() == 200_000
+    pa = a.ctypes.data
+    gg.lib.gg_host_free(gg.ctx, pa)
+    c = gg.host_buffer(50_000)
+    assert c.ctypes.data == pa  # the idle block is handed out again
+    gg.lib.gg_host_free(gg.ctx, b.ctypes.data)
+    gg.lib.gg_host_free(gg.ctx, c.ctypes.data)
+    csr.close()
+    g.close()
