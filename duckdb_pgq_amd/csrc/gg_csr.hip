@@ -821,16 +821,16 @@ __global__ __launch_bounds__(256) void k_set_init(int64_t *__restrict__ set, uin
 }
 
 __global__ __launch_bounds__(256) void k_set_insert(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
-                                                    uint64_t E, int64_t *__restrict__ set, uint64_t cap,
-                                                    uint64_t limit, uint32_t max_probes,
-                                                    SetStatus *__restrict__ st) {
+                                                    uint64_t E, const int64_t *__restrict__ extra, uint64_t n_extra,
+                                                    int64_t *__restrict__ set, uint64_t cap, uint64_t limit,
+                                                    uint32_t max_probes, SetStatus *__restrict__ st) {
   __shared__ uint32_t s_new;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool inserted = false;
-  if (i < 2 * E && *(volatile unsigned long long *)&st->overflow == 0ULL) {
-    const int64_t key = i < E ? src[i] : dst[i - E];
+  if (i < 2 * E + n_extra && *(volatile unsigned long long *)&st->overflow == 0ULL) {
+    const int64_t key = i < E ? src[i] : (i < 2 * E ? dst[i - E] : extra[i - 2 * E]);
     if (key == HT_EMPTY) {
       st->has_min = 1ULL;  // benign race: every writer stores the same value
     } else {
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) void k_set_emit(const uint32_t *__restrict__ l
 
 }  // namespace gg
 
-extern "C" int gg_vertices_from_edges(gg_ctx *ctx, uint64_t *n_vertices) {
+extern "C" int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uint64_t *n_vertices) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   if (n_vertices) *n_vertices = 0;
   GG_TRY(gg_staging_sync(ctx));
@@ -919,25 +919,30 @@ extern "C" int gg_vertices_from_edges(gg_ctx *ctx, uint64_t *n_vertices) {
   GG_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const uint64_t E = ctx->n_edges;
-  ctx->n_vertices = 0;
+  const uint64_t n_old = keep_staged_vertices ? ctx->n_vertices : 0;  // ids already in the vertex table
+  if (!keep_staged_vertices) ctx->n_vertices = 0;
   ctx->fill_v = 0;
-  if (E == 0) return GG_OK;
+  if (E == 0) {
+    if (n_vertices) *n_vertices = ctx->n_vertices;
+    return GG_OK;
+  }
 
   SetStatus *st = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&st, sizeof(SetStatus)));
   // the table starts small (graphs have far fewer vertices than edge rows) and is rebuilt larger when it
   // passes half full; at cap > 2E it cannot fill, so the probe bound is lifted and the loop ends
   uint64_t cap = 1u << 16;
-  while (cap < E / 8) cap <<= 1;
+  while (cap < E / 8 + 2 * n_old) cap <<= 1;
   int64_t *set = nullptr;
   SetStatus host{};
   while (true) {
-    const bool cannot_fill = cap > 2 * E + 1;
+    const bool cannot_fill = cap > 2 * E + n_old + 1;
     GG_TRY(ctx->dev_alloc((void **)&set, cap * sizeof(int64_t)));
     GG_HIP(hipMemsetAsync(st, 0, sizeof(SetStatus), s));
     GG_LAUNCH(ctx, "set_init", k_set_init, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, set, cap);
-    GG_LAUNCH(ctx, "set_insert", k_set_insert, dim3((unsigned)((2 * E + 255) / 256)), dim3(256), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, set, cap, cannot_fill ? ~0ULL : cap / 2, cannot_fill ? 0xFFFFFFFFu : 4096u, st);
+    GG_LAUNCH(ctx, "set_insert", k_set_insert, dim3((unsigned)((2 * E + n_old + 255) / 256)), dim3(256), 0,
+              ctx->c_src.dev, ctx->c_dst.dev, E, (const int64_t *)ctx->c_vid.dev, n_old, set, cap,
+              cannot_fill ? ~0ULL : cap / 2, cannot_fill ? 0xFFFFFFFFu : 4096u, st);
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(SetStatus), hipMemcpyDeviceToHost, s));
     GG_HIP(hipStreamSynchronize(s));
     memcpy(&host, ctx->pin_scratch, sizeof(SetStatus));

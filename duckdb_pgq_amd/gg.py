@@ -95,7 +95,7 @@ def load_library(path: str | None = None):
     lib.gg_expand_khop_result.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_result_filter_common_neighbour.argtypes = [P, P, C.c_int, P, C.POINTER(P)]
     lib.gg_staging_clear_edges.argtypes = [P]
-    lib.gg_vertices_from_edges.argtypes = [P, C.POINTER(u64)]
+    lib.gg_vertices_from_edges.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
@@ -256,10 +256,11 @@ class GG:
     def staging_clear_edges(self):
         self._chk(self.lib.gg_staging_clear_edges(self.ctx))
 
-    def vertices_from_edges(self) -> int:
-        """Vertex table := distinct endpoint ids of the staged edges, ascending; returns their number."""
+    def vertices_from_edges(self, keep_staged: bool = False) -> int:
+        """Vertex table := distinct endpoint ids of the staged edges (keep_staged: united with the ids
+        already staged as vertices), ascending; returns their number."""
         n = C.c_uint64()
-        self._chk(self.lib.gg_vertices_from_edges(self.ctx, C.byref(n)))
+        self._chk(self.lib.gg_vertices_from_edges(self.ctx, int(keep_staged), C.byref(n)))
         return int(n.value)
 
     def connected_paths_same_neighbour(self, path_csr: Csr, filter_csr: Csr, hops: int, sources=None):

@@ -54,6 +54,9 @@ struct GGGraphSpec {
 //! <=1024-row chunk (concurrently for table sources), Combine, Finalize.
 void GGRunSinkPipeline(ClientContext &context, const GGScanSource &source, PhysicalOperator &sink);
 
+//! every non-NULL value of a one-column source, through the same ingest path (order unspecified)
+vector<int64_t> GGScanInt64Column(ClientContext &context, const GGScanSource &source);
+
 //! (schema.)table resolved in the catalog, or a SQL fallback `SELECT columns FROM name` for views
 GGScanSource GGTableSource(ClientContext &context, const string &table_name, const vector<string> &columns,
                            bool with_rowid);

@@ -187,6 +187,55 @@ void GGRunSinkPipeline(ClientContext &context, const GGScanSource &source, Physi
 	}
 }
 
+namespace {
+//! a sink that just collects one key column on the host (for source-vertex lists)
+class CollectGlobalState : public GlobalSinkState {
+public:
+	mutex lock;
+	vector<int64_t> values;
+};
+class CollectLocalState : public LocalSinkState {
+public:
+	vector<vector<int64_t>> scratch;
+	vector<const int64_t *> keys;
+};
+class PhysicalGGCollect : public PhysicalOperator {
+public:
+	PhysicalGGCollect() : PhysicalOperator(PhysicalOperatorType::INVALID, {LogicalType::BIGINT}, 0) {
+	}
+	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override {
+		return make_unique<CollectGlobalState>();
+	}
+	unique_ptr<LocalSinkState> GetLocalSinkState(ExecutionContext &context) const override {
+		return make_unique<CollectLocalState>();
+	}
+	SinkResultType Sink(ExecutionContext &context, GlobalSinkState &gstate_p, LocalSinkState &lstate_p,
+	                    DataChunk &input) const override {
+		auto &gstate = (CollectGlobalState &)gstate_p;
+		auto &lstate = (CollectLocalState &)lstate_p;
+		const idx_t n = GGKeyColumns(input, {0}, lstate.scratch, lstate.keys);
+		lock_guard<mutex> guard(gstate.lock);
+		gstate.values.insert(gstate.values.end(), lstate.keys[0], lstate.keys[0] + n);
+		return SinkResultType::NEED_MORE_INPUT;
+	}
+	bool IsSink() const override {
+		return true;
+	}
+	bool ParallelSink() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_COLLECT";
+	}
+};
+} // namespace
+
+vector<int64_t> GGScanInt64Column(ClientContext &context, const GGScanSource &source) {
+	PhysicalGGCollect collect;
+	GGRunSinkPipeline(context, source, collect);
+	return move(((CollectGlobalState &)*collect.sink_state).values);
+}
+
 GGScanSource GGTableSource(ClientContext &context, const string &table_name, const vector<string> &columns,
                            bool with_rowid) {
 	GGScanSource source;

@@ -222,16 +222,17 @@ SinkFinalizeType PhysicalGGVertexSink::Finalize(Pipeline &pipeline, Event &event
 }
 
 PhysicalGGEdgeSink::PhysicalGGEdgeSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
-                                       idx_t estimated_cardinality, bool as_filter_p, bool derive_vertices_p)
+                                       idx_t estimated_cardinality, bool as_filter_p, bool derive_vertices_p,
+                                       bool keep_vertices_p, bool build_p)
     : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), graph(move(graph_p)),
-      as_filter(as_filter_p), derive_vertices(derive_vertices_p) {
+      as_filter(as_filter_p), derive_vertices(derive_vertices_p), keep_vertices(keep_vertices_p), build(build_p) {
 }
 
 unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext &context) const {
 	if (as_filter) {
 		// second edge table over the same staged vertices: drop the first table's staged rows only
 		GGGraph::Check(gg_staging_clear_edges(graph->ctx), "gg_staging_clear_edges");
-	} else if (derive_vertices) {
+	} else if (derive_vertices && !keep_vertices) {
 		// no vertex sink ran before this one: start from empty staging
 		GGGraph::Check(gg_staging_clear(graph->ctx), "gg_staging_clear");
 	}
@@ -268,7 +269,10 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
 		target = nullptr;
 	}
 	if (derive_vertices) {
-		GGGraph::Check(gg_vertices_from_edges(graph->ctx, nullptr), "gg_vertices_from_edges");
+		GGGraph::Check(gg_vertices_from_edges(graph->ctx, keep_vertices ? 1 : 0, nullptr), "gg_vertices_from_edges");
+	}
+	if (!build) {
+		return SinkFinalizeType::READY;
 	}
 	GGGraph::Check(gg_csr_build(graph->ctx, &target), "gg_csr_build");
 	return SinkFinalizeType::READY;
@@ -430,9 +434,9 @@ static vector<LogicalType> BigintColumns(idx_t n) {
 }
 
 PhysicalGGFilteredPaths::PhysicalGGFilteredPaths(shared_ptr<GGGraph> graph_p, int hops_p, vector<int64_t> sources_p,
-                                                 idx_t estimated_cardinality)
+                                                 idx_t estimated_cardinality, bool all_sources_p)
     : PhysicalOperator(PhysicalOperatorType::INVALID, BigintColumns(hops_p + 2), estimated_cardinality),
-      graph(move(graph_p)), hops(hops_p), sources(move(sources_p)) {
+      graph(move(graph_p)), hops(hops_p), sources(move(sources_p)), all_sources(all_sources_p) {
 }
 
 unique_ptr<GlobalSourceState> PhysicalGGFilteredPaths::GetGlobalSourceState(ClientContext &context) const {
@@ -443,8 +447,8 @@ unique_ptr<GlobalSourceState> PhysicalGGFilteredPaths::GetGlobalSourceState(Clie
 	}
 	gg_khop_stats stats;
 	gg_result *paths = nullptr;
-	GGGraph::Check(gg_expand_khop_result(graph->ctx, graph->csr, sources.data(), sources.size(), hops, hops, &stats,
-	                                     &paths),
+	GGGraph::Check(gg_expand_khop_result(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(),
+	                                     all_sources ? 0 : sources.size(), hops, hops, &stats, &paths),
 	               "gg_expand_khop_result");
 	int rc = gg_result_filter_common_neighbour(graph->ctx, paths, hops, graph->filter_csr, &state->result);
 	gg_result_destroy(paths);

@@ -106,12 +106,18 @@ public:
 	//! GGGraph::filter_csr instead of GGGraph::csr.
 	//! derive_vertices: there is no vertex sink — the pattern is a join chain over the edge table alone
 	//! (k1.dst = k2.src), so the vertex set is the distinct endpoint ids (gg_vertices_from_edges).
+	//! keep_vertices (with derive_vertices): unite the endpoint ids with the vertex ids already staged (a
+	//! second edge table over the same id space).  build = false: Finalize stops after the vertex set —
+	//! the edge rows only contribute their endpoints (the table is ingested again for its own CSR).
 	PhysicalGGEdgeSink(shared_ptr<GGGraph> graph, vector<LogicalType> types, idx_t estimated_cardinality,
-	                   bool as_filter = false, bool derive_vertices = false);
+	                   bool as_filter = false, bool derive_vertices = false, bool keep_vertices = false,
+	                   bool build = true);
 
 	shared_ptr<GGGraph> graph;
 	bool as_filter;
 	bool derive_vertices;
+	bool keep_vertices;
+	bool build;
 
 public:
 	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
@@ -172,11 +178,12 @@ public:
 class PhysicalGGFilteredPaths : public PhysicalOperator {
 public:
 	PhysicalGGFilteredPaths(shared_ptr<GGGraph> graph, int hops, vector<int64_t> sources,
-	                        idx_t estimated_cardinality);
+	                        idx_t estimated_cardinality, bool all_sources = false);
 
 	shared_ptr<GGGraph> graph;
 	int hops;
 	vector<int64_t> sources;
+	bool all_sources; // walks may start at any vertex (no source table in the pattern)
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;

@@ -13,6 +13,8 @@
 //                   under a projection that restores the join's column layout;
 //   aggregate rule  ungrouped count(*) directly over such a subtree -> the count-only expansion (nothing
 //                   is materialised), one output row;
+//   join rule 2     walks whose vertices all share a neighbour in a second edge table (Train Benchmark
+//                   ConnectedSegments, 11 hash joins) -> PhysicalGGFilteredPaths (see PlanSameNeighbourPaths);
 //   aggregate rule 2  min(hop) GROUP BY (start, friend) over the `friends` recursive CTE of
 //                   bi-10-shortestpath.sql -> the 64-lane bitset BFS (see PlanShortestPath below).
 //
@@ -617,12 +619,353 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	                                      move(data), move(column_ids), move(names), nullptr, estimated_cardinality);
 }
 
+
+//===--------------------------------------------------------------------===//
+// Join rule 2: fixed-length walks whose vertices all share one neighbour in a second edge table
+//===--------------------------------------------------------------------===//
+// benchmark/trainbenchmark/queries/connectedsegments.sql:1-25 (BASELINE.json configs[4]):
+//
+//   FROM Segment JOIN connectsTo ct1 ON Segment.id = ct1.TE1 JOIN connectsTo ct2 ON ct1.TE2 = ct2.TE1 ... ct5
+//        JOIN monitoredBy mb1 ON mb1.TE = ct1.TE1 ... JOIN monitoredBy mb6 ON mb6.TE = ct5.TE2
+//   WHERE mb1.Sensor = mb2.Sensor AND ... AND mb1.Sensor = mb6.Sensor
+//
+// i.e. h path-edge instances forming a walk, h+1 filter-edge instances — one per walk position, keyed by
+// it — whose far ends are all equal, and optionally one instance of a uniquely keyed table pinning where
+// walks may start.  Eleven hash joins in the reference; here PhysicalGGFilteredPaths (k-hop expansion +
+// gg_result_filter_common_neighbour).  Every column of the pattern is a join key, so NULLs drop out on
+// both sides and no NOT NULL declaration is needed; the vertex set is the union of both tables' endpoint
+// ids, so no row is dropped for a missing vertex either.
+struct SameNeighbourPattern {
+	TableCatalogEntry *path_table = nullptr, *filter_table = nullptr, *source_table = nullptr;
+	column_t path_src = 0, path_dst = 0, filter_src = 0, filter_dst = 0, source_key = 0;
+	idx_t hops = 0;
+	// per leaf: what its columns mean
+	vector<idx_t> path_position;   // 1-based edge number (0: not a path leaf)
+	vector<idx_t> filter_position; // walk position the filter leaf is keyed by (INVALID_INDEX: not one)
+	idx_t source_leaf = INVALID_INDEX;
+};
+
+bool SolveSameNeighbourWithRoles(PatternInput &in, ColumnClasses &classes, SameNeighbourPattern &out) {
+	const idx_t n = in.leaves.size();
+	vector<idx_t> path_leaves, filter_leaves;
+	out.source_leaf = INVALID_INDEX;
+	for (idx_t l = 0; l < n; l++) {
+		if (in.leaves[l].table == out.path_table) {
+			path_leaves.push_back(l);
+		} else if (in.leaves[l].table == out.filter_table) {
+			filter_leaves.push_back(l);
+		} else if (in.leaves[l].table == out.source_table && out.source_leaf == INVALID_INDEX) {
+			out.source_leaf = l;
+		} else {
+			return false;
+		}
+	}
+	const idx_t hops = path_leaves.size();
+	if (hops < 1 || hops + 1 > GG_MAX_HOPS || filter_leaves.size() != hops + 1) {
+		return false;
+	}
+	// the walk: every position must be in an equality class (a filter leaf is keyed by it)
+	vector<idx_t> src_class(n, INVALID_INDEX), dst_class(n, INVALID_INDEX), successor(n, INVALID_INDEX);
+	vector<bool> has_predecessor(n, false);
+	for (auto l : path_leaves) {
+		src_class[l] = classes.ClassOf({l, out.path_src});
+		dst_class[l] = classes.ClassOf({l, out.path_dst});
+		if (src_class[l] == INVALID_INDEX || dst_class[l] == INVALID_INDEX || src_class[l] == dst_class[l]) {
+			return false;
+		}
+	}
+	for (auto a : path_leaves) {
+		for (auto b : path_leaves) {
+			if (a == b) {
+				continue;
+			}
+			if (src_class[a] == src_class[b] || dst_class[a] == dst_class[b]) {
+				return false;
+			}
+			if (dst_class[a] == src_class[b]) {
+				successor[a] = b;
+				has_predecessor[b] = true;
+			}
+		}
+	}
+	idx_t first = INVALID_INDEX;
+	for (auto l : path_leaves) {
+		if (!has_predecessor[l]) {
+			if (first != INVALID_INDEX) {
+				return false;
+			}
+			first = l;
+		}
+	}
+	if (first == INVALID_INDEX) {
+		return false;
+	}
+	out.path_position.assign(n, 0);
+	out.filter_position.assign(n, INVALID_INDEX);
+	vector<idx_t> position_class(hops + 1, INVALID_INDEX);
+	idx_t visited = 0;
+	for (idx_t l = first; l != INVALID_INDEX; l = successor[l]) {
+		if (out.path_position[l] != 0 || visited == hops) {
+			return false;
+		}
+		out.path_position[l] = ++visited;
+		position_class[visited - 1] = src_class[l];
+		position_class[visited] = dst_class[l];
+	}
+	if (visited != hops) {
+		return false;
+	}
+	for (idx_t p = 0; p <= hops; p++) { // a walk position may not coincide with another one (no cycles pinned)
+		for (idx_t q = p + 1; q <= hops; q++) {
+			if (position_class[p] == position_class[q]) {
+				return false;
+			}
+		}
+	}
+	// the filter leaves: keyed by distinct positions, far ends all in one class of their own
+	idx_t neighbour_class = INVALID_INDEX;
+	vector<bool> covered(hops + 1, false);
+	for (auto l : filter_leaves) {
+		const auto key = classes.ClassOf({l, out.filter_src});
+		const auto far = classes.ClassOf({l, out.filter_dst});
+		if (key == INVALID_INDEX || far == INVALID_INDEX) {
+			return false;
+		}
+		if (neighbour_class == INVALID_INDEX) {
+			neighbour_class = far;
+		} else if (neighbour_class != far) {
+			return false;
+		}
+		idx_t position = INVALID_INDEX;
+		for (idx_t p = 0; p <= hops; p++) {
+			if (position_class[p] == key) {
+				position = p;
+			}
+		}
+		if (position == INVALID_INDEX || covered[position]) {
+			return false;
+		}
+		covered[position] = true;
+		out.filter_position[l] = position;
+	}
+	for (idx_t p = 0; p <= hops; p++) {
+		if (position_class[p] == neighbour_class) {
+			return false;
+		}
+	}
+	// the source table, if any: its key pins walk position 0
+	if (out.source_leaf != INVALID_INDEX) {
+		if (classes.ClassOf({out.source_leaf, out.source_key}) != position_class[0] ||
+		    !ColumnIsUnique(*out.source_table, out.source_key) || !ColumnIsIntegerKey(*out.source_table, out.source_key)) {
+			return false;
+		}
+	}
+	// nothing else is equated: every member of every class has one of the roles above
+	for (idx_t i = 0; i < classes.members.size(); i++) {
+		auto &member = classes.members[i];
+		const auto cls = classes.Find(i);
+		bool ok;
+		if (out.path_position[member.leaf]) {
+			const idx_t e = out.path_position[member.leaf];
+			ok = (member.column == out.path_src && cls == position_class[e - 1]) ||
+			     (member.column == out.path_dst && cls == position_class[e]);
+		} else if (out.filter_position[member.leaf] != INVALID_INDEX) {
+			ok = (member.column == out.filter_src && cls == position_class[out.filter_position[member.leaf]]) ||
+			     (member.column == out.filter_dst && cls == neighbour_class);
+		} else {
+			ok = member.leaf == out.source_leaf && member.column == out.source_key && cls == position_class[0];
+		}
+		if (!ok) {
+			return false;
+		}
+	}
+	for (auto column : {out.path_src, out.path_dst}) {
+		if (!ColumnIsIntegerKey(*out.path_table, column)) {
+			return false;
+		}
+	}
+	for (auto column : {out.filter_src, out.filter_dst}) {
+		if (!ColumnIsIntegerKey(*out.filter_table, column)) {
+			return false;
+		}
+	}
+	out.hops = hops;
+	return true;
+}
+
+bool SolveSameNeighbourPattern(PatternInput &in, SameNeighbourPattern &out) {
+	if (in.leaves.size() < 3 || !in.constants.empty()) {
+		return false;
+	}
+	vector<TableCatalogEntry *> tables;
+	for (auto &leaf : in.leaves) {
+		if (std::find(tables.begin(), tables.end(), leaf.table) == tables.end()) {
+			tables.push_back(leaf.table);
+		}
+	}
+	if (tables.size() < 2 || tables.size() > 3) {
+		return false;
+	}
+	ColumnClasses classes;
+	for (auto &eq : in.equalities) {
+		const auto a = classes.Add(eq.first), b = classes.Add(eq.second);
+		classes.Union(a, b);
+	}
+	auto columns_used = [&](TableCatalogEntry *table) {
+		vector<column_t> used;
+		for (auto &member : classes.members) {
+			if (in.leaves[member.leaf].table == table && std::find(used.begin(), used.end(), member.column) == used.end()) {
+				used.push_back(member.column);
+			}
+		}
+		std::sort(used.begin(), used.end());
+		return used;
+	};
+	for (auto path_table : tables) {
+		for (auto filter_table : tables) {
+			if (filter_table == path_table) {
+				continue;
+			}
+			TableCatalogEntry *source_table = nullptr;
+			for (auto table : tables) {
+				if (table != path_table && table != filter_table) {
+					source_table = table;
+				}
+			}
+			auto path_columns = columns_used(path_table), filter_columns = columns_used(filter_table);
+			vector<column_t> source_columns;
+			if (source_table) {
+				source_columns = columns_used(source_table);
+				if (source_columns.size() != 1) {
+					continue;
+				}
+			}
+			if (path_columns.size() != 2 || filter_columns.size() != 2) {
+				continue;
+			}
+			for (int path_flip = 0; path_flip < 2; path_flip++) {
+				for (int filter_flip = 0; filter_flip < 2; filter_flip++) {
+					out.path_table = path_table;
+					out.filter_table = filter_table;
+					out.source_table = source_table;
+					out.path_src = path_columns[path_flip];
+					out.path_dst = path_columns[1 - path_flip];
+					out.filter_src = filter_columns[filter_flip];
+					out.filter_dst = filter_columns[1 - filter_flip];
+					out.source_key = source_table ? source_columns[0] : 0;
+					if (SolveSameNeighbourWithRoles(in, classes, out)) {
+						return true;
+					}
+				}
+			}
+		}
+	}
+	return false;
+}
+
+unique_ptr<PhysicalOperator> PlanSameNeighbourPaths(LogicalComparisonJoin &op, PatternInput &in) {
+	SameNeighbourPattern pattern;
+	if (!SolveSameNeighbourPattern(in, pattern)) {
+		return nullptr;
+	}
+	// scan columns: (w, v0, ..., vh), all BIGINT
+	auto bindings = op.GetColumnBindings();
+	if (bindings.size() != op.types.size()) {
+		return nullptr;
+	}
+	vector<unique_ptr<Expression>> select_list;
+	for (idx_t i = 0; i < bindings.size(); i++) {
+		LeafColumn column;
+		if (!ResolveLeafColumn(in, bindings[i], column)) {
+			return nullptr;
+		}
+		idx_t scan_column;
+		if (pattern.path_position[column.leaf]) {
+			if (column.column == pattern.path_src) {
+				scan_column = 1 + pattern.path_position[column.leaf] - 1;
+			} else if (column.column == pattern.path_dst) {
+				scan_column = 1 + pattern.path_position[column.leaf];
+			} else {
+				return nullptr;
+			}
+		} else if (pattern.filter_position[column.leaf] != INVALID_INDEX) {
+			if (column.column == pattern.filter_src) {
+				scan_column = 1 + pattern.filter_position[column.leaf];
+			} else if (column.column == pattern.filter_dst) {
+				scan_column = 0;
+			} else {
+				return nullptr;
+			}
+		} else if (column.leaf == pattern.source_leaf && column.column == pattern.source_key) {
+			scan_column = 1;
+		} else {
+			return nullptr;
+		}
+		if (in.leaves[column.leaf].table->columns[column.column].type != op.types[i]) {
+			return nullptr;
+		}
+		unique_ptr<Expression> ref = make_unique<BoundReferenceExpression>(LogicalType::BIGINT, scan_column);
+		if (op.types[i] != LogicalType::BIGINT) {
+			ref = make_unique<BoundCastExpression>(move(ref), op.types[i]);
+		}
+		select_list.push_back(move(ref));
+	}
+	const int hops = (int)pattern.hops;
+	const auto path = TableColumns(pattern.path_table, {pattern.path_src, pattern.path_dst});
+	const auto filter = TableColumns(pattern.filter_table, {pattern.filter_src, pattern.filter_dst});
+	GGScanSource sources;
+	if (pattern.source_table) {
+		sources = TableColumns(pattern.source_table, {pattern.source_key});
+	}
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = make_shared<GGGraph>(0);
+		const vector<LogicalType> two = {LogicalType::BIGINT, LogicalType::BIGINT};
+		// vertex set = endpoint ids of both edge tables: the path table contributes its endpoints first ...
+		PhysicalGGEdgeSink endpoints(opened.graph, two, 0, false, true, false, false);
+		GGRunSinkPipeline(context, path, endpoints);
+		// ... the filter table adds its own and builds the filter CSR over the union ...
+		PhysicalGGEdgeSink filter_sink(opened.graph, two, 0, true, true, true, true);
+		GGRunSinkPipeline(context, filter, filter_sink);
+		// ... and the path table comes back for its CSR over the same vertex numbering
+		GGGraph::Check(gg_staging_clear_edges(opened.graph->ctx), "gg_staging_clear_edges");
+		PhysicalGGEdgeSink path_sink(opened.graph, two, 0);
+		GGRunSinkPipeline(context, path, path_sink);
+		vector<int64_t> source_ids;
+		if (sources.table) {
+			source_ids = GGScanInt64Column(context, sources);
+		}
+		opened.source = make_unique<PhysicalGGFilteredPaths>(opened.graph, hops, move(source_ids), 0, sources.table == nullptr);
+	};
+	data->description = pattern.path_table->name + ": " + pattern.path_table->columns[pattern.path_src].name + " -> " +
+	                    pattern.path_table->columns[pattern.path_dst].name + "\n" + to_string(hops) +
+	                    (hops == 1 ? " hop" : " hops") + "\nall on one " + pattern.filter_table->name + "." +
+	                    pattern.filter_table->columns[pattern.filter_dst].name +
+	                    (pattern.source_table ? "\nfrom every " + pattern.source_table->name : string());
+	vector<LogicalType> types(hops + 2, LogicalType::BIGINT);
+	vector<column_t> column_ids;
+	vector<string> names;
+	for (idx_t c = 0; c < types.size(); c++) {
+		column_ids.push_back(c);
+		names.push_back(c == 0 ? "w" : "v" + to_string(c - 1));
+	}
+	g_rules_fired++;
+	auto scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_same_neighbour_walks"), move(data),
+	                                           move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
+	projection->children.push_back(move(scan));
+	return move(projection);
+}
+
 //! Join rule: the subtree's columns are walk vertices.
 unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 	PatternInput in;
 	WalkPattern pattern;
-	if (!CollectJoinTree(op, in) || !SolveWalkPattern(in, pattern)) {
+	if (!CollectJoinTree(op, in)) {
 		return nullptr;
+	}
+	if (!SolveWalkPattern(in, pattern)) {
+		return PlanSameNeighbourPaths(op, in);
 	}
 	// output layout of the join: map every column to a walk position
 	auto bindings = op.GetColumnBindings();

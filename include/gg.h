@@ -175,9 +175,11 @@ int gg_staging_clear_edges(gg_ctx *ctx);
  * (signed) order — the vertex set a join chain over the edge table ALONE ranges over
  * (`knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id`, benchmark/ldbc/queries/
  * interactive-complex-3.sql:9-11: no vertex table in the pattern, so every id that occurs is a vertex
- * and no edge row is dropped).  Computed on the device (hash set + radix sort); *n_vertices (nullable)
- * receives the number of distinct ids. */
-int gg_vertices_from_edges(gg_ctx *ctx, uint64_t *n_vertices);
+ * and no edge row is dropped).  keep_staged_vertices != 0: the new table is the UNION of the ids already
+ * staged as vertices and the endpoints (several edge tables over one id space: derive from the first,
+ * gg_staging_clear_edges, stage the next, derive again with keep).  Computed on the device (hash set +
+ * radix sort); *n_vertices (nullable) receives the number of distinct ids. */
+int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uint64_t *n_vertices);
 
 /* ---- 64-lane bitset BFS (shortest path length) --------------------------------------------- */
 typedef struct gg_bfs_stats {

@@ -252,3 +252,46 @@ def test_plan_rule_friends_cte_gives_the_reference_result(db):
     every = keyed(R.sql_shortest([0], 2)).replace("WHERE p_personid IN (0)", "")
     cpu, gpu = both(every)
     assert cpu.shape[0] > vid.size and np.array_equal(cpu, gpu)
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_plan_rule_connectedsegments_query_text():
+    """BASELINE.json configs[4]: the reference's own ConnectedSegments text (11 hash joins), planned by the
+    reference and by the same-neighbour rule (one GPU operator): both give the golden rows at SF1 and the
+    same relation on a 16-fold replica; shorter walks too."""
+    from tests import trainbenchmark as tb
+    from tests.test_plan_rule import connectedsegments_sql
+
+    def both(d, sql):
+        d.execute("PRAGMA disable_gpu_graph")
+        cpu = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        assert "GG_SAME_NEIGHBOUR_WALKS" in d.explain(sql) and "HASH_JOIN" not in d.explain(sql)
+        gpu = d.execute(sql)
+        d.execute("PRAGMA disable_gpu_graph")
+        return sort_rows(cpu), sort_rows(gpu)
+
+    for copies in (1, 16):
+        t = tb.tables()
+        if copies > 1:
+            rep = datagen.replicate_tables({"Segment": t["Segment"][:, :1], "connectsTo": t["connectsTo"],
+                                            "monitoredBy": t["monitoredBy"]}, copies)
+            t = {"Segment": np.hstack([rep["Segment"].reshape(-1, 1), np.ones((rep["Segment"].size, 1), np.int64)]),
+                 "connectsTo": rep["connectsTo"], "monitoredBy": rep["monitoredBy"]}
+        d = R.RefDuckDB(threads=4)
+        d.execute("CREATE TABLE Segment (id int NOT NULL, length int NOT NULL DEFAULT 1, PRIMARY KEY (id))")
+        d.execute("CREATE TABLE connectsTo (TrackElement1_id int NOT NULL, TrackElement2_id int NOT NULL)")
+        d.execute("CREATE TABLE monitoredBy (TrackElement_id int NOT NULL, Sensor_id int NOT NULL)")
+        for name, cols in (("Segment", "id, length"), ("connectsTo", "TrackElement1_id, TrackElement2_id"),
+                           ("monitoredBy", "TrackElement_id, Sensor_id")):
+            d.load_table("stage_" + name, {c.strip(): t[name][:, i] for i, c in enumerate(cols.split(","))})
+            d.execute(f"INSERT INTO {name} SELECT {cols} FROM stage_{name}")  # BIGINT staging -> INT columns
+        d.execute(f"LOAD '{EXT}'")
+        cpu, gpu = both(d, connectedsegments_sql())
+        assert np.array_equal(cpu, gpu) and cpu.shape[0] == 4 * copies
+        if copies == 1:
+            assert np.array_equal(gpu, sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN))
+        for hops in (1, 3):
+            cpu, gpu = both(d, connectedsegments_sql(hops))
+            assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu)
+        d.close()

@@ -668,3 +668,29 @@ def test_csr_lookup_and_pinned_host_buffers(gg, orc):
     gg.lib.gg_host_free(gg.ctx, c.ctypes.data)
     csr.close()
     g.close()
+
+
+def test_vertices_from_edges_unions_with_staged_vertices(gg, orc):
+    """Two edge tables over one id space (ConnectedSegments: connectsTo and monitoredBy): derive from the
+    first, clear the edges, stage the second, derive again keeping what is there."""
+    _, s1, d1 = datagen.small_graph(300, 2000, 21)
+    _, s2, d2 = datagen.small_graph(500, 1500, 22)
+    gg.staging_clear()
+    gg.append_edges(s1, d1)
+    n1 = gg.vertices_from_edges()
+    assert n1 == np.unique(np.concatenate([s1, d1])).size
+    gg.staging_clear_edges()
+    gg.append_edges(s2, d2)
+    n2 = gg.vertices_from_edges(keep_staged=True)
+    expect = np.unique(np.concatenate([s1, d1, s2, d2]))
+    assert n2 == expect.size
+    csr = gg.build_csr()
+    _, _, _, vid = csr.export()
+    assert np.array_equal(vid, expect) and csr.E == s2.size
+    csr.close()
+    # keep with nothing staged before == plain derive; keep with no edges keeps the table as it is
+    gg.staging_clear()
+    gg.append_edges(s1, d1)
+    assert gg.vertices_from_edges(keep_staged=True) == n1
+    gg.staging_clear_edges()
+    assert gg.vertices_from_edges(keep_staged=True) == n1

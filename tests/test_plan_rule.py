@@ -168,3 +168,73 @@ def test_other_recursive_ctes_are_left_alone(db, sql):
     db.execute("PRAGMA enable_gpu_graph")
     plan = db.explain(sql)
     assert "GG_" not in plan and "REC_CTE" in plan, plan
+
+
+# ---- walks whose vertices share a neighbour in a second edge table (Train Benchmark ConnectedSegments) ----
+def connectedsegments_sql(hops=5, segment="INNER JOIN", extra=""):
+    """benchmark/trainbenchmark/queries/connectedsegments.sql:1-25, generalised over the walk length."""
+    cols = ", ".join(f"ct{i}.TrackElement1_id AS segment{i}" for i in range(1, hops + 1))
+    sql = f"SELECT mb1.Sensor_id AS sensor, {cols}, ct{hops}.TrackElement2_id AS segment{hops + 1}\nFROM Segment\n"
+    sql += f"{segment} connectsTo as ct1 ON Segment.id = ct1.TrackElement1_id\n"
+    for i in range(2, hops + 1):
+        sql += f"INNER JOIN connectsTo as ct{i} ON ct{i-1}.TrackElement2_id = ct{i}.TrackElement1_id\n"
+    for i in range(1, hops + 1):
+        sql += f"INNER JOIN monitoredBy as mb{i} ON mb{i}.TrackElement_id = ct{i}.TrackElement1_id\n"
+    sql += f"INNER JOIN monitoredBy as mb{hops + 1} ON mb{hops + 1}.TrackElement_id = ct{hops}.TrackElement2_id\n"
+    sql += "WHERE " + " AND ".join(f"mb1.Sensor_id = mb{i}.Sensor_id" for i in range(2, hops + 2)) + extra
+    return sql
+
+
+@pytest.fixture(scope="module")
+def traindb():
+    from tests import trainbenchmark as tb
+
+    d = R.RefDuckDB(threads=2)
+    # benchmark/trainbenchmark/schema.sql (load.sql:3,10-11): INT ids, primary keys
+    d.execute("CREATE TABLE Segment (id int NOT NULL, length int NOT NULL DEFAULT 1, PRIMARY KEY (id))")
+    d.execute("CREATE TABLE connectsTo (TrackElement1_id int NOT NULL, TrackElement2_id int NOT NULL, "
+              "PRIMARY KEY (TrackElement1_id, TrackElement2_id))")
+    d.execute("CREATE TABLE monitoredBy (TrackElement_id int NOT NULL, Sensor_id int NOT NULL, "
+              "PRIMARY KEY (TrackElement_id, Sensor_id))")
+    for name, rows in tb.tables().items():
+        for i in range(0, rows.shape[0], 500):
+            d.execute(f"INSERT INTO {name} VALUES " +
+                      ", ".join("(" + ", ".join(str(int(x)) for x in r) + ")" for r in rows[i:i + 500]))
+    d.execute(f"LOAD '{EXT}'")
+    yield d
+    d.execute("PRAGMA disable_gpu_graph")
+    d.close()
+
+
+def test_connectedsegments_query_text_becomes_one_operator(traindb):
+    traindb.execute("PRAGMA enable_gpu_graph")
+    plan = traindb.explain(connectedsegments_sql())
+    assert "GG_SAME_NEIGHBOUR_WALKS" in plan and "HASH_JOIN" not in plan, plan
+    flat = " ".join(plan.replace("│", " ").split())
+    assert "5 hops" in flat and "from every segment" in flat
+    for hops in (1, 2, 6):
+        assert "GG_SAME_NEIGHBOUR_WALKS" in traindb.explain(connectedsegments_sql(hops))
+    # without the Segment table: walks may start anywhere
+    no_source = connectedsegments_sql(2).replace("FROM Segment\nINNER JOIN connectsTo as ct1 ON Segment.id = ct1.TrackElement1_id",
+                                                  "FROM connectsTo as ct1")
+    plan = traindb.explain(no_source)
+    assert "GG_SAME_NEIGHBOUR_WALKS" in plan and "from every" not in " ".join(plan.replace("│", " ").split())
+
+
+@pytest.mark.parametrize("sql", [
+    connectedsegments_sql(2, extra=" AND ct1.TrackElement1_id > 5"),                    # another predicate
+    connectedsegments_sql(2).replace("mb1.Sensor_id = mb3.Sensor_id", "mb1.Sensor_id = mb3.TrackElement_id"),
+    connectedsegments_sql(2).replace("mb3.TrackElement_id = ct2.TrackElement2_id", "mb3.TrackElement_id = ct2.TrackElement1_id"),
+    connectedsegments_sql(2, segment="LEFT JOIN"),
+])
+def test_near_misses_of_the_same_neighbour_pattern_are_left_alone(traindb, sql):
+    traindb.execute("PRAGMA enable_gpu_graph")
+    assert "GG_SAME_NEIGHBOUR_WALKS" not in traindb.explain(sql)
+
+
+def test_payload_column_keeps_its_join_on_the_cpu(traindb):
+    """Segment.length is not a key: the join with Segment stays a hash join, the walk part below it (which
+    the reference's join order keeps together) is still substituted."""
+    traindb.execute("PRAGMA enable_gpu_graph")
+    plan = traindb.explain(connectedsegments_sql(2).replace("mb1.Sensor_id AS sensor", "Segment.length AS sensor"))
+    assert "HASH_JOIN" in plan
