@@ -57,10 +57,20 @@ class RefDuckDB:
         self.threads = threads or os.cpu_count() or 1
         self.execute(f"PRAGMA threads={self.threads}")
 
+    def connect(self) -> "RefDuckDB":
+        """A second connection to the same database (for concurrent statements)."""
+        other = object.__new__(RefDuckDB)
+        other.hook, other.L, other.G, other.db, other.threads = self.hook, self.L, self.G, self.db, self.threads
+        other.con = C.c_void_p()
+        assert self.L.duckdb_connect(self.db, C.byref(other.con)) == 0
+        other._owns_db = False
+        return other
+
     def close(self):
         if self.con:
             self.L.duckdb_disconnect(C.byref(self.con))
-            self.L.duckdb_close(C.byref(self.db))
+            if getattr(self, "_owns_db", True):
+                self.L.duckdb_close(C.byref(self.db))
             self.con = None
 
     def execute(self, sql: str) -> np.ndarray:

@@ -295,3 +295,51 @@ def test_plan_rule_connectedsegments_query_text():
             cpu, gpu = both(d, connectedsegments_sql(hops))
             assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu)
         d.close()
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_plan_rule_prepared_statements_and_concurrent_connections(db):
+    import threading
+
+    d, _ = db
+    d.execute("CREATE TABLE pe (a BIGINT NOT NULL, b BIGINT NOT NULL)")
+    d.execute("INSERT INTO pe SELECT k_person1id, k_person2id FROM knows LIMIT 20000")
+    sql = "SELECT count(*) FROM pe k1, pe k2 WHERE k1.b = k2.a"
+    expect = int(d.execute(sql)[0, 0])  # rules off: the reference's hash join
+    d.execute("PRAGMA enable_gpu_graph")
+    # planned once (with the rule), executed many times: every execution re-reads the table
+    d.execute("PREPARE walks AS " + sql)
+    d.execute("PRAGMA disable_gpu_graph")  # the prepared plan keeps its GPU operator
+    assert int(d.execute("EXECUTE walks")[0, 0]) == expect
+    d.execute("INSERT INTO pe SELECT k_person1id, k_person2id FROM knows LIMIT 5000 OFFSET 20000")
+    more = int(d.execute(sql)[0, 0])
+    assert more > expect and int(d.execute("EXECUTE walks")[0, 0]) == more
+
+    # statements on several connections at once: each takes its own device context from the pool
+    d.execute("PRAGMA enable_gpu_graph")
+    results, errs = [], []
+
+    def work():
+        try:
+            c = d.connect()
+            for _ in range(4):
+                results.append(int(c.execute(sql)[0, 0]))
+            c.close()
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=work) for _ in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    d.execute("PRAGMA disable_gpu_graph")
+    assert not errs and results == [more] * 12
+
+    # the prepared plan depends on the table: dropping it must not leave a dangling plan that runs
+    try:
+        d.execute("DROP TABLE pe")
+        dropped = True
+    except RuntimeError:
+        dropped = False  # the reference refuses the drop while a prepared statement depends on it
+    if dropped:
+        with pytest.raises(RuntimeError):
+            d.execute("EXECUTE walks")
