@@ -113,6 +113,67 @@ constexpr int RB_TILE = RB_THREADS * RB_ITEMS;     // 4096 elements per workgrou
 constexpr int RB_WTILE = RB_TILE / RB_WAVES;       // 1024 per wave
 constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
 
+// ---- direct-address id dictionary -------------------------------------------------------------------
+// The reference switches its join to a perfect hash table — an array indexed by key - min — when the build
+// keys are integers spanning at most 1 000 000 values (CheckForPerfectJoinOpt, src/execution/
+// physical_plan/plan_comparison_join.cpp:35-107; PerfectHashJoinExecutor::BuildPerfectHashTable,
+// src/execution/operator/join/perfect_hash_join_executor.cpp:24-65).  Same idea for the id -> dense index
+// dictionary: if the vertex ids span at most DIRECT_MAX_RANGE values the edge densification reads a
+// uint32 array indexed by id - min (<= 4 MiB: it stays in an XCD's 4 MiB L2, unlike the 16-byte-slot hash
+// table) instead of probing.  Decided on the device from the ids' min/max: no host synchronisation.
+constexpr uint64_t DIRECT_MAX_RANGE = 1u << 20;
+
+struct DirectMap {
+  long long min_id;              // INT64_MAX until k_id_minmax ran
+  long long max_id;
+  unsigned long long enabled;    // ids span <= DIRECT_MAX_RANGE values
+};
+
+__global__ __launch_bounds__(256) void k_id_minmax(const int64_t *__restrict__ vid, uint64_t V,
+                                                   DirectMap *__restrict__ dm) {
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (uint64_t)gridDim.x * blockDim.x) {
+    const long long x = vid[i];
+    lo = x < lo ? x : lo;
+    hi = x > hi ? x : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&dm->min_id, lo);
+    atomicMax(&dm->max_id, hi);
+  }
+}
+
+__global__ void k_direct_decide(DirectMap *__restrict__ dm, uint64_t V) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t span = (uint64_t)dm->max_id - (uint64_t)dm->min_id;  // exact in unsigned arithmetic
+    dm->enabled = (V > 0 && dm->max_id >= dm->min_id && span < DIRECT_MAX_RANGE) ? 1ULL : 0ULL;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_direct_init(uint32_t *__restrict__ dir, const DirectMap *__restrict__ dm) {
+  if (!dm->enabled) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < DIRECT_MAX_RANGE) dir[i] = INVALID_U32;
+}
+
+__global__ __launch_bounds__(256) void k_direct_fill(const int64_t *__restrict__ vid, uint64_t V,
+                                                     uint32_t *__restrict__ dir, const DirectMap *__restrict__ dm) {
+  if (!dm->enabled) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < V) dir[(uint64_t)vid[i] - (uint64_t)dm->min_id] = (uint32_t)i;  // duplicate ids: the hash insert reports them
+}
+
+__device__ __forceinline__ uint32_t direct_lookup(const uint32_t *__restrict__ dir, uint64_t min_id, int64_t key) {
+  const uint64_t off = (uint64_t)key - min_id;
+  return off < DIRECT_MAX_RANGE ? dir[off] : INVALID_U32;
+}
+
 // Densify + pass-0 histogram.  One lane per edge row: two id lookups (hash table is V-sized, L2 /
 // Infinity-Cache resident), dense endpoints written coalesced, digit counted in the tile's LDS histogram.
 // counts[digit * nblocks + block] = number of valid elements of that tile with that digit
@@ -120,6 +181,8 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__re
                                                              const int64_t *__restrict__ dst, uint64_t E,
                                                              const HtSlot *__restrict__ ht, uint64_t cap,
                                                              const BuildStatus *__restrict__ st,
+                                                             const uint32_t *__restrict__ dir,
+                                                             const DirectMap *__restrict__ dm,
                                                              uint32_t *__restrict__ fk, uint32_t *__restrict__ fv,
                                                              uint32_t bits, uint64_t nblocks,
                                                              uint32_t *__restrict__ counts) {
@@ -129,6 +192,40 @@ __global__ __launch_bounds__(RB_THREADS) void k_densify_hist(const int64_t *__re
   __syncthreads();
   const int64_t min_idx = st->min_idx;
   const uint64_t base = (uint64_t)blockIdx.x * RB_TILE;
+  if (dm->enabled) {  // uniform over the grid: dense ids, one 4-byte read per endpoint
+    const uint64_t min_id = (uint64_t)dm->min_id;
+    int64_t ks[RB_ITEMS], kd[RB_ITEMS];
+    uint32_t us[RB_ITEMS], vs[RB_ITEMS];
+#pragma unroll
+    for (int it = 0; it < RB_ITEMS; it++) {  // all row loads first, then all dictionary reads
+      const uint64_t e = base + (uint64_t)it * RB_THREADS + threadIdx.x;
+      ks[it] = e < E ? src[e] : 0;
+      kd[it] = e < E ? dst[e] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < RB_ITEMS; it++) {
+      const uint64_t e = base + (uint64_t)it * RB_THREADS + threadIdx.x;
+      us[it] = e < E ? direct_lookup(dir, min_id, ks[it]) : INVALID_U32;
+      vs[it] = e < E ? direct_lookup(dir, min_id, kd[it]) : INVALID_U32;
+    }
+#pragma unroll
+    for (int it = 0; it < RB_ITEMS; it++) {
+      const uint64_t e = base + (uint64_t)it * RB_THREADS + threadIdx.x;
+      if (e >= E) continue;
+      uint32_t u = us[it], v = vs[it];
+      if (u == INVALID_U32 || v == INVALID_U32) {
+        u = INVALID_U32;
+        v = INVALID_U32;
+      } else {
+        atomicAdd(&hist[u & (ndig - 1)], 1u);
+      }
+      fk[e] = u;
+      fv[e] = v;
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < ndig; d += RB_THREADS) counts[(uint64_t)d * nblocks + blockIdx.x] = hist[d];
+    return;
+  }
   constexpr int B = 4;  // edges per batch: 2*B independent first-probe loads in flight per lane
   for (int it0 = 0; it0 < RB_ITEMS; it0 += B) {
     int64_t ks[B], kd[B];
@@ -689,8 +786,26 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
       RadixIO ior{rk, rv, nullptr, rkey_sorted, csr->rnbr, nullptr};
       GG_TRY(radix_sort_stable(ctx, ior, E, false, false, key_bits, counts0r, bits0, kept_rev_dev, false, tvr));
     } else {
+      // direct-address dictionary for dense ids (decided on the device; see DirectMap)
+      DirectMap *dm = nullptr;
+      uint32_t *dir = nullptr;
+      GG_TRY(ctx->dev_alloc((void **)&dm, sizeof(DirectMap)));
+      GG_TRY(ctx->dev_alloc((void **)&dir, DIRECT_MAX_RANGE * sizeof(uint32_t)));
+      const DirectMap dm_init{INT64_MAX, INT64_MIN, 0ULL};
+      memcpy(ctx->pin_scratch + 8, &dm_init, sizeof(dm_init));  // (the first words carry the BuildStatus seed)
+      GG_HIP(hipMemcpyAsync(dm, ctx->pin_scratch + 8, sizeof(dm_init), hipMemcpyHostToDevice, s));
+      if (V) {
+        const unsigned mm_blocks = (unsigned)(V + 255) / 256 < 1024u ? (unsigned)((V + 255) / 256) : 1024u;
+        GG_LAUNCH(ctx, "id_minmax", k_id_minmax, dim3(mm_blocks), dim3(256), 0, csr->vid, V, dm);
+      }
+      GG_LAUNCH(ctx, "direct_decide", k_direct_decide, dim3(1), dim3(64), 0, dm, V);
+      GG_LAUNCH(ctx, "direct_init", k_direct_init, dim3((unsigned)(DIRECT_MAX_RANGE / 256)), dim3(256), 0, dir, dm);
+      if (V)
+        GG_LAUNCH(ctx, "direct_fill", k_direct_fill, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, dir,
+                  dm);
       GG_LAUNCH(ctx, "densify_hist", k_densify_hist, dim3(nblocks), dim3(RB_THREADS), 0, ctx->c_src.dev,
-                ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, su, dv, (uint32_t)bits0, nblocks64, counts0);
+                ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const DirectMap *)dm, su, dv,
+                (uint32_t)bits0, nblocks64, counts0);
       // ---- stable radix scatter by source: (u, v, position) -> (row, nbr, epos) ------------------------
       const bool rowid = ctx->keep_edge_rowid;
       RadixIO io{su, dv, nullptr, csr->row, csr->nbr, rowid ? csr->epos : nullptr};

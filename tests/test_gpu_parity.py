@@ -694,3 +694,33 @@ def test_vertices_from_edges_unions_with_staged_vertices(gg, orc):
     assert gg.vertices_from_edges(keep_staged=True) == n1
     gg.staging_clear_edges()
     assert gg.vertices_from_edges(keep_staged=True) == n1
+
+
+@pytest.mark.parametrize("name,ids", [
+    ("dense_from_zero", np.arange(5000, dtype=np.int64)),
+    ("dense_negative_offset", np.arange(5000, dtype=np.int64) * 3 - 7000),
+    ("span_just_inside", np.concatenate([np.arange(4000, dtype=np.int64), [(1 << 20) - 1]])),
+    ("span_just_outside", np.concatenate([np.arange(4000, dtype=np.int64), [1 << 20]])),
+    ("around_int64_min", np.arange(3000, dtype=np.int64) + np.iinfo(np.int64).min),
+    ("both_extremes", np.array([np.iinfo(np.int64).min, -1, 0, 1, np.iinfo(np.int64).max], np.int64)),
+])
+def test_dense_vertex_ids_take_the_direct_address_dictionary(gg, orc, name, ids):
+    """Vertex ids spanning < 2^20 values are densified through an array indexed by id - min (the reference's
+    perfect-hash-join case, plan_comparison_join.cpp:35-107); wider spans through the hash table.  Either
+    way the CSR must be the oracle's, including edges whose endpoints fall outside [min, max]."""
+    rng = np.random.default_rng(len(name))
+    vid = ids[rng.permutation(ids.size)]
+    E = 20 * vid.size
+    src = vid[rng.integers(0, vid.size, E)]
+    dst = vid[rng.integers(0, vid.size, E)]
+    # dangling endpoints: below min, above max, and inside the span but not a vertex
+    inside = np.setdiff1d(np.arange(int(vid.min()), int(vid.min()) + 50, dtype=np.int64), vid)[:5]
+    extra = np.concatenate([inside, [np.iinfo(np.int64).max - 5, np.iinfo(np.int64).min + 5]]).astype(np.int64)
+    extra = extra[~np.isin(extra, vid)]
+    src = np.concatenate([src, extra, vid[: extra.size]])
+    dst = np.concatenate([dst, vid[: extra.size], extra])
+    csr, g = build_both(gg, orc, vid, src, dst)
+    assert_csr_equal(csr, g)
+    assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
+    csr.close()
+    g.close()
