@@ -143,7 +143,17 @@ __global__ __launch_bounds__(256) void k_id_minmax(const int64_t *__restrict__ v
     lo = l2 < lo ? l2 : lo;
     hi = h2 > hi ? h2 : hi;
   }
+  __shared__ long long s_lo[4], s_hi[4];
   if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one pair of atomics per workgroup: same-address 64-bit atomics serialise
+    for (int w = 1; w < 4; w++) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
     atomicMin(&dm->min_id, lo);
     atomicMax(&dm->max_id, hi);
   }
@@ -795,7 +805,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
       memcpy(ctx->pin_scratch + 8, &dm_init, sizeof(dm_init));  // (the first words carry the BuildStatus seed)
       GG_HIP(hipMemcpyAsync(dm, ctx->pin_scratch + 8, sizeof(dm_init), hipMemcpyHostToDevice, s));
       if (V) {
-        const unsigned mm_blocks = (unsigned)(V + 255) / 256 < 1024u ? (unsigned)((V + 255) / 256) : 1024u;
+        const unsigned mm_blocks = (V + 255) / 256 < 64 ? (unsigned)((V + 255) / 256) : 64u;
         GG_LAUNCH(ctx, "id_minmax", k_id_minmax, dim3(mm_blocks), dim3(256), 0, csr->vid, V, dm);
       }
       GG_LAUNCH(ctx, "direct_decide", k_direct_decide, dim3(1), dim3(64), 0, dm, V);

@@ -138,6 +138,8 @@ struct gg_ctx {
   std::vector<uint64_t> prof_launches;
   std::vector<double> prof_ms;
   std::vector<gg::ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_event_pool;   // events are reused: creating two per launch costs more than timing
+  std::vector<std::string> prof_selected;    // gg_profile_select: time only these kernels (empty: all)
 
   // small pinned scratch for D2H of counters
   uint64_t *pin_scratch = nullptr;  // 64 x u64

@@ -101,7 +101,21 @@ void gg_ctx::dev_free(void *p) {
 // ------------------------------------------------------------------------------------------
 // event timing on the library's stream
 // ------------------------------------------------------------------------------------------
+static bool take_event(gg_ctx *ctx, hipEvent_t *ev) {
+  if (!ctx->prof_event_pool.empty()) {
+    *ev = ctx->prof_event_pool.back();
+    ctx->prof_event_pool.pop_back();
+    return true;
+  }
+  return hipEventCreate(ev) == hipSuccess;
+}
+
 int gg_ctx::prof_begin(const char *name) {
+  if (!prof_selected.empty()) {
+    bool wanted = false;
+    for (auto &s : prof_selected) wanted = wanted || s == name;
+    if (!wanted) return -1;
+  }
   int idx = -1;
   for (size_t i = 0; i < prof_names.size(); i++)
     if (prof_names[i] == name) {
@@ -116,7 +130,11 @@ int gg_ctx::prof_begin(const char *name) {
   }
   ProfRec r;
   r.name_idx = idx;
-  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return -1;
+  if (!take_event(this, &r.start)) return -1;
+  if (!take_event(this, &r.stop)) {
+    prof_event_pool.push_back(r.start);
+    return -1;
+  }
   (void)hipEventRecord(r.start, stream);
   prof_pending.push_back(r);
   return (int)prof_pending.size() - 1;
@@ -131,10 +149,27 @@ int gg_ctx::prof_flush() {
       prof_ms[r.name_idx] += ms;
       prof_launches[r.name_idx] += 1;
     }
-    (void)hipEventDestroy(r.start);
-    (void)hipEventDestroy(r.stop);
+    prof_event_pool.push_back(r.start);
+    prof_event_pool.push_back(r.stop);
   }
   prof_pending.clear();
+  return GG_OK;
+}
+
+extern "C" int gg_profile_select(gg_ctx *ctx, const char *names) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  GG_TRY(ctx->prof_flush());
+  ctx->prof_selected.clear();
+  if (!names) return GG_OK;
+  std::string all(names), cur;
+  for (char c : all + ",") {
+    if (c == ',') {
+      if (!cur.empty()) ctx->prof_selected.push_back(cur);
+      cur.clear();
+    } else if (c != ' ') {
+      cur.push_back(c);
+    }
+  }
   return GG_OK;
 }
 
@@ -226,6 +261,7 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
     if (ctx->eblk[i].free_ev) (void)hipEventDestroy(ctx->eblk[i].free_ev);
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
+  for (auto ev : ctx->prof_event_pool) (void)hipEventDestroy(ev);
   for (auto &h : ctx->host_blocks)
     if (h.ptr) (void)hipHostFree(h.ptr);
   // staged columns are plain hipMalloc (they grow by doubling, outside the block cache)

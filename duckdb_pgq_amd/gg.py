@@ -22,7 +22,7 @@ SYMBOLS = [
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
-    "gg_profile_enable", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
+    "gg_profile_enable", "gg_profile_select", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library(path: str | None = None):
     lib.gg_csr_lookup.argtypes = [P, P, i64p, u64, C.POINTER(C.c_uint32)]
     lib.gg_bfs64_pairs.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
     lib.gg_profile_enable.argtypes = [P, C.c_int]
+    lib.gg_profile_select.argtypes = [P, C.c_char_p]
     lib.gg_profile_reset.argtypes = [P]
     lib.gg_profile_count.argtypes = [P, C.POINTER(C.c_int)]
     lib.gg_profile_get.argtypes = [P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double)]
@@ -360,6 +361,10 @@ class GG:
     # ---- profiling
     def profile(self, on: bool):
         self._chk(self.lib.gg_profile_enable(self.ctx, int(on)))
+
+    def profile_select(self, names=None):
+        """Time only these kernels (list of names; None: all)."""
+        self._chk(self.lib.gg_profile_select(self.ctx, None if names is None else ",".join(names).encode()))
 
     def profile_reset(self):
         self._chk(self.lib.gg_profile_reset(self.ctx))

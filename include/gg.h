@@ -213,6 +213,10 @@ int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n
 int gg_debug_force_frontier(gg_ctx *ctx, int on);
 
 int gg_profile_enable(gg_ctx *ctx, int on);
+/* Time only the kernels named in the comma-separated list (NULL: every kernel).  Two event records per
+ * launch are not free — ~35 launches per build + expansion cost 0.3 ms of a 3.9 ms step — so a timed
+ * region restricts them to the kernels it reports on. */
+int gg_profile_select(gg_ctx *ctx, const char *names);
 int gg_profile_reset(gg_ctx *ctx);
 /* Number of distinct kernels seen; then per index: name, launches, total milliseconds. */
 int gg_profile_count(gg_ctx *ctx, int *n);
