@@ -4,9 +4,10 @@
 One "step" = one pass of the hot path over the synthetic LDBC-shaped tables already resident in HBM:
     gg_csr_build (densify ids, histogram, scan, stable radix scatter)  +  gg_expand_khop_range(1..2)
 i.e. what the reference does per query as hash-join build + probe chain.  With N > 1 ranks the
-vertices are hash-partitioned (owner = hash(person id) mod N); every rank holds the same staged base
-tables, builds only the CSR rows of the vertices it owns (gg_csr_build_shard) and produces the walks
-whose middle vertex it owns; there is no data-path collective, only one small all-reduce of
+vertices are hash-partitioned (owner = hash(person id) mod N) and so is the edge table: a rank holds the
+`knows` rows whose source or destination it owns (every row on at most two ranks; the 3.6 MB person
+table is replicated), builds only the CSR rows of the vertices it owns (gg_csr_build_shard) and produces
+the walks whose middle vertex it owns; there is no data-path collective, only one small all-reduce of
 (rows, digest, TE) per step, so `value` = total traversed edges of the whole query / max-over-ranks
 time ("strong" scaling: the query is fixed, ranks split it).
 
@@ -14,8 +15,8 @@ time ("strong" scaling: the query is fixed, ranks split it).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (expand_fused2; algorithmic bytes = 8*TE + 16*frontier entries, SURVEY.md §8d, divided by
-the kernel's average duration measured with HIP events on the library's own stream) and
+kernel (largest total time among densify / radix scatter / expansion; algorithmic bytes per SURVEY.md
+§8d divided by the kernel's average duration measured with HIP events on the library's own stream) and
 `cpu_baseline` (the compiled reference — oracle/_ref/libduckdb.so — or, if absent, the C oracle,
 timed on this box's host cores on a bounded sample of the same workload).
 """
@@ -39,7 +40,7 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(vid, src, dst, gg, csr, V, total_te, want_seconds=15.0):
+def cpu_baseline(vid, src, dst, V, want_seconds=15.0, with_reference=True):
     """Timed CPU path on a bounded sample (sources = first S vertices in table order).
 
     kind "reference": the compiled reference runs the 1-hop and 2-hop join chains (count(*)) with all
@@ -65,6 +66,8 @@ def cpu_baseline(vid, src, dst, gg, csr, V, total_te, want_seconds=15.0):
     out["oracle_stats"] = ost
     oracle_off = g.arrays()[0]
     g.close()
+    if not with_reference:  # N > 1: only the parity check of the combined result; the baseline is an N = 1 figure
+        return out
     if not R.available():
         out["cpu_baseline"] = port
         return out
@@ -165,6 +168,14 @@ def main():
     vid, src, dst = pkg.datagen.ldbc(args.workload)
     t_gen = time.perf_counter() - t0
     V, R = vid.size, src.size
+    # N > 1: the edge table is hash-partitioned across the GPUs by endpoint ownership — a rank holds the
+    # rows whose source or destination vertex it owns (each row on at most two ranks), not a replica of
+    # the whole table; the vertex table (3.6 MB) is replicated.  Placement happens here, before timing,
+    # like the staging itself.
+    parts = args.shard_of if args.shard_of > 1 else world
+    src_all, dst_all = src, dst  # the CPU leg (rank 0) checks the combined result against the whole graph
+    src, dst = sharding.local_edge_rows(src, dst, 0 if args.shard_of > 1 else rank, parts)
+    R_local = src.size
     gg = pkg.GG(device_index)
     # the benchmarked MATCH binds no edge variable: like the reference's build side, carry only the key columns
     gg.set_edge_rowid(False)
@@ -175,7 +186,8 @@ def main():
     gg.staging_sync()
     t_stage = time.perf_counter() - t0
     if rank == 0:
-        log(f"{args.workload}: V={V} knows rows={R}; datagen {t_gen:.1f}s, staging (PCIe) {t_stage*1e3:.1f} ms")
+        log(f"{args.workload}: V={V} knows rows={R} ({R_local} on this rank); datagen {t_gen:.1f}s, "
+            f"staging (PCIe) {t_stage*1e3:.1f} ms")
 
     def step():
         # all persons are sources; with N ranks this rank builds only the CSR rows of the vertices it
@@ -236,9 +248,9 @@ def main():
     alg = {
         "expand_mid2": 8 * te_l + 16 * fr_l,
         "expand_fused2": 8 * te_l + 16 * fr_l,
-        "densify_hist": 32 * R + 8 * V,
-        "densify_shard": 32 * R + 8 * V,
-        "radix_scatter": 8 * R,
+        "densify_hist": 32 * R_local + 8 * V,
+        "densify_shard": 32 * R_local + 8 * V,
+        "radix_scatter": 8 * R_local,
     }
     dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
     launches, total_ms = prof.get(dom, (0, 0.0)) if dom else (0, 0.0)
@@ -264,7 +276,7 @@ def main():
     expand_names = {"expand_mid2", "expand_fused2", "reduce_partials", "tile_partition"}
     t_expand = sum(ms for k, ms in per_step_ms.items() if k in expand_names) * 1e-3
     t_build = sum(ms for k, ms in per_step_ms.items() if k not in expand_names) * 1e-3
-    alg_build = (32 * R + 8 * V) + (32 * R + 16 * V)  # densification + one CSR without rowid
+    alg_build = (32 * R_local + 8 * V) + (32 * R_local + 16 * V)  # densification + one CSR without rowid
     phases = {}
     if t_build > 0:
         phases["csr_build"] = {"kernel_ms": t_build * 1e3, "algorithmic_bytes": alg_build,
@@ -289,9 +301,7 @@ def main():
     if rank == 0:
         extra = {}
         if not args.no_cpu:
-            c = gg.build_csr()
-            extra = cpu_baseline(vid, src, dst, gg, c, V, te_total, args.cpu_seconds)
-            c.close()
+            extra = cpu_baseline(vid, src_all, dst_all, V, args.cpu_seconds, with_reference=(world == 1))
             ost = extra.pop("oracle_stats")
             parity = (ost["rows"][1] == rows1 and ost["rows"][2] == rows2 and ost["digest"][1] == dig1
                       and ost["digest"][2] == dig2 and ost["traversed_edges"] == te_total)
@@ -313,7 +323,7 @@ def main():
             "data": "synthetic (seeded LDBC-shaped person/knows, duckdb_pgq_amd/datagen.py)",
             "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build (no edge-rowid payload) + 2-hop expansion (count + digest)",
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
-                       "traversed_edges": int(te_total), "parallelism": f"vertex-ownership shards x{world} (base tables replicated, CSR + expansion sharded, no data-path collective)"},
+                       "traversed_edges": int(te_total), "parallelism": f"vertex-ownership shards x{world} (edge table hash-partitioned by endpoint owner, vertex table replicated, CSR + expansion sharded, no data-path collective)"},
             "roofline": roof,
             "roofline_phases": phases,
             "kernels": kernels,

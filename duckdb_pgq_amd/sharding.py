@@ -70,3 +70,14 @@ def source_batches(rank: int, world: int, per_rank: int):
     """Source-batch sharding of the 64-lane BFS: rank r runs batches r, r+world, ... —
     `per_rank` of them, disjoint across ranks, together the first world*per_rank batches."""
     return [rank + i * world for i in range(per_rank)]
+
+
+def local_edge_rows(src: np.ndarray, dst: np.ndarray, part: int, n_parts: int):
+    """The edge rows rank `part` keeps when the edge table is hash-partitioned across GPUs by endpoint
+    ownership: a row lives on the owner of its source (it feeds that rank's forward CSR rows) and on the
+    owner of its destination (reverse CSR rows) — at most two ranks, 2/N - 1/N^2 of the table per rank.
+    gg_csr_build_shard drops every other row anyway, so building from the local rows gives the same shard."""
+    if n_parts <= 1:
+        return src, dst
+    keep = (owner_of(src, n_parts) == part) | (owner_of(dst, n_parts) == part)
+    return np.ascontiguousarray(src[keep]), np.ascontiguousarray(dst[keep])

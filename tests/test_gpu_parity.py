@@ -724,3 +724,33 @@ def test_dense_vertex_ids_take_the_direct_address_dictionary(gg, orc, name, ids)
     assert gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
     csr.close()
     g.close()
+
+
+@pytest.mark.parametrize("n_parts", [2, 3, 8])
+def test_shard_built_from_its_local_edge_rows_equals_shard_built_from_the_whole_table(gg, orc, n_parts):
+    """bench.py at N > 1 hash-partitions the edge table by endpoint owner (sharding.local_edge_rows): a rank
+    stages only the rows with an endpoint it owns.  The shard CSR and its 2-hop result must not change."""
+    from duckdb_pgq_amd import sharding
+
+    vid, src, dst = datagen.ldbc_knows(3000, 120_000, 88)
+    total = None
+    for part in range(n_parts):
+        per_input = []
+        for s_, d_ in ((src, dst), sharding.local_edge_rows(src, dst, part, n_parts)):
+            gg.staging_clear()
+            gg.set_edge_rowid(False)
+            gg.append_vertices(vid)
+            gg.append_edges(s_, d_)
+            c = gg.build_csr_shard(part, n_parts)
+            per_input.append(gg.expand_khop(c, 1, 2))
+            c.close()
+        assert per_input[0] == per_input[1]
+        vec = sharding.stats_to_vec(per_input[1])
+        total = vec if total is None else [a + b for a, b in zip(total, vec)]
+    gg.set_edge_rowid(True)
+    local_sizes = [sharding.local_edge_rows(src, dst, p, n_parts)[0].size for p in range(n_parts)]
+    assert max(local_sizes) < src.size * (2.0 / n_parts) * 1.1  # about 2/N - 1/N^2 of the table per rank
+    rc, g = orc.csr_build(vid, src, dst)
+    whole = g.khop(1, 2)
+    assert total[0] == whole["rows"][1] and total[1] == whole["rows"][2] and total[4] == whole["traversed_edges"]
+    g.close()

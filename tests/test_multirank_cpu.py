@@ -143,3 +143,23 @@ def test_bfs_source_batches_shard_over_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_local_edge_rows_cover_every_shard_need():
+    """Hash-partitioning the edge table by endpoint owner: every row lands on the owner of its source and
+    on the owner of its destination, nowhere else; about 2/N - 1/N^2 of the table per rank."""
+    vid, src, dst = datagen.ldbc_knows(2000, 60_000, 5)
+    for n in (1, 2, 8):
+        sizes = []
+        for part in range(n):
+            s, d = sharding.local_edge_rows(src, dst, part, n)
+            sizes.append(s.size)
+            os_, od = sharding.owner_of(s, n), sharding.owner_of(d, n)
+            assert ((os_ == part) | (od == part)).all()
+            # nothing this rank needs was left out
+            assert s.size == int(((sharding.owner_of(src, n) == part) | (sharding.owner_of(dst, n) == part)).sum())
+        if n == 1:
+            assert sizes == [src.size]
+        else:
+            expect = src.size * (2.0 / n - 1.0 / n**2)
+            assert all(abs(x - expect) < 0.15 * expect for x in sizes)
