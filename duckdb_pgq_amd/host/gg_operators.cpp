@@ -1,6 +1,9 @@
 // gg_operators.cpp — see gg_operators.hpp.
 #include "gg_operators.hpp"
 
+#include <cstdlib>
+#include <thread>
+
 #include "duckdb/common/exception.hpp"
 #include "duckdb/common/types/data_chunk.hpp"
 #include "duckdb/common/types/vector.hpp"
@@ -292,8 +295,13 @@ public:
 		return max_threads;
 	}
 
-	gg_khop_stats stats;
-	gg_result *result = nullptr;
+	gg_khop_stats stats;           // of the part that is materialised right now (count_only: of everything)
+	gg_result *result = nullptr;   // walks of the current part, in HBM
+	// A result too large for the device-memory budget is produced part by part: contiguous source ranges
+	// (all sources) or slices of the source list, one materialised at a time.  parts[i] = [first, last).
+	vector<std::pair<uint64_t, uint64_t>> parts;
+	idx_t part = 0;
+	std::atomic<idx_t> fetching {0}; // slab fetches still reading `result` (it may not be freed under them)
 	// scan position: (current hop length, next row of it nobody has claimed); pipeline threads claim
 	// GGResultSlab::SLAB_ROWS rows at a time under the lock and fetch them into their own slab
 	mutex lock;
@@ -325,21 +333,82 @@ PhysicalGGPathExpand::PhysicalGGPathExpand(shared_ptr<GGGraph> graph_p, int k_mi
       all_sources(all_sources_p) {
 }
 
+//! Device-memory budget for one materialised part (GG_RESULT_BUDGET_MB; default 16 GiB of the 288).
+static uint64_t ResultBudgetBytes() {
+	auto env = std::getenv("GG_RESULT_BUDGET_MB");
+	const uint64_t mb = env ? std::strtoull(env, nullptr, 10) : 16384;
+	return MaxValue<uint64_t>(mb, 1) << 20;
+}
+
+//! Materialise the walks of parts[part] (caller holds graph->lock or is single-threaded).
+void PhysicalGGPathExpand::MaterialisePart(GlobalSourceState &gstate_p) const {
+	auto &state = (GGExpandGlobalState &)gstate_p;
+	if (state.result) {
+		gg_result_destroy(state.result);
+		state.result = nullptr;
+	}
+	const auto range = state.parts[state.part];
+	if (all_sources) {
+		GGGraph::Check(gg_expand_khop_range(graph->ctx, graph->csr, range.first, range.second, k_min, k_max, 1,
+		                                    &state.stats, &state.result),
+		               "gg_expand_khop_range");
+	} else {
+		GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, sources.data() + range.first, range.second - range.first,
+		                              k_min, k_max, 1, &state.stats, &state.result),
+		               "gg_expand_khop");
+	}
+	state.hop = k_min;
+	state.offset = 0;
+}
+
 unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientContext &context) const {
 	auto state = make_unique<GGExpandGlobalState>();
 	lock_guard<mutex> guard(graph->lock);
 	if (!graph->csr) {
 		throw InternalException("GG_PATH_EXPAND scheduled before the CSR was built");
 	}
+	// count first: cheap (nothing is written), and it tells how much HBM the walks would take
 	GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(), k_min,
-	                              k_max, count_only ? 0 : 1, &state->stats, count_only ? nullptr : &state->result),
+	                              k_max, 0, &state->stats, nullptr),
 	               "gg_expand_khop");
 	state->hop = k_min;
-	idx_t total = 0;
+	if (count_only) {
+		return move(state);
+	}
+	uint64_t total = 0, bytes = 0;
 	for (int h = k_min; h <= k_max; h++) {
 		total += state->stats.rows[h];
+		bytes += state->stats.rows[h] * (uint64_t)(h + 1) * sizeof(int64_t);
 	}
-	state->max_threads = count_only ? 1 : MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
+	// The reference streams a join result of any size; so must its replacement: beyond the budget the
+	// sources are split into parts (twice as many as strictly needed: the split is balanced on 2-hop work,
+	// not on output bytes) that are expanded, handed out and freed one after the other.
+	uint64_t V = 0;
+	GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
+	const uint64_t units = all_sources ? V : sources.size();
+	uint64_t n_parts = bytes > ResultBudgetBytes() ? 2 * ((bytes + ResultBudgetBytes() - 1) / ResultBudgetBytes()) : 1;
+	n_parts = MaxValue<uint64_t>(1, MinValue<uint64_t>(n_parts, MaxValue<uint64_t>(units, 1)));
+	if (n_parts == 1 || units == 0) {
+		state->parts.emplace_back(0, units);
+	} else if (all_sources) {
+		vector<uint64_t> bounds(n_parts + 1);
+		GGGraph::Check(gg_khop_partition(graph->ctx, graph->csr, (int)n_parts, bounds.data()), "gg_khop_partition");
+		for (uint64_t i = 0; i < n_parts; i++) {
+			if (bounds[i + 1] > bounds[i]) {
+				state->parts.emplace_back(bounds[i], bounds[i + 1]);
+			}
+		}
+	} else {
+		for (uint64_t i = 0; i < n_parts; i++) {
+			const uint64_t lo = units * i / n_parts, hi = units * (i + 1) / n_parts;
+			if (hi > lo) {
+				state->parts.emplace_back(lo, hi);
+			}
+		}
+	}
+	state->part = 0;
+	MaterialisePart(*state);
+	state->max_threads = MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
 	return move(state);
 }
 
@@ -373,24 +442,39 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 	auto &slab = (GGResultSlab &)lstate;
 	if (slab.pos >= slab.rows) { // claim the next rows of the next non-empty hop-length table
 		idx_t offset, want;
+		gg_result *result;
 		{
 			lock_guard<mutex> guard(gstate.lock);
-			while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
-				gstate.hop++;
-				gstate.offset = 0;
-			}
-			if (gstate.hop > k_max) {
-				return;
+			while (true) {
+				while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
+					gstate.hop++;
+					gstate.offset = 0;
+				}
+				if (gstate.hop <= k_max) {
+					break;
+				}
+				if (gstate.part + 1 >= gstate.parts.size()) {
+					return; // every part handed out
+				}
+				// this part is claimed completely: wait for the fetches still reading it, then replace it
+				while (gstate.fetching.load() != 0) {
+					std::this_thread::yield();
+				}
+				gstate.part++;
+				lock_guard<mutex> device_guard(graph->lock);
+				MaterialisePart(gstate);
 			}
 			slab.table = gstate.hop;
 			offset = gstate.offset;
 			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.stats.rows[gstate.hop] - gstate.offset);
 			gstate.offset += want;
+			result = gstate.result;
+			gstate.fetching++;
 		}
 		uint32_t got = 0;
-		GGGraph::Check(gg_result_fetch(gstate.result, slab.table, offset, (uint32_t)want, slab.Columns(slab.table + 1),
-		                               &got),
-		               "gg_result_fetch");
+		const int rc = gg_result_fetch(result, slab.table, offset, (uint32_t)want, slab.Columns(slab.table + 1), &got);
+		gstate.fetching--;
+		GGGraph::Check(rc, "gg_result_fetch");
 		slab.rows = got;
 		slab.pos = 0;
 		if (got == 0) {

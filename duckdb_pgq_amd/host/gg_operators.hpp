@@ -147,6 +147,8 @@ public:
 	                     bool all_sources, idx_t estimated_cardinality);
 
 	static vector<LogicalType> OutputTypes(int k_max, bool count_only);
+	//! expand the current part of a result that is produced part by part (see GetGlobalSourceState)
+	void MaterialisePart(GlobalSourceState &gstate) const;
 
 	shared_ptr<GGGraph> graph;
 	int k_min, k_max;

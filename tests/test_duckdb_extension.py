@@ -343,3 +343,30 @@ def test_plan_rule_prepared_statements_and_concurrent_connections(db):
     if dropped:
         with pytest.raises(RuntimeError):
             d.execute("EXECUTE walks")
+
+
+def test_oversized_results_are_produced_part_by_part(db, monkeypatch):
+    """The reference streams a join result of any size; the GPU operator materialises walks in HBM, so
+    beyond a device-memory budget it expands the sources part by part.  With a 1 MiB budget the 2-hop
+    result of the fixture splits into dozens of parts — same relation, all sources and a source list."""
+    d, vid = db
+    d.execute("PRAGMA disable_gpu_graph")
+    whole = d.execute(f"SELECT v0, v1, v2 FROM gg_khop({GRAPH}, 2, 2)")
+    assert whole.shape[0] * 24 > 20 * (1 << 20)
+    monkeypatch.setenv("GG_RESULT_BUDGET_MB", "1")
+    parts = d.execute(f"SELECT v0, v1, v2 FROM gg_khop({GRAPH}, 2, 2)")
+    mixed = d.execute(f"SELECT hops, v0, v1, v2 FROM gg_khop({GRAPH}, 1, 2)")
+    monkeypatch.delenv("GG_RESULT_BUDGET_MB")
+    assert np.array_equal(sort_rows(parts), sort_rows(whole))
+    assert np.array_equal(sort_rows(mixed[mixed[:, 0] == 2][:, 1:]), sort_rows(whole))
+    assert np.array_equal(sort_rows(mixed[mixed[:, 0] == 1][:, 1:3]), sort_rows(d.execute(R.sql_khop_rows(1))))
+    if os.path.exists(R.PLAN_HOOK):  # the substituted join takes the same route
+        sql = "SELECT k1.k_person1id, k2.k_person1id, k2.k_person2id FROM knows k1, knows k2 " \
+              "WHERE k1.k_person2id = k2.k_person1id"
+        cpu = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        monkeypatch.setenv("GG_RESULT_BUDGET_MB", "1")
+        gpu = d.execute(sql)
+        monkeypatch.delenv("GG_RESULT_BUDGET_MB")
+        d.execute("PRAGMA disable_gpu_graph")
+        assert np.array_equal(sort_rows(cpu), sort_rows(gpu))
