@@ -569,20 +569,22 @@ void PhysicalGGFilteredPaths::GetData(ExecutionContext &context, DataChunk &chun
 class GGShortestGlobalState : public GlobalSourceState {
 public:
 	~GGShortestGlobalState() override {
-		for (auto result : batches) {
+		if (result) {
 			gg_result_destroy(result);
 		}
 	}
 	idx_t MaxThreads() override {
 		return max_threads;
 	}
-	//! one device-resident (source, vertex, distance) table per 64-source batch
-	vector<gg_result *> batches;
-	vector<idx_t> batch_rows;
+	vector<int64_t> uniq;            // the sources, deduplicated, in 64-lane batches
+	idx_t batch_base = 0;            // first source of the batch whose rows are in `result`
+	gg_result *result = nullptr;     // (source, vertex, distance) rows of the current batch, in HBM
+	idx_t rows = 0;                  // ... and how many
+	std::atomic<idx_t> fetching {0}; // slab fetches still reading `result`
 	//! seed rows of sources that are not vertices of the graph (lone_sources): served once, at the end
 	vector<int64_t> lone;
 	mutex lock;
-	idx_t batch = 0, offset = 0; // next unclaimed rows
+	idx_t offset = 0; // next unclaimed row of the current batch
 	idx_t lone_offset = 0;
 	idx_t max_threads = 1;
 };
@@ -594,6 +596,25 @@ PhysicalGGShortestPath::PhysicalGGShortestPath(shared_ptr<GGGraph> graph_p, vect
       graph(move(graph_p)), sources(move(sources_p)), max_hops(max_hops_p), lone_sources(lone_sources_p) {
 }
 
+//! Run the 64-lane BFS of the batch starting at batch_base; its reached (source, vertex, distance) rows are
+//! compacted on the device and stay there until the pipeline threads have fetched them.  One batch is
+//! resident at a time: "every person" as seeds at SF100 is 7 000 batches of up to 0.7 GB of rows each.
+void PhysicalGGShortestPath::RunBatch(GlobalSourceState &gstate_p) const {
+	auto &state = (GGShortestGlobalState &)gstate_p;
+	if (state.result) {
+		gg_result_destroy(state.result);
+		state.result = nullptr;
+	}
+	const int n = (int)MinValue<idx_t>(GG_BFS_LANES, state.uniq.size() - state.batch_base);
+	GGGraph::Check(gg_bfs64_pairs(graph->ctx, graph->csr, state.uniq.data() + state.batch_base, n, max_hops, nullptr,
+	                              &state.result),
+	               "gg_bfs64_pairs");
+	uint64_t rows = 0;
+	GGGraph::Check(gg_result_rows(state.result, 2, &rows), "gg_result_rows");
+	state.rows = rows;
+	state.offset = 0;
+}
+
 unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(ClientContext &context) const {
 	auto state = make_unique<GGShortestGlobalState>();
 	lock_guard<mutex> guard(graph->lock);
@@ -601,43 +622,31 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 		throw InternalException("GG_SHORTEST_PATH scheduled before the CSR was built");
 	}
 	// UNION semantics: a source listed twice yields its rows once
-	vector<int64_t> uniq;
 	{
 		unordered_set<int64_t> seen;
 		for (auto s : sources) {
 			if (seen.insert(s).second) {
-				uniq.push_back(s);
+				state->uniq.push_back(s);
 			}
 		}
 	}
-	if (lone_sources && !uniq.empty()) {
+	if (lone_sources && !state->uniq.empty()) {
 		// a source that is not a vertex of the graph reaches nothing but keeps its own seed row
-		vector<uint32_t> dense(uniq.size());
-		GGGraph::Check(gg_csr_lookup(graph->ctx, graph->csr, uniq.data(), uniq.size(), dense.data()), "gg_csr_lookup");
-		for (idx_t i = 0; i < uniq.size(); i++) {
+		vector<uint32_t> dense(state->uniq.size());
+		GGGraph::Check(gg_csr_lookup(graph->ctx, graph->csr, state->uniq.data(), state->uniq.size(), dense.data()),
+		               "gg_csr_lookup");
+		for (idx_t i = 0; i < state->uniq.size(); i++) {
 			if (dense[i] == 0xFFFFFFFFu) {
-				state->lone.push_back(uniq[i]);
+				state->lone.push_back(state->uniq[i]);
 			}
 		}
 	}
-	idx_t total = 0;
-	for (idx_t base = 0; base < uniq.size(); base += GG_BFS_LANES) { // 64 bit lanes per batch
-		if (context.interrupted) {
-			throw InterruptException();
-		}
-		const int n = (int)MinValue<idx_t>(GG_BFS_LANES, uniq.size() - base);
-		// the reached (source, vertex, distance) rows are compacted on the device and stay there until
-		// the pipeline threads fetch them slab by slab
-		gg_result *pairs = nullptr;
-		GGGraph::Check(gg_bfs64_pairs(graph->ctx, graph->csr, uniq.data() + base, n, max_hops, nullptr, &pairs),
-		               "gg_bfs64_pairs");
-		state->batches.push_back(pairs);
-		uint64_t rows = 0;
-		GGGraph::Check(gg_result_rows(pairs, 2, &rows), "gg_result_rows");
-		state->batch_rows.push_back(rows);
-		total += rows;
+	if (!state->uniq.empty()) {
+		RunBatch(*state);
 	}
-	state->max_threads = MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
+	// the first batch's size is the only estimate there is of how much the threads will have to drain
+	const idx_t batches = (state->uniq.size() + GG_BFS_LANES - 1) / GG_BFS_LANES;
+	state->max_threads = MaxValue<idx_t>(1, state->rows * batches / GGResultSlab::SLAB_ROWS);
 	return move(state);
 }
 
@@ -654,36 +663,43 @@ void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk
 		throw InterruptException();
 	}
 	if (slab.pos >= slab.rows) {
-		idx_t batch, offset, want;
+		idx_t offset, want;
+		gg_result *result;
 		{
 			lock_guard<mutex> guard(gstate.lock);
-			while (gstate.batch < gstate.batches.size() && gstate.offset >= gstate.batch_rows[gstate.batch]) {
-				gstate.batch++;
-				gstate.offset = 0;
-			}
-			if (gstate.batch >= gstate.batches.size()) {
-				if (gstate.lone_offset >= gstate.lone.size()) {
+			while (gstate.offset >= gstate.rows) { // current batch claimed completely: run the next one
+				if (gstate.batch_base + GG_BFS_LANES >= gstate.uniq.size()) {
+					if (gstate.uniq.empty() || gstate.lone_offset >= gstate.lone.size()) {
+						return;
+					}
+					// last: the seed rows of the sources that are not vertices
+					const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.lone.size() - gstate.lone_offset);
+					for (idx_t i = 0; i < n; i++) {
+						FlatVector::GetData<int64_t>(chunk.data[0])[i] = gstate.lone[gstate.lone_offset + i];
+						FlatVector::GetData<int64_t>(chunk.data[1])[i] = gstate.lone[gstate.lone_offset + i];
+						FlatVector::GetData<int32_t>(chunk.data[2])[i] = 0;
+					}
+					gstate.lone_offset += n;
+					chunk.SetCardinality(n);
 					return;
 				}
-				// last: the seed rows of the sources that are not vertices
-				const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gstate.lone.size() - gstate.lone_offset);
-				for (idx_t i = 0; i < n; i++) {
-					FlatVector::GetData<int64_t>(chunk.data[0])[i] = gstate.lone[gstate.lone_offset + i];
-					FlatVector::GetData<int64_t>(chunk.data[1])[i] = gstate.lone[gstate.lone_offset + i];
-					FlatVector::GetData<int32_t>(chunk.data[2])[i] = 0;
+				while (gstate.fetching.load() != 0) { // fetches still reading the batch that is about to go
+					std::this_thread::yield();
 				}
-				gstate.lone_offset += n;
-				chunk.SetCardinality(n);
-				return;
+				gstate.batch_base += GG_BFS_LANES;
+				lock_guard<mutex> device_guard(graph->lock);
+				RunBatch(gstate);
 			}
-			batch = gstate.batch;
 			offset = gstate.offset;
-			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.batch_rows[batch] - offset);
+			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.rows - offset);
 			gstate.offset += want;
+			result = gstate.result;
+			gstate.fetching++;
 		}
 		uint32_t got = 0;
-		GGGraph::Check(gg_result_fetch(gstate.batches[batch], 2, offset, (uint32_t)want, slab.Columns(3), &got),
-		               "gg_result_fetch");
+		const int rc = gg_result_fetch(result, 2, offset, (uint32_t)want, slab.Columns(3), &got);
+		gstate.fetching--;
+		GGGraph::Check(rc, "gg_result_fetch");
 		slab.rows = got;
 		slab.pos = 0;
 		if (got == 0) {

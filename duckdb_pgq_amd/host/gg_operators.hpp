@@ -209,6 +209,9 @@ public:
 	PhysicalGGShortestPath(shared_ptr<GGGraph> graph, vector<int64_t> sources, int max_hops,
 	                       idx_t estimated_cardinality, bool lone_sources = false);
 
+	//! BFS of the next 64-source batch (batches run one at a time, when the previous one is drained)
+	void RunBatch(GlobalSourceState &gstate) const;
+
 	shared_ptr<GGGraph> graph;
 	vector<int64_t> sources;
 	int max_hops;

@@ -569,7 +569,9 @@ string QualifiedName(TableCatalogEntry &table) {
 	return GGQuote(table.schema->name) + "." + GGQuote(table.name);
 }
 
-thread_local extern vector<CatalogEntry *> g_plan_tables;
+//! tables the plan being substituted reads; registered with the generator like LogicalGet's dependency
+//! callback does (plan_get.cpp:50-52), so a prepared statement notices when one of them is dropped
+thread_local vector<CatalogEntry *> g_plan_tables;
 
 GGScanSource TableColumns(TableCatalogEntry *table, vector<column_t> columns) {
 	g_plan_tables.push_back(table);
@@ -1590,10 +1592,6 @@ unique_ptr<PhysicalOperator> PlanAggregate(LogicalAggregate &op) {
 	}
 	return PlanShortestPath(op);
 }
-
-//! tables the substituted plan reads, registered with the generator like LogicalGet's dependency
-//! callback does (plan_get.cpp:50-52), so a prepared statement notices when one of them is dropped
-thread_local vector<CatalogEntry *> g_plan_tables;
 
 template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
 int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
