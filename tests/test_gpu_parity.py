@@ -754,3 +754,20 @@ def test_shard_built_from_its_local_edge_rows_equals_shard_built_from_the_whole_
     whole = g.khop(1, 2)
     assert total[0] == whole["rows"][1] and total[1] == whole["rows"][2] and total[4] == whole["traversed_edges"]
     g.close()
+
+
+@pytest.mark.parametrize("keys", [[1, 2, 3], [-1, -2, 3]])
+def test_perfect_hash_join_vectors_of_the_reference(gg, orc, keys):
+    """test/sql/join/inner/test_join_perfect_hash.test:13-44 and :55-86: three build keys (positive; negative)
+    probed by 15 rows, five per key -> 15 join rows.  As a graph: the build keys are the vertices (a dense
+    id range, so the direct-address dictionary is taken), every probe row is an edge key -> key."""
+    vid = np.array(keys, np.int64)
+    probe = np.array(keys * 5, np.int64)
+    csr, g = build_both(gg, orc, vid, probe, probe)
+    assert_csr_equal(csr, g)
+    st = gg.expand_khop(csr, 1, 1)
+    assert st["rows"][1] == 15 and st == g.khop(1, 1)
+    off, nbr, _, _ = csr.export()
+    assert np.diff(off).tolist() == [5, 5, 5] and np.array_equal(vid[nbr], np.repeat(vid, 5))
+    csr.close()
+    g.close()

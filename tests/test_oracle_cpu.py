@@ -100,3 +100,22 @@ def test_datagen_deterministic():
     half = src.size // 2
     assert np.array_equal(src[:half], dst[half:]) and np.array_equal(dst[:half], src[half:])
     assert not np.any(src == dst)
+
+
+def test_recursive_cte_restatement_on_the_references_own_vectors(orc):
+    """test/sql/cte/test_recursive_cte_union.test written as graphs (x -> x+1 is an edge of a path graph):
+    :8-14   `select 1 union select x+1 from t where x < 3`      -> 1, 2, 3
+    :40-44  `select 1 union select x from t` (UNION dedupe stops the self-reference) -> 1
+    :54-60  two references, `m.x + f.x ... where m.x < 3`       -> not a walk pattern (not restated)
+    The friends CTE carries (start, hop, vertex); its min(hop) per vertex is what orc_cte_shortest returns."""
+    vid = np.array([1, 2, 3, 4, 5], np.int64)
+    # path 1 -> 2 -> 3 -> 4 -> 5, recursion allowed while x < 3 i.e. two steps from the seed 1
+    got = orc.cte_shortest(vid, vid[:-1], vid[1:], np.array([1], np.int64), 2)
+    assert sort_rows(got).tolist() == [[1, 1, 0], [1, 2, 1], [1, 3, 2]]
+    # self-reference x -> x: the vertex is reached once, at hop 0, however long the recursion may run
+    loop = orc.cte_shortest(np.array([1], np.int64), np.array([1], np.int64), np.array([1], np.int64),
+                            np.array([1], np.int64), 50)
+    assert loop.tolist() == [[1, 1, 0]]
+    # a cycle 1 -> 2 -> 3 -> 1 terminates by dedupe too and keeps the shortest hop of every vertex
+    cyc = orc.cte_shortest(vid[:3], vid[:3], np.roll(vid[:3], -1), np.array([2], np.int64), 50)
+    assert sort_rows(cyc).tolist() == [[2, 1, 2], [2, 2, 0], [2, 3, 1]]
