@@ -210,7 +210,8 @@ struct ApiScope {
   } while (0)
 
 // exclusive scan of n uint32 values (in place allowed: out may equal in); writes the grand
-// total (as uint64) to *total_dev if non-null.  Three hand-written kernels (gg_scan.hip).
+// total (as uint64) to *total_dev if non-null.  One hand-written kernel, tiles chained by decoupled
+// look-back (gg_runtime.hip).
 int scan_exclusive_u32(gg_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint64_t *total_dev);
 // exclusive scan of n uint64 values
 int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n, uint64_t *total_dev);

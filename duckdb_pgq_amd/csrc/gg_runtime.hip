@@ -540,7 +540,7 @@ extern "C" int gg_staging_clear_edges(gg_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------------------------------
-// exclusive scans (hand-written: per-block reduce -> single-block scan of block sums -> apply)
+// exclusive scans (hand-written: one pass, tiles chained by decoupled look-back)
 // ------------------------------------------------------------------------------------------
 namespace gg {
 
@@ -578,59 +578,77 @@ __device__ __forceinline__ T block_excl_scan(T v, T *total, T *lds /* >= 4 */) {
   return wbase + incl - v;
 }
 
-template <typename TIn, typename TAcc>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const TIn *__restrict__ in, TAcc *__restrict__ bsum,
-                                                              uint64_t n) {
-  __shared__ TAcc lds[4];
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
-  TAcc s = 0;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    uint64_t idx = base + (uint64_t)i * SCAN_THREADS + threadIdx.x;
-    if (idx < n) s += (TAcc)in[idx];
-  }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+// ---- single-pass scan with decoupled look-back ---------------------------------------------------------
+// One kernel instead of three (reduce, scan of block sums, apply) and one read of the input instead of two:
+// the arrays scanned here are the (digit x tile) counters of a radix pass — a megabyte or less per scan,
+// seven scans per build — so launch latency and the second read are most of their cost.
+// Tiles take a ticket (so a tile only ever waits for tiles that already run), publish their sum
+// (FLAG_SUM), then wave 0 looks back 64 predecessors at a time, adding sums until it meets a tile that
+// already knows its inclusive prefix (FLAG_PREFIX), and publishes its own.  A status word carries flag and
+// value together (one 8-byte agent-scope atomic), so no fence ordering between separate words is needed.
+constexpr unsigned long long SCAN_FLAG_SUM = 1ULL << 62, SCAN_FLAG_PREFIX = 2ULL << 62;
+constexpr unsigned long long SCAN_VALUE_MASK = (1ULL << 62) - 1;
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const TIn *__restrict__ in, TOut *__restrict__ out,
+                                                               uint64_t n, uint64_t nb,
+                                                               unsigned long long *__restrict__ status /* nb + 1 */,
+                                                               uint64_t *__restrict__ total_dev) {
+  __shared__ uint64_t lds[4];
+  __shared__ uint64_t s_tile, s_prefix;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&status[nb], 1ULL);  // the ticket counter lives behind the status words
   __syncthreads();
-  if (threadIdx.x == 0) bsum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-}
-
-// single block: exclusive scan of nb block sums in place, total to *total_dev
-template <typename TAcc>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_blocksums(TAcc *__restrict__ bsum, uint64_t nb,
-                                                                 uint64_t *__restrict__ total_dev) {
-  __shared__ TAcc lds[4];
-  TAcc carry = 0;
-  for (uint64_t base = 0; base < nb; base += SCAN_THREADS) {
-    uint64_t idx = base + threadIdx.x;
-    TAcc v = idx < nb ? bsum[idx] : 0;
-    TAcc tot;
-    TAcc ex = block_excl_scan<TAcc>(v, &tot, lds);
-    if (idx < nb) bsum[idx] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total_dev) *total_dev = (uint64_t)carry;
-}
-
-template <typename TIn, typename TOut, typename TAcc>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TIn *__restrict__ in, TOut *__restrict__ out,
-                                                             const TAcc *__restrict__ bsum, uint64_t n) {
-  __shared__ TAcc lds[4];
+  const uint64_t tile = s_tile;
   // thread t owns SCAN_ITEMS consecutive elements -> serial scan in registers + block scan of sums
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-  TAcc v[SCAN_ITEMS];
-  TAcc s = 0;
+  const uint64_t base = tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t v[SCAN_ITEMS];
+  uint64_t sum = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
-    uint64_t idx = base + i;
-    v[i] = idx < n ? (TAcc)in[idx] : 0;
-    s += v[i];
+    const uint64_t idx = base + i;
+    v[i] = idx < n ? (uint64_t)in[idx] : 0;
+    sum += v[i];
   }
-  TAcc tot;
-  TAcc ex = block_excl_scan<TAcc>(s, &tot, lds) + bsum[blockIdx.x];
+  uint64_t tot;
+  uint64_t ex = block_excl_scan<uint64_t>(sum, &tot, lds);
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
+    if (tile > 0 && lane == 0)
+      __hip_atomic_store(&status[tile], SCAN_FLAG_SUM | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t run = 0;
+    int64_t hi = (int64_t)tile - 1;  // nearest predecessor not yet accounted for
+    while (hi >= 0) {
+      const int64_t j = hi - lane;
+      unsigned long long w = SCAN_FLAG_PREFIX;  // before tile 0: prefix 0
+      if (j >= 0) {
+        uint32_t spins = 0;
+        do {
+          w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((w >> 62) == 0 && ++spins < (1u << 24));  // predecessors hold lower tickets: they are running
+      }
+      const unsigned long long is_prefix = __ballot((w >> 62) == 2);
+      // lanes up to (and including) the nearest tile that knows its prefix contribute; a lane that gave
+      // up waiting contributes nothing (the result is then wrong, but the grid still drains)
+      const int stop = is_prefix ? __ffsll((long long)is_prefix) - 1 : 63;
+      uint64_t part = (lane <= stop && (w >> 62) != 0) ? (uint64_t)(w & SCAN_VALUE_MASK) : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      run += part;
+      if (is_prefix) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&status[tile], SCAN_FLAG_PREFIX | ((run + tot) & SCAN_VALUE_MASK), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = run;
+      if (tile == nb - 1 && total_dev) *total_dev = run + tot;
+    }
+  }
+  __syncthreads();
+  ex += s_prefix;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
-    uint64_t idx = base + i;
+    const uint64_t idx = base + i;
     if (idx < n) out[idx] = (TOut)ex;
     ex += v[i];
   }
@@ -642,14 +660,13 @@ static int scan_impl(gg_ctx *ctx, const TIn *in, TOut *out, uint64_t n, uint64_t
     if (total_dev) GG_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint64_t), ctx->stream));
     return GG_OK;
   }
-  uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-  TAcc *bsum = nullptr;
-  GG_TRY(ctx->dev_alloc((void **)&bsum, nb * sizeof(TAcc)));
-  GG_LAUNCH(ctx, "scan_reduce", (k_scan_reduce<TIn, TAcc>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, in, bsum, n);
-  GG_LAUNCH(ctx, "scan_blocksums", (k_scan_blocksums<TAcc>), dim3(1), dim3(SCAN_THREADS), 0, bsum, nb, total_dev);
-  GG_LAUNCH(ctx, "scan_apply", (k_scan_apply<TIn, TOut, TAcc>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, in, out,
-            bsum, n);
-  ctx->dev_free(bsum);  // stream-ordered reuse: later work on the same stream runs after these kernels
+  const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  unsigned long long *status = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&status, (nb + 1) * sizeof(unsigned long long)));
+  GG_HIP(hipMemsetAsync(status, 0, (nb + 1) * sizeof(unsigned long long), ctx->stream));
+  GG_LAUNCH(ctx, "scan_chained", (k_scan_chained<TIn, TOut>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, in, out, n, nb,
+            status, total_dev);
+  ctx->dev_free(status);  // stream-ordered reuse: later work on the same stream runs after this kernel
   return GG_OK;
 }
 
