@@ -13,9 +13,9 @@
 //                          k_bfs_push:    wavefront per active vertex, coalesced CSR row read, 8-byte OR
 //                                         into next[w] only for lanes w has not seen
 //                          k_bfs_update:  new = next & ~seen; seen |= new; distances; next frontier + stats
-//   pull (heavy frontier)  k_bfs_pull:    wavefront per vertex w that still misses lanes: OR of
-//                                         frontier[v] over the in-neighbours (reverse CSR, coalesced row
-//                                         read + 8-byte gathers from the V-sized, L2-resident frontier),
+//   pull (heavy frontier)  k_bfs_pull:    16 lanes (lists of >= 128: the whole wavefront) per vertex w that
+//                                         still misses lanes: OR of frontier[v] over the in-neighbours
+//                                         (reverse CSR row read + 8-byte gathers from the V-sized, L2-resident frontier),
 //                                         no atomics; writes the next frontier, seen, distances and the
 //                                         next level's stats in the same pass
 // Distances live as one byte per (vertex, lane) — 64 contiguous bytes per vertex — and are widened to the
@@ -83,24 +83,28 @@ __global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ sr
                                                  const uint32_t *__restrict__ off, uint64_t *__restrict__ frontier,
                                                  uint64_t *__restrict__ seen, uint64_t *__restrict__ dist8,
                                                  BfsLevel *__restrict__ lv) {
-  // serial over the (<= 64) sources so that a vertex seeded by several lanes is counted once
-  if (threadIdx.x != 0) return;
-  unsigned long long act = 0, te = 0, reached = 0;
-  for (int i = 0; i < n_src; i++) {
-    const uint32_t v = src_dense[i];
-    if (v == INVALID_U32) continue;
-    if (frontier[v] == 0) {
-      act++;
-      te += off[v + 1] - off[v];
-    }
-    frontier[v] |= 1ULL << i;
-    seen[v] |= 1ULL << i;
-    reinterpret_cast<DistT *>(dist8)[(uint64_t)v * 64 + i] = 0;
-    reached++;
+  // one lane per source; a vertex seeded by several sources is counted once (by its lowest lane)
+  const int i = threadIdx.x;
+  const uint32_t v = i < n_src ? src_dense[i] : INVALID_U32;
+  const bool valid = v != INVALID_U32;
+  bool first = valid;
+  for (int j = 0; j < 64; j++) {
+    const uint32_t other = __shfl(v, j, 64);
+    if (j < i && other == v) first = false;
   }
-  lv->n_active = act;
-  lv->te = te;
-  lv->reached = reached;
+  if (valid) {
+    atomicOr((unsigned long long *)&frontier[v], 1ULL << i);
+    atomicOr((unsigned long long *)&seen[v], 1ULL << i);
+    reinterpret_cast<DistT *>(dist8)[(uint64_t)v * 64 + i] = 0;
+  }
+  const uint64_t act = (uint64_t)__popcll(__ballot(first));
+  const uint64_t te = wave_reduce_add_u64(first ? (uint64_t)(off[v + 1] - off[v]) : 0ULL);
+  const uint64_t reached = (uint64_t)__popcll(__ballot(valid));
+  if (i == 0) {
+    lv->n_active = act;
+    lv->te = te;
+    lv->reached = reached;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_bfs_compact(const uint64_t *__restrict__ frontier, uint64_t V,
@@ -167,7 +171,16 @@ __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ front
   add_level_stats(nw ? 1 : 0, te, (uint64_t)__popcll(nw), s_red, lv);
 }
 
-// pull: a wavefront per vertex (grid-strided); reads fin, writes fout (ping-pong frontiers)
+// pull: four vertices per wavefront, sixteen lanes each (grid-strided); reads fin, writes fout (ping-pong
+// frontiers).  In-degrees are heavy-tailed (SF100: median 27, mean 89, max ~1000): a whole wavefront per
+// vertex leaves 40 % of the lanes idle and runs one dependent seen -> offsets -> list -> frontier chain at a
+// time, so short lists go to a 16-lane group each, four chains in flight per wave, and only lists of
+// PULL_HEAVY entries or more are walked by all 64 lanes, one after the other.
+#ifndef GG_PULL_HEAVY
+#define GG_PULL_HEAVY 128
+#endif
+constexpr uint32_t PULL_HEAVY = GG_PULL_HEAVY;
+
 template <typename DistT>
 __global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
                                                   uint64_t *__restrict__ seen, uint64_t V, uint32_t level,
@@ -175,22 +188,38 @@ __global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ f
                                                   const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
                                                   BfsLevel *__restrict__ lv) {
   __shared__ uint64_t s_red[12];
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, group = lane >> 4, gl = lane & 15;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  uint64_t act = 0, te = 0, reached = 0;  // accumulated by lane 0 of each wave
-  for (uint64_t w = wave0; w < V; w += nwaves) {
-    const uint64_t s = seen[w];
-    uint64_t nw = 0;
-    if (~s) {  // some lane still missing at w
-      uint64_t acc = 0;
-      const uint32_t b = roff[w], e = roff[w + 1];
-      for (uint32_t i = b + lane; i < e; i += 64) acc |= fin[rnbr[i]];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);
-      nw = acc & ~s;
+  uint64_t act = 0, te = 0, reached = 0;  // accumulated by the first lane of each group
+  for (uint64_t wbase = wave0 * 4; wbase < V; wbase += nwaves * 4) {
+    const uint64_t w = wbase + group;
+    const bool valid = w < V;
+    const uint64_t s = valid ? seen[w] : ~0ULL;
+    uint32_t b = 0, e = 0;
+    if (valid && ~s) {  // some lane still missing at w
+      b = roff[w];
+      e = roff[w + 1];
     }
-    if (lane == 0) {
+    const bool heavy = e - b >= PULL_HEAVY;
+    uint64_t acc = 0;
+    if (!heavy)
+      for (uint32_t i = b + gl; i < e; i += 16) acc |= fin[rnbr[i]];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);  // stays inside the 16-lane group
+    uint64_t hm = __ballot(heavy && gl == 0);  // bit 16*g: group g's vertex wants the whole wave
+    while (hm) {
+      const int leader = __ffsll((long long)hm) - 1;
+      hm &= hm - 1;
+      const uint32_t hb = __shfl(b, leader, 64), he = __shfl(e, leader, 64);
+      uint64_t a = 0;
+      for (uint32_t i = hb + lane; i < he; i += 64) a |= fin[rnbr[i]];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a |= __shfl_xor(a, o, 64);
+      if (group == (leader >> 4)) acc = a;
+    }
+    const uint64_t nw = acc & ~s;
+    if (gl == 0 && valid) {
       fout[w] = nw;
       if (nw) {
         seen[w] = s | nw;
@@ -330,7 +359,8 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
     const bool pull = h.te * 16 > csr->E;  // heavy frontier: gather instead of scatter
     if (pull) {
       GG_TRY(ensure_reverse(ctx, csr));
-      uint64_t waves = V < max_waves ? V : max_waves;
+      const uint64_t quads = (V + 3) / 4;  // four vertices per wavefront
+      uint64_t waves = quads < max_waves ? quads : max_waves;
       GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull<DistT>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, front, other,
                 seen, V, (uint32_t)level, csr->off, csr->roff, csr->rnbr, dist8, lv);
       // the old frontier becomes the spare buffer and must be zero again for a later push level
