@@ -19,8 +19,9 @@
 //                   bi-10-shortestpath.sql -> the 64-lane bitset BFS (see PlanShortestPath below).
 //
 // A pattern is accepted only when the substitution is exact for every database state:
-//   * every leaf is a plain sequential scan, every join INNER with only column = column conditions; the
-//     only pushed-down filter allowed is `= constant` on the walk's first vertex (a single source);
+//   * every leaf is a plain sequential scan, every join INNER with only column = column conditions;
+//     pushed-down filters must be on key columns: `= constant` on the walk's first vertex becomes the single
+//     source, comparisons with constants on other positions stay as a filter above the GPU scan;
 //   * the edge instances form one path  e1.dst = e2.src, e2.dst = e3.src, ...  and nothing else is
 //     equated;
 //   * either every walk position is also joined to an instance of ONE vertex table whose key column
@@ -44,6 +45,7 @@
 #include "duckdb/catalog/catalog.hpp"
 #include "duckdb/catalog/catalog_entry/schema_catalog_entry.hpp"
 #include "duckdb/catalog/catalog_entry/table_catalog_entry.hpp"
+#include "duckdb/execution/operator/filter/physical_filter.hpp"
 #include "duckdb/execution/operator/projection/physical_projection.hpp"
 #include "duckdb/execution/operator/scan/physical_table_scan.hpp"
 #include "duckdb/execution/physical_plan_generator.hpp"
@@ -101,12 +103,24 @@ struct LeafColumn {
 struct LeafConstant {
 	LeafColumn column;
 	int64_t value;
+	TableFilter *filter;
+};
+
+//! any other filter pushed into a leaf's scan (<>, <, >=, ranges, ORs of those) on an integer column
+struct LeafFilter {
+	LeafColumn column;
+	TableFilter *filter;
 };
 
 struct PatternInput {
 	vector<ScanLeaf> leaves;
 	vector<std::pair<LeafColumn, LeafColumn>> equalities;
 	vector<LeafConstant> constants;
+	vector<LeafFilter> filters;
+	vector<unique_ptr<TableFilter>> owned_filters; // filters rebuilt from a LogicalFilter above a leaf
+	//! pure column projections above a leaf (column pruning leaves one after a filter whose column is not
+	//! needed further up): projection table index -> the leaf column behind each of its outputs
+	vector<std::pair<idx_t, vector<LeafColumn>>> aliases;
 };
 
 //! What the pattern turned out to be.
@@ -118,12 +132,25 @@ struct WalkPattern {
 	idx_t hops = 0;
 	bool all_sources = true;
 	vector<int64_t> sources; // walk position 0 is pinned to a constant (k1.src = C, interactive-complex-3.sql:9)
+	//! predicates on other walk positions (k2.dst <> X, interactive-complex-3.sql:11): kept as a filter
+	//! above the GPU scan.  (walk position, the pushed-down filter) — the filter outlives planning inside
+	//! the logical operator tree only, so it is turned into an expression before the rule returns
+	vector<std::pair<idx_t, TableFilter *>> residual;
 	//! per leaf: walk position of its src column (edge leaves: position of dst is +1) or of its key
 	vector<idx_t> edge_position;   // leaf -> 1-based edge number, 0 for vertex leaves
 	vector<idx_t> vertex_position; // leaf -> walk position (vertex leaves only)
 };
 
 bool ResolveLeafColumn(const PatternInput &in, const ColumnBinding &binding, LeafColumn &out) {
+	for (auto &alias : in.aliases) {
+		if (alias.first == binding.table_index) {
+			if (binding.column_index >= alias.second.size()) {
+				return false;
+			}
+			out = alias.second[binding.column_index];
+			return true;
+		}
+	}
 	for (idx_t l = 0; l < in.leaves.size(); l++) {
 		auto &get = *in.leaves[l].get;
 		if (get.table_index != binding.table_index) {
@@ -240,6 +267,106 @@ bool FilterToSQL(TableFilter &filter, const string &column, string &out) {
 	}
 }
 
+//! The same filter as an expression over scan column `column` (BIGINT); shapes FilterToSQL accepts.
+unique_ptr<Expression> FilterToExpression(TableFilter &filter, idx_t column) {
+	switch (filter.filter_type) {
+	case TableFilterType::IS_NOT_NULL: {
+		auto result = make_unique<BoundOperatorExpression>(ExpressionType::OPERATOR_IS_NOT_NULL, LogicalType::BOOLEAN);
+		result->children.push_back(make_unique<BoundReferenceExpression>(LogicalType::BIGINT, column));
+		return move(result);
+	}
+	case TableFilterType::CONSTANT_COMPARISON: {
+		auto &constant = (ConstantFilter &)filter;
+		return make_unique<BoundComparisonExpression>(
+		    constant.comparison_type, make_unique<BoundReferenceExpression>(LogicalType::BIGINT, column),
+		    make_unique<BoundConstantExpression>(Value::BIGINT(constant.constant.GetValue<int64_t>())));
+	}
+	case TableFilterType::CONJUNCTION_AND:
+	case TableFilterType::CONJUNCTION_OR: {
+		const bool is_and = filter.filter_type == TableFilterType::CONJUNCTION_AND;
+		auto &children = is_and ? ((ConjunctionAndFilter &)filter).child_filters
+		                        : ((ConjunctionOrFilter &)filter).child_filters;
+		auto result = make_unique<BoundConjunctionExpression>(is_and ? ExpressionType::CONJUNCTION_AND
+		                                                             : ExpressionType::CONJUNCTION_OR);
+		for (auto &child : children) {
+			result->children.push_back(FilterToExpression(*child, column));
+		}
+		return move(result);
+	}
+	default:
+		throw InternalException("gg: unexpected table filter");
+	}
+}
+
+//! A predicate the optimizer left in a LogicalFilter above a scan (it pushes =, <, >, ranges into the scan
+//! but not <>), restated as a table filter on ONE column: comparisons of a column reference with an integer
+//! constant, and AND/OR of those over the same column.  ref_index receives the referenced child column.
+unique_ptr<TableFilter> ExpressionToFilter(Expression &expr, idx_t &ref_index) {
+	switch (expr.type) {
+	case ExpressionType::COMPARE_EQUAL:
+	case ExpressionType::COMPARE_NOTEQUAL:
+	case ExpressionType::COMPARE_LESSTHAN:
+	case ExpressionType::COMPARE_LESSTHANOREQUALTO:
+	case ExpressionType::COMPARE_GREATERTHAN:
+	case ExpressionType::COMPARE_GREATERTHANOREQUALTO: {
+		auto &cmp = (BoundComparisonExpression &)expr;
+		auto type = expr.type;
+		Expression *ref = cmp.left.get(), *constant = cmp.right.get();
+		if (ref->type != ExpressionType::BOUND_REF) { // constant on the left: mirror the comparison
+			std::swap(ref, constant);
+			switch (type) {
+			case ExpressionType::COMPARE_LESSTHAN:
+				type = ExpressionType::COMPARE_GREATERTHAN;
+				break;
+			case ExpressionType::COMPARE_LESSTHANOREQUALTO:
+				type = ExpressionType::COMPARE_GREATERTHANOREQUALTO;
+				break;
+			case ExpressionType::COMPARE_GREATERTHAN:
+				type = ExpressionType::COMPARE_LESSTHAN;
+				break;
+			case ExpressionType::COMPARE_GREATERTHANOREQUALTO:
+				type = ExpressionType::COMPARE_LESSTHANOREQUALTO;
+				break;
+			default:
+				break;
+			}
+		}
+		if (ref->type != ExpressionType::BOUND_REF || constant->type != ExpressionType::VALUE_CONSTANT) {
+			return nullptr;
+		}
+		auto &value = ((BoundConstantExpression &)*constant).value;
+		const auto index = ((BoundReferenceExpression &)*ref).index;
+		if (value.is_null || !value.type().IsIntegral() || (ref_index != INVALID_INDEX && ref_index != index)) {
+			return nullptr;
+		}
+		ref_index = index;
+		return make_unique<ConstantFilter>(type, Value::BIGINT(value.GetValue<int64_t>()));
+	}
+	case ExpressionType::CONJUNCTION_AND:
+	case ExpressionType::CONJUNCTION_OR: {
+		auto &conjunction = (BoundConjunctionExpression &)expr;
+		vector<unique_ptr<TableFilter>> children;
+		for (auto &child : conjunction.children) {
+			auto filter = ExpressionToFilter(*child, ref_index);
+			if (!filter) {
+				return nullptr;
+			}
+			children.push_back(move(filter));
+		}
+		if (expr.type == ExpressionType::CONJUNCTION_AND) {
+			auto result = make_unique<ConjunctionAndFilter>();
+			result->child_filters = move(children);
+			return move(result);
+		}
+		auto result = make_unique<ConjunctionOrFilter>();
+		result->child_filters = move(children);
+		return move(result);
+	}
+	default:
+		return nullptr;
+	}
+}
+
 //! Flatten a tree of inner equi-joins over sequential scans; false if anything else is in it.
 bool CollectJoinTree(LogicalOperator &op, PatternInput &in) {
 	switch (op.type) {
@@ -257,11 +384,64 @@ bool CollectJoinTree(LogicalOperator &op, PatternInput &in) {
 		// ConstantFilter AND IsNotNullFilter, src/optimizer/filter_combiner.cpp:473-475)
 		for (auto &entry : get.table_filters.filters) {
 			int64_t value;
-			if (entry.first >= bind.table->columns.size() || !ColumnIsIntegerKey(*bind.table, entry.first) ||
-			    !IsEqualityWithConstant(*entry.second, value)) {
+			string ignored;
+			if (entry.first >= bind.table->columns.size() || !ColumnIsIntegerKey(*bind.table, entry.first)) {
 				return false;
 			}
-			in.constants.push_back({{in.leaves.size() - 1, entry.first}, value});
+			if (IsEqualityWithConstant(*entry.second, value)) {
+				in.constants.push_back({{in.leaves.size() - 1, entry.first}, value, entry.second.get()});
+			} else if (FilterToSQL(*entry.second, "c", ignored)) { // a shape FilterToExpression understands
+				in.filters.push_back({{in.leaves.size() - 1, entry.first}, entry.second.get()});
+			} else {
+				return false;
+			}
+		}
+		return true;
+	}
+	case LogicalOperatorType::LOGICAL_PROJECTION: {
+		// a projection that only passes columns of the scan below it through
+		auto &projection = (LogicalProjection &)op;
+		if (projection.children.size() != 1 ||
+		    (projection.children[0]->type != LogicalOperatorType::LOGICAL_GET &&
+		     projection.children[0]->type != LogicalOperatorType::LOGICAL_FILTER) ||
+		    !CollectJoinTree(*projection.children[0], in)) {
+			return false;
+		}
+		auto child_bindings = projection.children[0]->GetColumnBindings();
+		vector<LeafColumn> columns;
+		for (auto &expr : projection.expressions) {
+			idx_t index;
+			LeafColumn column;
+			if (expr->type != ExpressionType::BOUND_REF ||
+			    (index = ((BoundReferenceExpression &)*expr).index) >= child_bindings.size() ||
+			    !ResolveLeafColumn(in, child_bindings[index], column)) {
+				return false;
+			}
+			columns.push_back(column);
+		}
+		in.aliases.emplace_back(projection.table_index, move(columns));
+		return true;
+	}
+	case LogicalOperatorType::LOGICAL_FILTER: {
+		// predicates the optimizer kept above a scan (e.g. `k2.k_person2id <> X`, interactive-complex-3.sql:11)
+		auto &filter = (LogicalFilter &)op;
+		// (a projection_map only drops columns from the filter's output — the bindings the joins above see
+		// still name the scan's columns; the predicates themselves index the scan's full output)
+		if (filter.children.size() != 1 || filter.children[0]->type != LogicalOperatorType::LOGICAL_GET ||
+		    !CollectJoinTree(*filter.children[0], in)) {
+			return false;
+		}
+		const idx_t leaf = in.leaves.size() - 1;
+		auto &get = *in.leaves[leaf].get;
+		for (auto &expr : filter.expressions) {
+			idx_t ref_index = INVALID_INDEX;
+			auto restated = ExpressionToFilter(*expr, ref_index);
+			if (!restated || ref_index >= get.column_ids.size() || get.column_ids[ref_index] == COLUMN_IDENTIFIER_ROW_ID ||
+			    !ColumnIsIntegerKey(*in.leaves[leaf].table, get.column_ids[ref_index])) {
+				return false;
+			}
+			in.filters.push_back({{leaf, get.column_ids[ref_index]}, restated.get()});
+			in.owned_filters.push_back(move(restated));
 		}
 		return true;
 	}
@@ -501,19 +681,52 @@ bool SolveWithRoles(PatternInput &in, ColumnClasses &classes, TableCatalogEntry 
 	if (!ColumnIsIntegerKey(*edge_table, src) || !ColumnIsIntegerKey(*edge_table, dst)) {
 		return false;
 	}
-	// pinned constants: all on walk position 0 and all the same value (the optimizer copies a constant
-	// to every column it is transitively equal to)
-	out.all_sources = in.constants.empty();
+	// predicates pushed into the scans.  A column is a walk position: src of edge e is position e-1, dst is e,
+	// a vertex leaf's key its own position.  `= c` on position 0 pins the source (the optimizer copies a
+	// constant to every column it is transitively equal to: all copies must agree); everything else stays
+	// a filter on the walks.
+	auto position_of = [&](const LeafColumn &column, idx_t &position) {
+		const auto l = column.leaf;
+		if (out.edge_position[l]) {
+			if (column.column == src) {
+				position = out.edge_position[l] - 1;
+			} else if (column.column == dst) {
+				position = out.edge_position[l];
+			} else {
+				return false;
+			}
+			return true;
+		}
+		if (out.vertex_position[l] != INVALID_INDEX && column.column == vertex_key) {
+			position = out.vertex_position[l];
+			return true;
+		}
+		return false;
+	};
+	out.all_sources = true;
 	out.sources.clear();
+	out.residual.clear();
 	for (auto &constant : in.constants) {
-		const auto l = constant.column.leaf;
-		const bool at_start = (out.edge_position[l] == 1 && constant.column.column == src) ||
-		                      (out.edge_position[l] == 0 && out.vertex_position[l] == 0 &&
-		                       constant.column.column == vertex_key);
-		if (!at_start || (!out.sources.empty() && out.sources[0] != constant.value)) {
+		idx_t position;
+		if (!position_of(constant.column, position)) {
 			return false;
 		}
-		out.sources.assign(1, constant.value);
+		if (position == 0) {
+			if (!out.sources.empty() && out.sources[0] != constant.value) {
+				return false; // contradictory: the reference returns nothing, leave it to it
+			}
+			out.sources.assign(1, constant.value);
+			out.all_sources = false;
+		} else {
+			out.residual.emplace_back(position, constant.filter); // a pinned middle or far end: filtered afterwards
+		}
+	}
+	for (auto &filter : in.filters) {
+		idx_t position;
+		if (!position_of(filter.column, position)) {
+			return false;
+		}
+		out.residual.emplace_back(position, filter.filter);
 	}
 	out.edge_table = edge_table;
 	out.src_column = src;
@@ -557,8 +770,17 @@ bool SolveWalkPattern(PatternInput &in, WalkPattern &out) {
 			continue;
 		}
 		std::sort(used.begin(), used.end()); // prefer reading the table's first key column as the source
-		if (SolveWithRoles(in, classes, edge_table, vertex_table, used[0], used[1], out) ||
-		    SolveWithRoles(in, classes, edge_table, vertex_table, used[1], used[0], out)) {
+		// both readings of the walk's direction may fit; the one that turns a pinned end into the source
+		// (fewer predicates left to filter afterwards) wins
+		WalkPattern forward, backward;
+		const bool fits_forward = SolveWithRoles(in, classes, edge_table, vertex_table, used[0], used[1], forward);
+		const bool fits_backward = SolveWithRoles(in, classes, edge_table, vertex_table, used[1], used[0], backward);
+		if (fits_forward && (!fits_backward || forward.residual.size() <= backward.residual.size())) {
+			out = forward;
+			return true;
+		}
+		if (fits_backward) {
+			out = backward;
 			return true;
 		}
 	}
@@ -796,7 +1018,7 @@ bool SolveSameNeighbourWithRoles(PatternInput &in, ColumnClasses &classes, SameN
 }
 
 bool SolveSameNeighbourPattern(PatternInput &in, SameNeighbourPattern &out) {
-	if (in.leaves.size() < 3 || !in.constants.empty()) {
+	if (in.leaves.size() < 3 || !in.constants.empty() || !in.filters.empty()) {
 		return false;
 	}
 	vector<TableCatalogEntry *> tables;
@@ -1007,6 +1229,16 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 		select_list.push_back(move(ref));
 	}
 	auto scan = MakeExpandScan(pattern, false, op.estimated_cardinality);
+	if (!pattern.residual.empty()) {
+		// predicates on walk positions other than the source: a filter over the scan's (hops, v0, v1, ...)
+		vector<unique_ptr<Expression>> predicates;
+		for (auto &entry : pattern.residual) {
+			predicates.push_back(FilterToExpression(*entry.second, 1 + entry.first));
+		}
+		auto filter = make_unique<PhysicalFilter>(scan->types, move(predicates), op.estimated_cardinality);
+		filter->children.push_back(move(scan));
+		scan = move(filter);
+	}
 	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
 	projection->children.push_back(move(scan));
 	return move(projection);
@@ -1037,8 +1269,8 @@ unique_ptr<PhysicalOperator> PlanCountOverJoinChain(LogicalAggregate &op) {
 	}
 	PatternInput in;
 	WalkPattern pattern;
-	if (!CollectJoinTree(*child, in) || !SolveWalkPattern(in, pattern)) {
-		return nullptr;
+	if (!CollectJoinTree(*child, in) || !SolveWalkPattern(in, pattern) || !pattern.residual.empty()) {
+		return nullptr; // (with a residual predicate the walks must be looked at: the join rule takes the join)
 	}
 	// scan columns: (hops, rows, digest, traversed_edges), one row; every count(*) is `rows`
 	vector<unique_ptr<Expression>> select_list;

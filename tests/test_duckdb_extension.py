@@ -370,3 +370,26 @@ def test_oversized_results_are_produced_part_by_part(db, monkeypatch):
         monkeypatch.delenv("GG_RESULT_BUDGET_MB")
         d.execute("PRAGMA disable_gpu_graph")
         assert np.array_equal(sort_rows(cpu), sort_rows(gpu))
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_plan_rule_predicates_on_walk_positions(db):
+    """Predicates on key columns other than the pinned source stay as a filter above the GPU scan — the
+    friends-of-friends branch of interactive-complex-3.sql:9-11 (`k1.src = C ... AND k2.dst <> X`), ranges,
+    ORs, a pinned far end."""
+    d, vid = db
+    s, x = int(vid[7]), int(vid[100])
+    two = int(d.execute(f"SELECT k2.k_person2id FROM knows k1, knows k2 WHERE k1.k_person1id = {s} "
+                        "AND k1.k_person2id = k2.k_person1id LIMIT 1")[0, 0])
+    lo, hi = int(np.sort(vid)[200]), int(np.sort(vid)[900])
+    cases = [
+        _chain(2, "k2.k_person2id") + f" AND k1.k_person1id = {s} AND k2.k_person2id <> {two}",
+        _chain(2, "k1.k_person1id, k2.k_person2id") + f" AND k2.k_person1id > {lo} AND k2.k_person1id <= {hi}",
+        _chain(2, "count(*)") + f" AND (k1.k_person2id = {x} OR k1.k_person2id = {s})",
+        _chain(3, "k1.k_person1id, k2.k_person1id, k3.k_person1id, k3.k_person2id") +
+        f" AND k1.k_person1id = {s} AND k3.k_person2id = {s}",
+        _chain(2, "count(*)") + f" AND k1.k_person1id <> {s} AND k2.k_person2id < {hi}",
+    ]
+    for sql in cases:
+        cpu, gpu = _both_plans(d, sql)
+        assert cpu.shape[0] > 0 and np.array_equal(sort_rows(cpu), sort_rows(gpu)), sql

@@ -58,6 +58,12 @@ TAKEN = [
     # single source pinned by a constant
     (chain(2, select="k2.k_person2id") + " AND k1.k_person1id = 2", "GG_PATH_EXPAND", "from 2"),
     (chain(2) + " AND k2.k_person2id = 3", "GG_PATH_COUNT", "from 3"),
+    # predicates on other walk positions stay as a filter above the GPU scan (interactive-complex-3.sql:9-11:
+    # `k1.k_person1id = C and k1.k_person2id = k2.k_person1id and k2.k_person2id <> X`)
+    (chain(2, select="k2.k_person2id") + " AND k1.k_person1id = 2 AND k2.k_person2id <> 1", "GG_PATH_EXPAND", "from 2"),
+    (chain(2) + " AND k1.k_person1id > 2", "GG_PATH_EXPAND", "2 hops"),
+    (chain(2) + " AND k2.k_person1id = 2", "GG_PATH_EXPAND", "2 hops"),
+    (chain(3, select="k3.k_person2id") + " AND k1.k_person1id = 1 AND k3.k_person2id = 1", "GG_PATH_EXPAND", "3 hops"),
 ]
 
 LEFT_ALONE = [
@@ -76,8 +82,6 @@ LEFT_ALONE = [
     chain(2, select="k1.k_weight"),
     "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id < k2.k_person1id",
     "SELECT count(*) FROM knows k1 LEFT JOIN knows k2 ON k1.k_person2id = k2.k_person1id",
-    chain(2) + " AND k1.k_person1id > 2",
-    chain(2) + " AND k2.k_person1id = 2",
     # aggregates other than an ungrouped count(*) keep their aggregate; the join under them is still a walk
 ]
 
