@@ -393,3 +393,10 @@ def test_plan_rule_predicates_on_walk_positions(db):
     for sql in cases:
         cpu, gpu = _both_plans(d, sql)
         assert cpu.shape[0] > 0 and np.array_equal(sort_rows(cpu), sort_rows(gpu)), sql
+    # the friends + friends-of-friends derived table of interactive-complex-3.sql:3-12, verbatim shape:
+    # the 2-hop branch of the UNION is substituted, the 1-hop branch and the UNION stay with the reference
+    ic3 = (f"select k_person2id from knows where k_person1id = {s} union "
+           f"select k2.k_person2id from knows k1, knows k2 where k1.k_person1id = {s} "
+           f"and k1.k_person2id = k2.k_person1id and k2.k_person2id <> {s}")
+    cpu, gpu = _both_plans(d, ic3)
+    assert cpu.shape[0] > 10 and np.array_equal(sort_rows(cpu), sort_rows(gpu))
