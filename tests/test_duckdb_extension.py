@@ -400,3 +400,24 @@ def test_plan_rule_predicates_on_walk_positions(db):
            f"and k1.k_person2id = k2.k_person1id and k2.k_person2id <> {s}")
     cpu, gpu = _both_plans(d, ic3)
     assert cpu.shape[0] > 10 and np.array_equal(sort_rows(cpu), sort_rows(gpu))
+
+
+def test_table_functions_accept_views_and_reject_unknown_names(db):
+    """Base tables are read straight from storage; anything else named in a gg function (here a view) goes
+    through a statement on a side connection; unknown names surface as the reference's own binder error."""
+    d, vid = db
+    d.execute("PRAGMA disable_gpu_graph")
+    cut = int(np.sort(vid)[700])
+    d.execute(f"CREATE VIEW knows_low AS SELECT k_person1id AS a, k_person2id AS b FROM knows WHERE k_person1id < {cut}")
+    d.execute(f"CREATE VIEW person_all AS SELECT p_personid AS id FROM person")
+    got = d.execute("SELECT hops, rows FROM gg_khop_count('person_all', 'id', 'knows_low', 'a', 'b', 1, 2) ORDER BY hops")
+    one = int(d.execute("SELECT count(*) FROM person_all p0, knows_low k, person_all p1 WHERE p0.id = k.a AND k.b = p1.id")[0, 0])
+    two = int(d.execute("SELECT count(*) FROM person_all p0, knows_low k1, person_all p1, knows_low k2, person_all p2 "
+                        "WHERE p0.id = k1.a AND k1.b = p1.id AND p1.id = k2.a AND k2.b = p2.id")[0, 0])
+    assert got.tolist() == [[1, one], [2, two]] and one > 0
+    with pytest.raises(RuntimeError, match="(?i)knows_missing|does not exist|not found"):
+        d.execute("SELECT * FROM gg_khop_count('person', 'p_personid', 'knows_missing', 'a', 'b', 1, 1)")
+    with pytest.raises(RuntimeError):
+        d.execute("SELECT * FROM gg_khop_count('person', 'no_such_column', 'knows', 'k_person1id', 'k_person2id', 1, 1)")
+    # the session is still usable after the errors
+    assert int(d.execute("SELECT rows FROM gg_khop_count('person', 'p_personid', 'knows', 'k_person1id', 'k_person2id', 1, 1)")[0, 0]) > 0
