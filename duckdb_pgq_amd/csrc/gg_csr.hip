@@ -5,7 +5,9 @@
 //   (src/execution/operator/join/physical_hash_join.cpp:165-185, src/execution/join_hashtable.cpp:240-302),
 // which inserts every build row single-threaded into a chained pointer table.  Here:
 //   1. k_ht_insert       vertex ids -> open-addressing id hash table (16-byte slots, one cache line
-//                        per probe; dense index = vertex-table position)
+//                        per probe; dense index = vertex-table position); k_id_minmax / k_direct_*: a
+//                        direct-address dictionary instead when the ids span < 2^20 values (the
+//                        reference's perfect-hash-join case)
 //   2. k_densify_hist    (src,dst) ids -> dense (u,v); edges with a non-vertex endpoint get an invalid
 //                        key; fused with the first radix pass's per-wave digit histogram (LDS)
 //   3. LSD radix passes  stable radix-bucket scatter of (u, v, edge position) by u: global prefix scan
@@ -18,6 +20,8 @@
 // No host synchronisation happens between the first launch and the final status read-back.
 // The reverse CSR (in-neighbour lists, needed by the 2-hop product kernel and by pull-style BFS) is
 // derived from the forward CSR's COO view by the same radix machinery (ensure_reverse).
+// gg_vertices_from_edges (end of the file) derives the vertex table itself — the sorted distinct endpoint
+// ids — for join chains that name no vertex table.
 // All integer work, HBM-bound: algorithmic bytes 40E + 16V (with rowid).
 #include "gg_internal.h"
 
