@@ -117,10 +117,16 @@ void IngestTable(ClientContext &context, const GGScanSource &source, PhysicalOpe
 	state.storage.InitializeParallelScan(context, state.parallel_state);
 
 	auto &scheduler = TaskScheduler::GetScheduler(context);
-	// the scan ends in a PCIe copy: measured on the MI355X host, 8 tasks already stage 40 M rows in 33 ms
-	// (19 GB/s); more only add contention, so 16 is the ceiling whatever PRAGMA threads says
+	// the scan ends in a PCIe copy: measured on the MI355X host (PRAGMA threads=256, 40 M rows), 4 tasks
+	// stage the table in 29 ms, 8 in 21-28 ms, 16 in 34-50 ms, 32 in 55-70 ms — past eight the tasks only
+	// contend for the staging block — so 8 (GG_INGEST_TASKS) is the ceiling whatever PRAGMA threads says
+	static const idx_t task_cap = [] {
+		auto env = std::getenv("GG_INGEST_TASKS");
+		const idx_t n = env ? (idx_t)std::strtoull(env, nullptr, 10) : 8;
+		return MaxValue<idx_t>(1, n);
+	}();
 	const idx_t tasks = MaxValue<idx_t>(
-	    1, MinValue<idx_t>(MinValue<idx_t>((idx_t)scheduler.NumberOfThreads(), 16), state.storage.MaxThreads(context)));
+	    1, MinValue<idx_t>(MinValue<idx_t>((idx_t)scheduler.NumberOfThreads(), task_cap), state.storage.MaxThreads(context)));
 	auto producer = scheduler.CreateProducer();
 	state.pending = tasks;
 	for (idx_t i = 0; i < tasks; i++) {
