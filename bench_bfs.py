@@ -20,12 +20,103 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+def graph_sharded(args, pkg, sharding, gg, device, dist, rank, world, vid, src, dst):
+    """one BFS spread over the ranks.  Every rank builds the shard of the vertices it owns
+    from its part of the hash-partitioned edge table, holds the whole frontier, pulls the next frontier words
+    of its vertices and adds its words to the others' with one all-reduce per level (disjoint supports: SUM is
+    OR; 8*V bytes = 3.6 MB at SF100).  Result rows stay sharded."""
+    import torch
+
+    gg.set_edge_rowid(False)
+    gg.append_vertices(vid)
+    s_loc, d_loc = sharding.local_edge_rows(src, dst, rank, world)
+    gg.append_edges(s_loc, d_loc)
+    shard = gg.build_csr_shard(rank, world) if world > 1 else gg.build_csr()
+    on_device = dist is not None and dist.get_backend() == "nccl"
+
+    def run_batch(sources, fetch=False):
+        run = gg.bfs_sharded_begin(shard, sources)
+        levels = pairs = 0
+        while args.max_hops < 0 or levels < args.max_hops:
+            new = run.expand()
+            if dist is not None:
+                if on_device:  # RCCL straight on the words in HBM
+                    words = torch.as_tensor(run, device="cuda")
+                    count = torch.tensor([new], dtype=torch.int64, device="cuda")
+                    dist.all_reduce(words, op=dist.ReduceOp.SUM)
+                    dist.all_reduce(count, op=dist.ReduceOp.SUM)
+                    torch.cuda.synchronize()
+                    new = int(count[0])
+                else:  # rehearsal backend: through the host
+                    words = torch.from_numpy(run.words().view(np.int64))
+                    count = torch.tensor([new], dtype=torch.int64)
+                    dist.all_reduce(words, op=dist.ReduceOp.SUM)
+                    dist.all_reduce(count, op=dist.ReduceOp.SUM)
+                    run.set_words(words.numpy().view(np.uint64))
+                    new = int(count[0])
+            if new == 0:
+                break
+            pairs += new
+            run.commit()
+            levels += 1
+        rows = run.pairs() if fetch else None  # (the rows stay on the device unless somebody wants them)
+        run.close()
+        return levels, pairs, rows
+
+    batches = [pkg.datagen.pick_sources(vid, 64, 0x5EED, batch=b) for b in range(args.batches)]
+    run_batch(batches[0])  # warm-up
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    lv = pairs = 0
+    for b in batches:
+        l, p, _ = run_batch(b)
+        lv += l
+        pairs += p
+    dt = time.perf_counter() - t0
+    _, _, rows = run_batch(batches[-1], fetch=True)
+    # parity: the union of the ranks' rows of the last batch against the whole-graph BFS (rank 0 builds it):
+    # same number of rows and the same sum of all their fields (mod 2^59)
+    ok = None
+    if not args.no_cpu:
+        M = 1 << 59
+        mine = torch.tensor([rows.shape[0], int(rows.astype(np.uint64).sum(dtype=np.uint64) % M)], dtype=torch.int64,
+                            device="cuda" if on_device else "cpu")
+        if dist is not None:
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            g2 = pkg.GG(device)
+            g2.set_edge_rowid(False)
+            g2.append_vertices(vid)
+            g2.append_edges(src, dst)
+            whole = g2.build_csr()
+            expect, _ = g2.bfs64_pairs(whole, batches[-1], args.max_hops)
+            ok = bool(expect.shape[0] == int(mine[0]) and
+                      int(expect.astype(np.uint64).sum(dtype=np.uint64) % M) == int(mine[1]) % M)
+            whole.close()
+            g2.close()
+    if rank == 0:
+        print(json.dumps({"metric": "64-source bitset BFS, graph-sharded (one BFS over all ranks)", "workload": args.workload,
+                          "n_gpus": world, "batches": args.batches, "ms_per_batch": dt / args.batches * 1e3,
+                          "levels_per_batch": lv / args.batches, "reached_pairs_per_batch": pairs / args.batches,
+                          "exchange": "all-reduce(SUM) of 8*V bytes per level" if world > 1 else "none",
+                          "rows_match_whole_graph_bfs": ok}))
+    shard.close()
+    gg.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="sf100")
     ap.add_argument("--batches", type=int, default=16)
     ap.add_argument("--max-hops", type=int, default=-1)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--graph-sharded", action="store_true",
+                    help="N ranks share ONE BFS per batch: the graph is vertex-partitioned (gg_csr_build_shard), every "
+                         "rank pulls the next frontier words of its vertices, one all-reduce of 8*V bytes per level")
     args = ap.parse_args()
     import duckdb_pgq_amd as pkg
     from duckdb_pgq_amd import sharding
@@ -36,11 +127,19 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # GG_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
+        rehearsal = os.environ.get("GG_BENCH_BACKEND", "nccl") != "nccl"
+        torch.cuda.set_device(0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(os.environ.get("GG_BENCH_BACKEND", "nccl"))
 
     vid, src, dst = pkg.datagen.ldbc(args.workload)
-    gg = pkg.GG(int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)
+    backend = os.environ.get("GG_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = (local if backend == "nccl" else 0) if world > 1 else 0
+    gg = pkg.GG(device)
+    if args.graph_sharded:
+        graph_sharded(args, pkg, sharding, gg, device, dist, rank, world, vid, src, dst)
+        return
     gg.append_vertices(vid)
     gg.append_edges(src, dst)
     csr = gg.build_csr()

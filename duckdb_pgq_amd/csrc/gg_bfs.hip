@@ -82,7 +82,8 @@ template <typename DistT>
 __global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ src_dense, int n_src,
                                                  const uint32_t *__restrict__ off, uint64_t *__restrict__ frontier,
                                                  uint64_t *__restrict__ seen, uint64_t *__restrict__ dist8,
-                                                 BfsLevel *__restrict__ lv) {
+                                                 BfsLevel *__restrict__ lv, const int64_t *__restrict__ vid = nullptr,
+                                                 uint32_t part = 0, uint32_t n_parts = 1) {
   // one lane per source; a vertex seeded by several sources is counted once (by its lowest lane)
   const int i = threadIdx.x;
   const uint32_t v = i < n_src ? src_dense[i] : INVALID_U32;
@@ -92,14 +93,17 @@ __global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ sr
     const uint32_t other = __shfl(v, j, 64);
     if (j < i && other == v) first = false;
   }
-  if (valid) {
-    atomicOr((unsigned long long *)&frontier[v], 1ULL << i);
+  // graph-sharded runs: every rank holds the whole frontier, but a vertex's seen word, distances and
+  // statistics live on the rank that owns it
+  const bool mine = valid && (n_parts <= 1 || owns(vid[v], part, n_parts));
+  if (valid) atomicOr((unsigned long long *)&frontier[v], 1ULL << i);
+  if (mine) {
     atomicOr((unsigned long long *)&seen[v], 1ULL << i);
     reinterpret_cast<DistT *>(dist8)[(uint64_t)v * 64 + i] = 0;
   }
-  const uint64_t act = (uint64_t)__popcll(__ballot(first));
-  const uint64_t te = wave_reduce_add_u64(first ? (uint64_t)(off[v + 1] - off[v]) : 0ULL);
-  const uint64_t reached = (uint64_t)__popcll(__ballot(valid));
+  const uint64_t act = (uint64_t)__popcll(__ballot(first && mine));
+  const uint64_t te = wave_reduce_add_u64(first && mine ? (uint64_t)(off[v + 1] - off[v]) : 0ULL);
+  const uint64_t reached = (uint64_t)__popcll(__ballot(mine));
   if (i == 0) {
     lv->n_active = act;
     lv->te = te;
@@ -502,3 +506,187 @@ static int bfs_dispatch(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids
   }
   return bfs_run<uint8_t>(ctx, csr, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, &overflow, pairs);
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Graph-sharded BFS (north_star's layout): the graph is vertex-partitioned over the
+// GPUs (gg_csr_build_shard: a rank holds the reverse-CSR rows of the vertices it owns), every rank holds
+// the whole 8*V-byte frontier, and a level is
+//     expand   each rank pulls the next frontier words of ITS vertices over its reverse rows (k_bfs_pull on
+//              the shard: rows of vertices it does not own are empty, so their words come out zero)
+//     exchange the ranks combine their word arrays — supports are disjoint, so a SUM all-reduce over
+//              RCCL is the bitwise OR (RCCL has no OR reduction) — outside this library (the host owns
+//              the communicator); 3.6 MB per level at SF100
+//     commit   the combined words become the frontier of the next level
+// seen words, distances and the reached (source, vertex, distance) rows stay with the owner: the result is
+// sharded like the graph, its union over the ranks is gg_bfs64_pairs of the whole graph.
+// ------------------------------------------------------------------------------------------------------
+struct gg_bfs_run {
+  gg_ctx *ctx = nullptr;
+  gg_csr *csr = nullptr;
+  int n_src = 0;
+  uint32_t level = 0;
+  int64_t *ids_dev = nullptr;
+  uint64_t *front = nullptr, *next = nullptr, *seen = nullptr, *dist8 = nullptr;
+  gg::BfsLevel *lv = nullptr;
+};
+
+extern "C" void gg_bfs_sharded_end(gg_bfs_run *run) {
+  if (!run) return;
+  gg_ctx *ctx = run->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (void *p : {(void *)run->ids_dev, (void *)run->front, (void *)run->next, (void *)run->seen, (void *)run->dist8,
+                  (void *)run->lv})
+    ctx->dev_free(p);
+  delete run;
+}
+
+extern "C" int gg_bfs_sharded_begin(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, int n_src,
+                                    gg_bfs_run **out) {
+  if (!out) return GG_ERR_INVALID_ARG;
+  *out = nullptr;
+  gg_csr *csr = const_cast<gg_csr *>(csr_c);
+  if (!ctx || !csr || csr->ctx != ctx || n_src < 0 || n_src > GG_BFS_LANES || (n_src && !src_ids))
+    return GG_ERR_INVALID_ARG;
+  if (!csr->roff || !csr->rnbr) GG_TRY(ensure_reverse(ctx, csr));  // a whole CSR works too (one shard)
+  ApiScope scope(ctx);
+  GG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t V = csr->V ? csr->V : 1;
+  gg_bfs_run *run = new gg_bfs_run();
+  run->ctx = ctx;
+  run->csr = csr;
+  run->n_src = n_src;
+  struct Guard {
+    gg_bfs_run *r;
+    bool armed = true;
+    ~Guard() {
+      if (armed) gg_bfs_sharded_end(r);
+    }
+  } guard{run};
+  uint32_t *src_dense = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&run->ids_dev, GG_BFS_LANES * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&src_dense, GG_BFS_LANES * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&run->front, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&run->next, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&run->seen, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&run->dist8, V * 64 * sizeof(uint8_t)));
+  GG_TRY(ctx->dev_alloc((void **)&run->lv, sizeof(BfsLevel)));
+  for (void *p : {(void *)run->ids_dev, (void *)run->front, (void *)run->next, (void *)run->seen, (void *)run->dist8,
+                  (void *)run->lv})
+    ctx->keep(p);
+  if (n_src) GG_HIP(hipMemcpyAsync(run->ids_dev, src_ids, (size_t)n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  GG_HIP(hipStreamSynchronize(s));
+  GG_TRY(lookup_ids(ctx, csr, run->ids_dev, (uint64_t)n_src, src_dense));
+  GG_HIP(hipMemsetAsync(run->front, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(run->next, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(run->seen, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(run->dist8, 0xFF, V * 64 * sizeof(uint8_t), s));
+  GG_HIP(hipMemsetAsync(run->lv, 0, sizeof(BfsLevel), s));
+  if (csr->V)
+    GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<uint8_t>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, run->front,
+              run->seen, run->dist8, run->lv, (const int64_t *)csr->vid, (uint32_t)csr->part, (uint32_t)csr->n_parts);
+  GG_HIP(hipStreamSynchronize(s));
+  guard.armed = false;
+  *out = run;
+  return GG_OK;
+}
+
+extern "C" int gg_bfs_sharded_expand(gg_bfs_run *run, void **next_words_dev, uint64_t *n_words,
+                                     uint64_t *new_pairs_local) {
+  if (!run) return GG_ERR_INVALID_ARG;
+  gg_ctx *ctx = run->ctx;
+  gg_csr *csr = run->csr;
+  GG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (run->level >= 254) {
+    set_error("gg_bfs_sharded: deeper than 254 levels is not supported");
+    return GG_ERR_TOO_LARGE;
+  }
+  const uint64_t V = csr->V;
+  GG_HIP(hipMemsetAsync(run->lv, 0, sizeof(BfsLevel), s));
+  run->level++;
+  if (V) {
+    const uint64_t max_waves = (uint64_t)ctx->num_cus * 32;
+    const uint64_t quads = (V + 3) / 4;
+    const uint64_t waves = quads < max_waves ? quads : max_waves;
+    GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull<uint8_t>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, run->front,
+              run->next, run->seen, V, run->level, csr->off, csr->roff, csr->rnbr, run->dist8, run->lv);
+  }
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, run->lv, sizeof(BfsLevel), hipMemcpyDeviceToHost, s));
+  GG_HIP(hipStreamSynchronize(s));  // the words are complete in memory: the caller's collective may read them
+  BfsLevel h;
+  memcpy(&h, ctx->pin_scratch, sizeof(h));
+  if (next_words_dev) *next_words_dev = run->next;
+  if (n_words) *n_words = V;
+  if (new_pairs_local) *new_pairs_local = h.reached;
+  return GG_OK;
+}
+
+extern "C" int gg_bfs_sharded_words(gg_bfs_run *run, uint64_t *host_words, int write_back) {
+  if (!run || !host_words) return GG_ERR_INVALID_ARG;
+  gg_ctx *ctx = run->ctx;
+  GG_HIP(hipSetDevice(ctx->device));
+  const size_t bytes = run->csr->V * sizeof(uint64_t);
+  if (write_back)
+    GG_HIP(hipMemcpyAsync(run->next, host_words, bytes, hipMemcpyHostToDevice, ctx->stream));
+  else
+    GG_HIP(hipMemcpyAsync(host_words, run->next, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  return GG_OK;
+}
+
+extern "C" int gg_bfs_sharded_commit(gg_bfs_run *run) {
+  if (!run) return GG_ERR_INVALID_ARG;
+  uint64_t *t = run->front;  // the combined words are the next level's frontier
+  run->front = run->next;
+  run->next = t;
+  return GG_OK;
+}
+
+extern "C" int gg_bfs_sharded_pairs(gg_bfs_run *run, gg_result **out_result) {
+  if (!run || !out_result) return GG_ERR_INVALID_ARG;
+  *out_result = nullptr;
+  gg_ctx *ctx = run->ctx;
+  gg_csr *csr = run->csr;
+  ApiScope scope(ctx);
+  GG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t V = csr->V;
+  gg_result *res = new gg_result();
+  res->ctx = ctx;
+  res->k_min = res->k_max = 2;
+  struct Guard {
+    gg_result *r;
+    bool armed = true;
+    ~Guard() {
+      if (armed) gg_result_destroy(r);
+    }
+  } guard{res};
+  if (V) {
+    uint32_t *counts = nullptr;
+    uint64_t *total = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&counts, V * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&total, sizeof(uint64_t)));
+    const unsigned vgrid = (unsigned)((V + 255) / 256);
+    GG_LAUNCH(ctx, "bfs_pairs_count", (k_bfs_pairs_count<uint8_t>), dim3(vgrid), dim3(256), 0,
+              (const uint8_t *)run->dist8, V, run->n_src, counts);
+    GG_TRY(scan_exclusive_u32(ctx, counts, counts, V, total));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    GG_HIP(hipStreamSynchronize(s));
+    const uint64_t rows = ctx->pin_scratch[0];
+    if (rows) {
+      for (int c = 0; c < 3; c++) GG_TRY(ctx->dev_alloc((void **)&res->cols[2][c], rows * sizeof(int64_t)));
+      GG_LAUNCH(ctx, "bfs_pairs_fill", (k_bfs_pairs_fill<uint8_t>), dim3(vgrid), dim3(256), 0, (const uint8_t *)run->dist8,
+                V, run->n_src, (const uint32_t *)counts, (const int64_t *)run->ids_dev, (const int64_t *)csr->vid,
+                res->cols[2][0], res->cols[2][1], res->cols[2][2]);
+      for (int c = 0; c < 3; c++) ctx->keep(res->cols[2][c]);
+      res->rows[2] = rows;
+    }
+  }
+  GG_HIP(hipStreamSynchronize(s));
+  guard.armed = false;
+  *out_result = res;
+  return GG_OK;
+}
+

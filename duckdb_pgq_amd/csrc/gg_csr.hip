@@ -37,12 +37,6 @@ struct BuildStatus {  // device-side status block, copied back once per build
   unsigned long long owned;        // vertices owned by this shard
 };
 
-// shard ownership of a vertex id: independent of table order, so every rank decides it alone
-__device__ __forceinline__ bool owns(int64_t id, uint32_t part, uint32_t n_parts) {
-  // owner = floor(h32 * n_parts / 2^32) with h32 the high half of the multiplicative hash (no division)
-  return n_parts <= 1 || (uint32_t)((((((uint64_t)id * DIG_GOLD) >> 32)) * (uint64_t)n_parts) >> 32) == part;
-}
-
 __global__ __launch_bounds__(256) void k_rowid_iota(int64_t *__restrict__ out, int64_t first, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = first + (int64_t)i;

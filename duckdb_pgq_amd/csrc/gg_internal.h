@@ -270,6 +270,12 @@ __device__ __forceinline__ uint32_t ht_resolve(const HtSlot *__restrict__ ht, ui
   }
 }
 
+// shard ownership of a vertex id: independent of table order, so every rank decides it alone
+__device__ __forceinline__ bool owns(int64_t id, uint32_t part, uint32_t n_parts) {
+  // owner = floor(h32 * n_parts / 2^32) with h32 the high half of the multiplicative hash (no division)
+  return n_parts <= 1 || (uint32_t)((((((uint64_t)id * DIG_GOLD) >> 32)) * (uint64_t)n_parts) >> 32) == part;
+}
+
 // Digest sums are 32-bit: the LOW half of each row hash, summed mod 2^32 (carried in u64 fields whose
 // high half stays zero).  One v_xad_u32 (xor + add) per walk in the product kernel.
 __host__ __device__ __forceinline__ uint64_t dsum_add(uint64_t a, uint64_t b) {

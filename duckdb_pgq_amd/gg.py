@@ -22,6 +22,8 @@ SYMBOLS = [
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
+    "gg_bfs_sharded_begin", "gg_bfs_sharded_expand", "gg_bfs_sharded_words", "gg_bfs_sharded_commit",
+    "gg_bfs_sharded_pairs", "gg_bfs_sharded_end",
     "gg_profile_enable", "gg_profile_select", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
 
@@ -104,6 +106,13 @@ def load_library(path: str | None = None):
     lib.gg_host_free.restype = None
     lib.gg_csr_lookup.argtypes = [P, P, i64p, u64, C.POINTER(C.c_uint32)]
     lib.gg_bfs64_pairs.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
+    lib.gg_bfs_sharded_begin.argtypes = [P, P, i64p, C.c_int, C.POINTER(P)]
+    lib.gg_bfs_sharded_expand.argtypes = [P, C.POINTER(C.c_void_p), C.POINTER(u64), C.POINTER(u64)]
+    lib.gg_bfs_sharded_words.argtypes = [P, C.POINTER(C.c_uint64), C.c_int]
+    lib.gg_bfs_sharded_commit.argtypes = [P]
+    lib.gg_bfs_sharded_pairs.argtypes = [P, C.POINTER(P)]
+    lib.gg_bfs_sharded_end.argtypes = [P]
+    lib.gg_bfs_sharded_end.restype = None
     lib.gg_profile_enable.argtypes = [P, C.c_int]
     lib.gg_profile_select.argtypes = [P, C.c_char_p]
     lib.gg_profile_reset.argtypes = [P]
@@ -117,6 +126,60 @@ def load_library(path: str | None = None):
 def _i64(a):
     a = np.ascontiguousarray(a, dtype=np.int64)
     return a, a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class ShardedBfs:
+    """One rank's state of a graph-sharded BFS (gg_bfs_sharded_*)."""
+
+    def __init__(self, gg: "GG", handle, V: int):
+        self.gg, self.handle, self.V = gg, handle, V
+        self.next_ptr = 0
+
+    def expand(self) -> int:
+        """Pull the next frontier words of the owned vertices; returns the rank's newly reached pairs."""
+        ptr, n, new = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self.gg._chk(self.gg.lib.gg_bfs_sharded_expand(self.handle, C.byref(ptr), C.byref(n), C.byref(new)))
+        self.next_ptr = ptr.value or 0
+        return int(new.value)
+
+    @property
+    def __cuda_array_interface__(self):
+        """The rank's next-frontier words in HBM, for a device-side collective: torch.as_tensor(run, device="cuda")
+        views them as int64[V] (a SUM all-reduce over disjoint supports is the OR of the ranks' words)."""
+        return {"shape": (self.V,), "typestr": "<i8", "data": (self.next_ptr, False), "version": 2}
+
+    def words(self) -> np.ndarray:
+        out = np.empty(self.V, np.uint64)
+        self.gg._chk(self.gg.lib.gg_bfs_sharded_words(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64)), 0))
+        return out
+
+    def set_words(self, words: np.ndarray):
+        w = np.ascontiguousarray(words, np.uint64)
+        self.gg._chk(self.gg.lib.gg_bfs_sharded_words(self.handle, w.ctypes.data_as(C.POINTER(C.c_uint64)), 1))
+
+    def commit(self):
+        self.gg._chk(self.gg.lib.gg_bfs_sharded_commit(self.handle))
+
+    def pairs(self) -> np.ndarray:
+        i64p = C.POINTER(C.c_int64)
+        res = C.c_void_p()
+        self.gg._chk(self.gg.lib.gg_bfs_sharded_pairs(self.handle, C.byref(res)))
+        try:
+            n = C.c_uint64()
+            self.gg._chk(self.gg.lib.gg_result_rows(res, 2, C.byref(n)))
+            out = np.empty((3, n.value), np.int64)
+            if n.value:
+                ptrs = (i64p * 3)(*[out[c].ctypes.data_as(i64p) for c in range(3)])
+                got = C.c_uint32()
+                self.gg._chk(self.gg.lib.gg_result_fetch(res, 2, 0, n.value, ptrs, C.byref(got)))
+        finally:
+            self.gg.lib.gg_result_destroy(res)
+        return out.T.copy()
+
+    def close(self):
+        if self.handle:
+            self.gg.lib.gg_bfs_sharded_end(self.handle)
+            self.handle = None
 
 
 class Csr:
@@ -357,6 +420,38 @@ class GG:
             self.lib.gg_result_destroy(res)
         return out.T.copy(), {"levels": st.levels, "traversed_edges": st.traversed_edges,
                               "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
+
+    # ---- graph-sharded BFS (one shard per GPU; see include/gg.h)
+    def bfs_sharded_begin(self, shard: Csr, sources) -> "ShardedBfs":
+        s, ps = _i64(sources)
+        h = C.c_void_p()
+        self._chk(self.lib.gg_bfs_sharded_begin(self.ctx, shard.handle, ps, s.size, C.byref(h)))
+        return ShardedBfs(self, h, shard.V)
+
+    def bfs_sharded_emulated(self, shards, sources, max_hops: int):
+        """All ranks of a graph-sharded BFS in ONE process (the shards live on this context): the exchange is
+        a host-side sum of the ranks' words.  Returns the union of the ranks' (source, vertex, distance) rows
+        and the number of levels expanded — what N GPUs with an RCCL all-reduce between them produce."""
+        runs = [self.bfs_sharded_begin(c, sources) for c in shards]
+        try:
+            level = 0
+            while max_hops < 0 or level < max_hops:
+                words = np.zeros(runs[0].V, np.uint64)
+                new = 0
+                for r in runs:
+                    new += r.expand()
+                    words += r.words()  # disjoint supports: the sum is the OR
+                if new == 0:
+                    break
+                for r in runs:
+                    r.set_words(words)
+                    r.commit()
+                level += 1
+            rows = [r.pairs() for r in runs]
+            return np.concatenate(rows, axis=0), level
+        finally:
+            for r in runs:
+                r.close()
 
     # ---- profiling
     def profile(self, on: bool):

@@ -207,6 +207,28 @@ int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, 
 int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
                    gg_bfs_stats *stats, gg_result **out_result);
 
+/* ---- graph-sharded 64-lane BFS (one shard of the graph per GPU) ------------------------------- */
+/* The layout north_star names for graphs that do not fit one GPU: `shard` comes from
+ * gg_csr_build_shard; every rank holds the whole frontier (one uint64 of 64 lanes per vertex) and owns the
+ * seen words, distances and result rows of its vertices.  Per level, on every rank:
+ *     gg_bfs_sharded_expand   pull the next frontier words of the owned vertices (zero elsewhere);
+ *                             *next_words_dev points at the n_words uint64 words in HBM
+ *     (exchange)              combine the ranks' words — disjoint supports, so a SUM all-reduce (RCCL through
+ *                             torch.distributed on a view of that memory) is their OR; the library does
+ *                             not own a communicator.  gg_bfs_sharded_words copies the words to / from the
+ *                             host for hosts without a device-side collective (and for tests)
+ *     gg_bfs_sharded_commit   the combined words become the next level's frontier
+ * until no rank reports new pairs (or the hop bound is reached).  gg_bfs_sharded_pairs then returns the
+ * rank's share of the (source, vertex, distance) rows, in the layout of gg_bfs64_pairs; their union over
+ * the ranks is gg_bfs64_pairs on the whole graph.  A whole (unsharded) CSR is accepted as the 1-rank case. */
+typedef struct gg_bfs_run gg_bfs_run;
+int gg_bfs_sharded_begin(gg_ctx *ctx, const gg_csr *shard, const int64_t *src_ids, int n_src, gg_bfs_run **out);
+int gg_bfs_sharded_expand(gg_bfs_run *run, void **next_words_dev, uint64_t *n_words, uint64_t *new_pairs_local);
+int gg_bfs_sharded_words(gg_bfs_run *run, uint64_t *host_words, int write_back);
+int gg_bfs_sharded_commit(gg_bfs_run *run);
+int gg_bfs_sharded_pairs(gg_bfs_run *run, gg_result **out_result);
+void gg_bfs_sharded_end(gg_bfs_run *run);
+
 /* ---- in-library kernel timing (HIP events on the library's own stream) ---------------------- */
 /* Testing knob: force gg_expand_khop to use the frontier kernels even where the product kernel
  * applies (both must give identical results). */

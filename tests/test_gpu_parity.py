@@ -771,3 +771,29 @@ def test_perfect_hash_join_vectors_of_the_reference(gg, orc, keys):
     assert np.diff(off).tolist() == [5, 5, 5] and np.array_equal(vid[nbr], np.repeat(vid, 5))
     csr.close()
     g.close()
+
+
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8])
+@pytest.mark.parametrize("V,E,seed,max_hops", [(300, 2500, 31, -1), (3000, 40000, 32, 3), (40, 35, 33, 6)])
+def test_graph_sharded_bfs_equals_the_whole_graph_bfs(gg, orc, n_parts, V, E, seed, max_hops):
+    """the graph vertex-partitioned over N ranks, every rank pulling the next frontier
+    words of its own vertices, words combined between levels (here on the host; over RCCL on N GPUs).  The
+    union of the ranks' (source, vertex, distance) rows must be the unsharded BFS, i.e. the recursive CTE."""
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=3)
+    sources = np.concatenate([datagen.pick_sources(vid, 40, seed), np.array([-9], np.int64)])
+    gg.staging_clear()
+    gg.set_edge_rowid(False)
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    whole = gg.build_csr()
+    expect, st = gg.bfs64_pairs(whole, sources, max_hops)
+    shards = [gg.build_csr_shard(p, n_parts) for p in range(n_parts)] if n_parts > 1 else [whole]
+    got, levels = gg.bfs_sharded_emulated(shards, sources, max_hops)
+    assert np.array_equal(sort_rows(got), sort_rows(expect))
+    cte = orc.cte_shortest(vid, src, dst, sources[:-1], max_hops if max_hops >= 0 else V)
+    assert np.array_equal(sort_rows(got[:, [0, 1, 2]]), sort_rows(cte))
+    for c in shards:
+        if c is not whole:
+            c.close()
+    whole.close()
+    gg.set_edge_rowid(True)

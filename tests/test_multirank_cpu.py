@@ -163,3 +163,87 @@ def test_local_edge_rows_cover_every_shard_need():
         else:
             expect = src.size * (2.0 / n - 1.0 / n**2)  # on average; hubs make single ranks deviate
             assert abs(sum(sizes) / n - expect) < 0.1 * expect and max(sizes) < 1.6 * expect
+
+
+def _graph_sharded_worker(rank, world, port, q):
+    """Graph-sharded BFS (bench_bfs.py --graph-sharded, gg_bfs_sharded_*): every rank holds the frontier words
+    of all vertices and the in-neighbour lists of the vertices it owns; a level = pull the owned vertices'
+    next words, all-reduce(SUM) the word arrays (disjoint supports: the sum is the OR), commit.  Per-rank
+    compute here is numpy over the oracle's CSR; the union of the ranks' rows must be the oracle's BFS."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = oracle_lib.load()
+        vid, src, dst = datagen.small_graph(300, 2200, 57, dangling=3)
+        rc, g = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        off, nbr, _, _ = g.arrays()
+        V = vid.size
+        # in-neighbour lists of the owned vertices only (what gg_csr_build_shard keeps on this rank)
+        own = sharding.owner_of(vid, world) == rank
+        rows = np.repeat(np.arange(V), np.diff(off))
+        keep = own[nbr]
+        order = np.argsort(nbr[keep], kind="stable")
+        in_dst, in_src = nbr[keep][order], rows[keep][order]
+        roff = np.searchsorted(in_dst, np.arange(V + 1))
+        sources = datagen.pick_sources(vid, 20, 9)
+        sd = g.lookup(sources)
+        front = np.zeros(V, np.uint64)
+        seen = np.zeros(V, np.uint64)
+        dist_local = {}
+        for lane, v in enumerate(sd):
+            front[v] |= np.uint64(1) << np.uint64(lane)
+            if own[v]:
+                seen[v] |= np.uint64(1) << np.uint64(lane)
+                dist_local[(lane, int(v))] = 0
+        level = 0
+        while True:
+            level += 1
+            nxt = np.zeros(V, np.uint64)
+            new = 0
+            for w in np.nonzero(own)[0]:
+                acc = np.bitwise_or.reduce(front[in_src[roff[w]:roff[w + 1]]]) if roff[w + 1] > roff[w] else np.uint64(0)
+                nw = acc & ~seen[w]
+                if nw:
+                    nxt[w] = nw
+                    seen[w] |= nw
+                    for lane in range(len(sd)):
+                        if (int(nw) >> lane) & 1:
+                            dist_local[(lane, int(w))] = level
+                            new += 1
+            words = torch.from_numpy(nxt.view(np.int64))
+            count = torch.tensor([new], dtype=torch.int64)
+            dist.all_reduce(words, op=dist.ReduceOp.SUM)  # disjoint supports: SUM == OR
+            dist.all_reduce(count, op=dist.ReduceOp.SUM)
+            if int(count[0]) == 0:
+                break
+            front = words.numpy().view(np.uint64).copy()
+        # union over ranks == the oracle's whole-graph BFS
+        d, _ = g.bfs64(sd, -1)
+        mine = sorted((lane, v, h) for (lane, v), h in dist_local.items())
+        expect = sorted((int(l), int(v), int(d[l, v])) for l, v in zip(*np.nonzero(d >= 0)) if own[v])
+        assert mine == expect, (rank, len(mine), len(expect))
+        total = torch.tensor([len(mine)], dtype=torch.int64)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        assert int(total[0]) == int((d >= 0).sum())
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_graph_sharded_bfs_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
