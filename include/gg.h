@@ -21,13 +21,19 @@
  *        <- PhysicalHashJoin::Execute -> JoinHashTable::Probe + ScanStructure::NextInnerJoin (chain of k joins)
  *                                                               physical_hash_join.cpp:217-254, join_hashtable.cpp:304-476
  *           (fixed-length path expansion; fetch hands back <=1024-row slices = one DataChunk)
- *   gg_bfs64
+ *   gg_bfs64 / gg_bfs64_pairs / gg_bfs_sharded_* (one BFS over a vertex-partitioned graph, several GPUs)
  *        <- PhysicalRecursiveCTE::{Sink,GetData,ExecuteRecursivePipelines} + GroupedAggregateHashTable::FindOrCreateGroups
  *           + PhysicalHashAggregate (min(hopCount) GROUP BY start, friend)
  *                                                               src/execution/operator/set/physical_recursive_cte.cpp:48-139,
  *                                                               src/execution/aggregate_hashtable.cpp:367-504,
  *                                                               src/execution/operator/aggregate/physical_hash_aggregate.cpp:152-266
  *           (the friends/friends_shortest CTE pair of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31)
+ *   gg_vertices_from_edges
+ *        <- the implicit vertex set of a join chain over an edge table alone (interactive-complex-3.sql:9-11)
+ *   gg_result_filter_common_neighbour
+ *        <- the six monitoredBy hash joins of benchmark/trainbenchmark/queries/connectedsegments.sql:1-25
+ *   gg_csr_lookup
+ *        <- JoinHashTable::Probe of plain keys                 join_hashtable.cpp:304-330
  *
  * Conventions
  *   - every int-returning function returns GG_OK (0) or a negative GG_ERR_*; the message is
@@ -103,12 +109,13 @@ int gg_ctx_set_edge_rowid(gg_ctx *ctx, int keep);
  * deterministic.  Staged columns stay resident, so the build can be repeated.
  * Fails with GG_ERR_DUPLICATE_VERTEX if the vertex key column is not unique. */
 int gg_csr_build(gg_ctx *ctx, gg_csr **out);
-/* Multi-GPU sharding of the whole hot path with NO data-path collective: every rank holds the same
- * staged base tables and builds only the CSR rows of the vertices it owns (owner = hash(vertex id)
- * mod n_parts): forward rows of owned sources, reverse rows of owned destinations.  Non-owned edge
- * rows are skipped before the id lookups.  gg_expand_khop(all sources, k_min..2, count) on a shard
- * returns the walks whose MIDDLE vertex (1-hop rows: destination) is owned; over all parts the
- * counts add and the digests add lane-wise.  Other operations reject a shard (GG_ERR_STATE). */
+/* Multi-GPU sharding of the whole hot path with NO data-path collective: every rank stages the vertex
+ * table and (at least) the edge rows with an endpoint it owns, and builds only the CSR rows of the vertices
+ * it owns (owner = hash(vertex id) mod n_parts): forward rows of owned sources, reverse rows of owned
+ * destinations.  Other edge rows are skipped before the id lookups, so staging the whole table works too.
+ * gg_expand_khop(all sources, k_min..2, count) on a shard returns the walks whose MIDDLE vertex (1-hop
+ * rows: destination) is owned; over all parts the counts add and the digests add mod 2^32.  gg_bfs_sharded_*
+ * runs a BFS over the shards; other operations reject a shard (GG_ERR_STATE). */
 int gg_csr_build_shard(gg_ctx *ctx, int part, int n_parts, gg_csr **out);
 void gg_csr_destroy(gg_csr *csr);
 /* Probe the CSR's id dictionary: dense_out[i] = dense index (vertex-table position) of ids[i], or
