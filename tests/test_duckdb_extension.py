@@ -87,8 +87,8 @@ def test_null_keys_and_int32_columns_follow_join_semantics(db):
 
 def test_connectedsegments_gpu_table_function_vs_reference_query():
     """BASELINE.json configs[4] inside the reference: its own ConnectedSegments query (11 hash joins,
-    benchmark/trainbenchmark/queries/connectedsegments.sql, text reproduced from the reference's
-    .benchmark file) and the GPU operator run on the same tables; both must give the golden rows."""
+    benchmark/trainbenchmark/queries/connectedsegments.sql) and the GPU operator run on the same tables;
+    both must give the golden rows."""
     from tests import trainbenchmark as tb
 
     d = R.RefDuckDB(threads=4)
@@ -99,23 +99,11 @@ def test_connectedsegments_gpu_table_function_vs_reference_query():
     d.load_table("connectsTo", {"TrackElement1_id": t["connectsTo"][:, 0], "TrackElement2_id": t["connectsTo"][:, 1]})
     d.load_table("monitoredBy", {"TrackElement_id": t["monitoredBy"][:, 0], "Sensor_id": t["monitoredBy"][:, 1]})
     d.execute(f"LOAD '{EXT}'")
-    cpu = d.execute("""
-        SELECT mb1.Sensor_id, ct1.TrackElement1_id, ct2.TrackElement1_id, ct3.TrackElement1_id,
-               ct4.TrackElement1_id, ct5.TrackElement1_id, ct5.TrackElement2_id
-        FROM Segment
-        INNER JOIN connectsTo as ct1 ON Segment.id = ct1.TrackElement1_id
-        INNER JOIN connectsTo as ct2 ON ct1.TrackElement2_id = ct2.TrackElement1_id
-        INNER JOIN connectsTo as ct3 ON ct2.TrackElement2_id = ct3.TrackElement1_id
-        INNER JOIN connectsTo as ct4 ON ct3.TrackElement2_id = ct4.TrackElement1_id
-        INNER JOIN connectsTo as ct5 ON ct4.TrackElement2_id = ct5.TrackElement1_id
-        INNER JOIN monitoredBy as mb1 ON mb1.TrackElement_id = ct1.TrackElement1_id
-        INNER JOIN monitoredBy as mb2 ON mb2.TrackElement_id = ct2.TrackElement1_id
-        INNER JOIN monitoredBy as mb3 ON mb3.TrackElement_id = ct3.TrackElement1_id
-        INNER JOIN monitoredBy as mb4 ON mb4.TrackElement_id = ct4.TrackElement1_id
-        INNER JOIN monitoredBy as mb5 ON mb5.TrackElement_id = ct5.TrackElement1_id
-        INNER JOIN monitoredBy as mb6 ON mb6.TrackElement_id = ct5.TrackElement2_id
-        WHERE mb1.Sensor_id = mb2.Sensor_id AND mb1.Sensor_id = mb3.Sensor_id AND mb1.Sensor_id = mb4.Sensor_id
-          AND mb1.Sensor_id = mb5.Sensor_id AND mb1.Sensor_id = mb6.Sensor_id""")
+    # the reference's query (benchmark/trainbenchmark/queries/connectedsegments.sql:1-25), built by the
+    # same generator the planner-rule tests use: 5 connectsTo joins, 6 monitoredBy joins, sensors equal
+    from tests.test_plan_rule import connectedsegments_sql
+
+    cpu = d.execute(connectedsegments_sql(5))
     gpu = d.execute("""SELECT * FROM gg_same_neighbour_paths(
         'SELECT id FROM TrackElement UNION ALL SELECT id FROM Sensor', 'SELECT id FROM Segment',
         'connectsTo', 'TrackElement1_id', 'TrackElement2_id', 'monitoredBy', 'TrackElement_id', 'Sensor_id', 5)""")
