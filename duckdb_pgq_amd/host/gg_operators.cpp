@@ -189,7 +189,31 @@ class GGSinkLocalState : public LocalSinkState {
 public:
 	vector<vector<int64_t>> columns; // per-thread conversion buffers, reused across chunks
 	vector<const int64_t *> keys;    // what is handed to gg_*_append: the chunk's own vectors or `columns`
+	// Edge rows are batched per thread and handed to the staging area BATCH_ROWS at a time: one reservation
+	// per 64 chunks instead of one per chunk keeps a dozen Sink threads off each other's reservation lock
+	// (GG_SINK_BATCH_ROWS; 1024 = unbatched)
+	vector<int64_t> batch[3];
+	idx_t batch_rows = 0;
 };
+
+static idx_t SinkBatchRows() {
+	static const idx_t rows = [] {
+		auto env = std::getenv("GG_SINK_BATCH_ROWS");
+		const idx_t n = env ? (idx_t)std::strtoull(env, nullptr, 10) : 64 * STANDARD_VECTOR_SIZE;
+		return MaxValue<idx_t>(n, STANDARD_VECTOR_SIZE);
+	}();
+	return rows;
+}
+
+static void FlushEdgeBatch(GGGraph &graph, GGSinkLocalState &lstate, bool has_rowid) {
+	if (lstate.batch_rows == 0) {
+		return;
+	}
+	GGGraph::Check(gg_edges_append(graph.ctx, lstate.batch[0].data(), lstate.batch[1].data(),
+	                               has_rowid ? lstate.batch[2].data() : nullptr, lstate.batch_rows),
+	               "gg_edges_append");
+	lstate.batch_rows = 0;
+}
 
 PhysicalGGVertexSink::PhysicalGGVertexSink(shared_ptr<GGGraph> graph_p, vector<LogicalType> types,
                                            idx_t estimated_cardinality)
@@ -253,13 +277,27 @@ SinkResultType PhysicalGGEdgeSink::Sink(ExecutionContext &context, GlobalSinkSta
 	const bool has_rowid = input.ColumnCount() >= 3;
 	idx_t n = has_rowid ? GGKeyColumns(input, {0, 1, 2}, lstate.columns, lstate.keys)
 	                    : GGKeyColumns(input, {0, 1}, lstate.columns, lstate.keys);
-	GGGraph::Check(gg_edges_append(graph->ctx, lstate.keys[0], lstate.keys[1], has_rowid ? lstate.keys[2] : nullptr, n),
-	               "gg_edges_append");
+	const idx_t capacity = SinkBatchRows();
+	const idx_t ncols = has_rowid ? 3 : 2;
+	if (lstate.batch[0].size() < capacity) {
+		for (idx_t c = 0; c < ncols; c++) {
+			lstate.batch[c].resize(capacity);
+		}
+	}
+	if (lstate.batch_rows + n > capacity) {
+		FlushEdgeBatch(*graph, lstate, has_rowid);
+	}
+	for (idx_t c = 0; c < ncols; c++) {
+		memcpy(lstate.batch[c].data() + lstate.batch_rows, lstate.keys[c], n * sizeof(int64_t));
+	}
+	lstate.batch_rows += n;
 	gstate.rows += n;
 	return SinkResultType::NEED_MORE_INPUT;
 }
 
-void PhysicalGGEdgeSink::Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const {
+void PhysicalGGEdgeSink::Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate_p) const {
+	auto &lstate = (GGSinkLocalState &)lstate_p;
+	FlushEdgeBatch(*graph, lstate, !lstate.batch[2].empty());
 }
 
 SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
