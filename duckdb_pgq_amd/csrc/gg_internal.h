@@ -127,6 +127,9 @@ struct gg_ctx {
   std::vector<HostBlock> host_blocks;
 
   // ---- caching device allocator ----
+  // pool_mu: compute calls on one context are externally serialised, but results of earlier calls are
+  // destroyed (their blocks freed) from whatever thread finishes with them
+  std::mutex pool_mu;
   std::vector<gg::DevBlock> blocks;
   size_t bytes_allocated = 0;
 
@@ -195,6 +198,7 @@ struct ApiScope {
   explicit ApiScope(gg_ctx *c) : ctx(c), mark(c ? c->next_serial : 0) {}
   ~ApiScope() {
     if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
     for (auto &b : ctx->blocks)
       if (b.in_use && !b.keep && b.serial >= mark) b.in_use = false;
   }

@@ -40,6 +40,7 @@ extern "C" int gg_device_count(int *out_count) {
 // blocks are recycled instead of hipMalloc/hipFree inside the hot path (guide: Guideline 9).
 // ------------------------------------------------------------------------------------------
 int gg_ctx::dev_alloc(void **out, size_t bytes) {
+  std::lock_guard<std::mutex> lk(pool_mu);
   if (bytes == 0) bytes = 256;
   bytes = (bytes + 255) & ~size_t(255);
   int best = -1;
@@ -82,6 +83,7 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
 
 void gg_ctx::keep(void *p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lk(pool_mu);
   for (auto &b : blocks)
     if (b.ptr == p) {
       b.keep = true;
@@ -91,6 +93,7 @@ void gg_ctx::keep(void *p) {
 
 void gg_ctx::dev_free(void *p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lk(pool_mu);
   for (auto &b : blocks)
     if (b.ptr == p) {
       b.in_use = false;

@@ -28,6 +28,8 @@
 
 #include "duckdb.hpp"
 #include "duckdb/catalog/catalog.hpp"
+#include "duckdb/catalog/catalog_entry/table_catalog_entry.hpp"
+#include "duckdb/storage/data_table.hpp"
 #include "duckdb/common/exception.hpp"
 #include "duckdb/function/table_function.hpp"
 #include "duckdb/main/client_context.hpp"
@@ -69,7 +71,61 @@ struct PhaseTimer {
 	}
 };
 
-shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec) {
+//===--------------------------------------------------------------------===//
+// Pinned graphs
+//===--------------------------------------------------------------------===//
+// Every statement reads its base tables again (like the hash-join builds it replaces), which makes a
+// selective query — one source, two hops — pay for the whole edge table.  `gg_graph_pin(...)` builds the
+// graph of a (vertex table, key, edge table, src, dst) combination once and keeps it on the device, the way
+// a property graph or an index is declared once; table functions and planner rules that need exactly that
+// graph then skip ingest and build.  A pinned graph is a SNAPSHOT (this version of the reference has no
+// per-table modification counter to hang an invalidation on): it is dropped when a table's row count no
+// longer matches — which catches appends, not updates or deletes — and by gg_graph_unpin(); pin again
+// after changing the tables.
+struct PinnedGraph {
+	idx_t vertex_oid, edge_oid; // catalog oids (never reused), vertex_oid = 0: vertex set = endpoint ids
+	column_t vertex_key, src, dst;
+	idx_t vertex_rows, edge_rows;
+	shared_ptr<GGGraph> graph;
+};
+static mutex g_pinned_lock;
+static vector<PinnedGraph> g_pinned;
+
+static bool PinKey(const GGGraphSpec &spec, PinnedGraph &key) {
+	if (!spec.edges.table || spec.edges.columns.size() != 2 || (!spec.vertices.Empty() && !spec.vertices.table)) {
+		return false; // only plain tables, and no rowid payload
+	}
+	key.edge_oid = spec.edges.table->oid;
+	key.src = spec.edges.columns[0];
+	key.dst = spec.edges.columns[1];
+	key.edge_rows = spec.edges.table->storage->GetTotalRows();
+	key.vertex_oid = spec.vertices.table ? spec.vertices.table->oid : 0;
+	key.vertex_key = spec.vertices.table ? spec.vertices.columns[0] : 0;
+	key.vertex_rows = spec.vertices.table ? spec.vertices.table->storage->GetTotalRows() : 0;
+	return true;
+}
+
+static shared_ptr<GGGraph> FindPinned(const GGGraphSpec &spec) {
+	PinnedGraph key;
+	if (!PinKey(spec, key)) {
+		return nullptr;
+	}
+	lock_guard<mutex> guard(g_pinned_lock);
+	for (idx_t i = 0; i < g_pinned.size(); i++) {
+		auto &p = g_pinned[i];
+		if (p.vertex_oid == key.vertex_oid && p.edge_oid == key.edge_oid && p.vertex_key == key.vertex_key &&
+		    p.src == key.src && p.dst == key.dst) {
+			if (p.vertex_rows == key.vertex_rows && p.edge_rows == key.edge_rows) {
+				return p.graph;
+			}
+			g_pinned.erase(g_pinned.begin() + i); // rows were appended (or the table rebuilt): stale
+			return nullptr;
+		}
+	}
+	return nullptr;
+}
+
+static shared_ptr<GGGraph> BuildGraphNow(ClientContext &context, const GGGraphSpec &spec) {
 	PhaseTimer timer;
 	auto graph = make_shared<GGGraph>(0);
 	timer.Lap("device context");
@@ -83,6 +139,13 @@ shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec
 	GGRunSinkPipeline(context, spec.edges, esink);
 	timer.Lap("edge ingest + CSR build");
 	return graph;
+}
+
+shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec) {
+	if (auto pinned = FindPinned(spec)) {
+		return pinned;
+	}
+	return BuildGraphNow(context, spec);
 }
 
 //! (vertex_table, vertex_key, edge_table, src_col, dst_col) arguments -> scans, resolved at execution time
@@ -314,6 +377,93 @@ static unique_ptr<FunctionData> ShortestBind(ClientContext &context, vector<Valu
 	return move(data);
 }
 
+//! gg_graph_pin(vertex_table, vertex_key, edge_table, src_col, dst_col) -> (vertices, edges, build_ms);
+//! vertex_table = '' pins the edge-only form (vertex set = endpoint ids).  gg_graph_unpin() drops all.
+struct PinResultData : public TableFunctionData {
+	int64_t vertices = 0, edges = 0;
+	double build_ms = 0;
+	bool done = false;
+};
+
+static unique_ptr<FunctionData> GraphPinBind(ClientContext &context, vector<Value> &inputs,
+                                             unordered_map<string, Value> &named_parameters,
+                                             vector<LogicalType> &input_table_types, vector<string> &input_table_names,
+                                             vector<LogicalType> &return_types, vector<string> &names) {
+	const string vertex_table = inputs[0].ToString();
+	GGGraphSpec spec;
+	if (!vertex_table.empty()) {
+		spec.vertices = GGTableSource(context, vertex_table, {inputs[1].ToString()}, false);
+	}
+	spec.edges = GGTableSource(context, inputs[2].ToString(), {inputs[3].ToString(), inputs[4].ToString()}, false);
+	PinnedGraph pin;
+	if (!PinKey(spec, pin)) {
+		throw BinderException("gg_graph_pin: only base tables can be pinned");
+	}
+	auto t0 = std::chrono::steady_clock::now();
+	pin.graph = BuildGraphNow(context, spec);
+	auto result = make_unique<PinResultData>();
+	result->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	uint64_t v = 0, e = 0;
+	GGGraph::Check(gg_csr_info(pin.graph->csr, &v, &e, nullptr), "gg_csr_info");
+	result->vertices = (int64_t)v;
+	result->edges = (int64_t)e;
+	{
+		lock_guard<mutex> guard(g_pinned_lock);
+		for (idx_t i = 0; i < g_pinned.size(); i++) { // replace an older pin of the same combination
+			auto &p = g_pinned[i];
+			if (p.vertex_oid == pin.vertex_oid && p.edge_oid == pin.edge_oid && p.vertex_key == pin.vertex_key &&
+			    p.src == pin.src && p.dst == pin.dst) {
+				g_pinned.erase(g_pinned.begin() + i);
+				break;
+			}
+		}
+		g_pinned.push_back(move(pin));
+	}
+	return_types = {LogicalType::BIGINT, LogicalType::BIGINT, LogicalType::DOUBLE};
+	names = {"vertices", "edges", "build_ms"};
+	return move(result);
+}
+
+static void GraphPinFunction(ClientContext &context, const FunctionData *bind_data, FunctionOperatorData *operator_state,
+                             DataChunk *input, DataChunk &output) {
+	auto &data = (PinResultData &)*bind_data;
+	if (data.done) {
+		return;
+	}
+	data.done = true;
+	output.SetValue(0, 0, Value::BIGINT(data.vertices));
+	output.SetValue(1, 0, Value::BIGINT(data.edges));
+	output.SetValue(2, 0, Value::DOUBLE(data.build_ms));
+	output.SetCardinality(1);
+}
+
+static unique_ptr<FunctionData> GraphUnpinBind(ClientContext &context, vector<Value> &inputs,
+                                               unordered_map<string, Value> &named_parameters,
+                                               vector<LogicalType> &input_table_types,
+                                               vector<string> &input_table_names, vector<LogicalType> &return_types,
+                                               vector<string> &names) {
+	auto result = make_unique<PinResultData>();
+	{
+		lock_guard<mutex> guard(g_pinned_lock);
+		result->vertices = (int64_t)g_pinned.size();
+		g_pinned.clear();
+	}
+	return_types = {LogicalType::BIGINT};
+	names = {"unpinned"};
+	return move(result);
+}
+
+static void GraphUnpinFunction(ClientContext &context, const FunctionData *bind_data, FunctionOperatorData *operator_state,
+                               DataChunk *input, DataChunk &output) {
+	auto &data = (PinResultData &)*bind_data;
+	if (data.done) {
+		return;
+	}
+	data.done = true;
+	output.SetValue(0, 0, Value::BIGINT(data.vertices));
+	output.SetCardinality(1);
+}
+
 static void LoadInternal(DatabaseInstance &db) {
 	const vector<LogicalType> graph_args = {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
 	                                        LogicalType::VARCHAR, LogicalType::VARCHAR};
@@ -332,8 +482,10 @@ static void LoadInternal(DatabaseInstance &db) {
 	                                LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
 	                                LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::BIGINT},
 	                               FilteredPathsBind);
+	TableFunction pin("gg_graph_pin", graph_args, GraphPinFunction, GraphPinBind);
+	TableFunction unpin("gg_graph_unpin", {}, GraphUnpinFunction, GraphUnpinBind);
 	CreateTableFunctionInfo khop_info(khop), khop_count_info(khop_count), shortest_info(shortest),
-	    filtered_info(filtered);
+	    filtered_info(filtered), pin_info(pin), unpin_info(unpin);
 
 	Connection con(db);
 	con.BeginTransaction();
@@ -342,6 +494,8 @@ static void LoadInternal(DatabaseInstance &db) {
 	catalog.CreateTableFunction(*con.context, &khop_count_info);
 	catalog.CreateTableFunction(*con.context, &shortest_info);
 	catalog.CreateTableFunction(*con.context, &filtered_info);
+	catalog.CreateTableFunction(*con.context, &pin_info);
+	catalog.CreateTableFunction(*con.context, &unpin_info);
 	GGRegisterPlanRules(*con.context);
 	con.Commit();
 }

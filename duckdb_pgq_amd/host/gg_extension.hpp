@@ -60,6 +60,7 @@ vector<int64_t> GGScanInt64Column(ClientContext &context, const GGScanSource &so
 //! (schema.)table resolved in the catalog, or a SQL fallback `SELECT columns FROM name` for views
 GGScanSource GGTableSource(ClientContext &context, const string &table_name, const vector<string> &columns,
                            bool with_rowid);
+//! Builds the graph — or hands back the pinned one for exactly these tables and columns (gg_graph_pin).
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec);
 
 //! first column of `sql` (run on a side connection) as int64, NULLs skipped

@@ -46,6 +46,12 @@ def main():
             "SELECT count(*), sum(hopCount) FROM (SELECT startPerson, friend, min(hopCount) AS hopCount "
             "FROM friends GROUP BY startPerson, friend) t"),
     }
+    s0 = int(vid[7])
+    # the friends + friends-of-friends derived table of interactive-complex-3.sql:3-12 (one source)
+    queries["ic3_friends_of_friends"] = (
+        f"select count(*) from (select k_person2id from knows where k_person1id = {s0} union "
+        f"select k2.k_person2id from knows k1, knows k2 where k1.k_person1id = {s0} "
+        f"and k1.k_person2id = k2.k_person1id and k2.k_person2id <> {s0}) f")
     out = {"scale": a.scale, "threads": a.threads, "rows": int(src.size), "load_s": round(load_s, 2), "queries": {}}
     for name, sql in queries.items():
         rec = {}
@@ -54,6 +60,12 @@ def main():
         gpu, best = d.timed(sql, runs=a.gpu_runs)
         rec["gpu_s"] = round(best, 4)
         rec["result"] = gpu.tolist()
+        # the same statement with the graph pinned on the device (gg_graph_pin): no ingest, no build
+        d.execute("SELECT * FROM gg_graph_pin('', '', 'knows', 'k_person1id', 'k_person2id')")
+        pinned, best = d.timed(sql, runs=a.gpu_runs)
+        rec["gpu_pinned_s"] = round(best, 5)
+        assert np.array_equal(pinned, gpu)
+        d.execute("SELECT * FROM gg_graph_unpin()")
         d.execute("PRAGMA disable_gpu_graph")
         if not a.skip_cpu:
             cpu, best = d.timed(sql, runs=a.cpu_runs)

@@ -409,3 +409,59 @@ def test_table_functions_accept_views_and_reject_unknown_names(db):
         d.execute("SELECT * FROM gg_khop_count('person', 'no_such_column', 'knows', 'k_person1id', 'k_person2id', 1, 1)")
     # the session is still usable after the errors
     assert int(d.execute("SELECT rows FROM gg_khop_count('person', 'p_personid', 'knows', 'k_person1id', 'k_person2id', 1, 1)")[0, 0]) > 0
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_pinned_graphs_are_reused_and_dropped_when_rows_are_appended(db):
+    """gg_graph_pin builds a graph once and keeps it on the device; statements that need exactly that graph
+    skip ingest and build.  It is a snapshot: appending rows makes the row count differ, the pin is dropped
+    and the statement reads the table again."""
+    import time
+
+    d, vid = db
+    d.execute("CREATE TABLE pk (a BIGINT NOT NULL, b BIGINT NOT NULL)")
+    d.execute("INSERT INTO pk SELECT k_person1id, k_person2id FROM knows")
+    sql = "SELECT count(*) FROM pk k1, pk k2 WHERE k1.b = k2.a"
+    expect = int(d.execute(sql)[0, 0])
+    one = "SELECT k2.b FROM pk k1, pk k2 WHERE k1.b = k2.a AND k1.a = %d" % int(vid[5])
+    expect_one = sort_rows(d.execute(one))
+    d.execute("PRAGMA enable_gpu_graph")
+    assert int(d.execute(sql)[0, 0]) == expect
+    pinned = d.execute("SELECT vertices, edges FROM gg_graph_pin('', '', 'pk', 'a', 'b')")
+    assert pinned[0, 1] == int(d.execute("SELECT count(*) FROM pk")[0, 0])
+    t = time.perf_counter()
+    for _ in range(5):
+        assert int(d.execute(sql)[0, 0]) == expect
+        assert np.array_equal(sort_rows(d.execute(one)), expect_one)
+    with_pin = (time.perf_counter() - t) / 5
+    # concurrent statements on one pinned graph
+    import threading
+    out, errs = [], []
+
+    def work():
+        try:
+            c = d.connect()
+            for _ in range(3):
+                out.append(int(c.execute(sql)[0, 0]))
+                out.append(sort_rows(c.execute(one)).shape[0])
+            c.close()
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=work) for _ in range(3)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs and sorted(set(out)) == sorted({expect, expect_one.shape[0]})
+    # rows appended: the pin no longer matches the table and is dropped
+    d.execute("INSERT INTO pk VALUES (%d, %d)" % (int(vid[5]), int(vid[6])))
+    d.execute("PRAGMA disable_gpu_graph")
+    more = int(d.execute(sql)[0, 0])
+    d.execute("PRAGMA enable_gpu_graph")
+    assert more > expect and int(d.execute(sql)[0, 0]) == more
+    # the vertex-validated form is a different graph: pin it too, through the table function signature
+    d.execute(f"SELECT * FROM gg_graph_pin({GRAPH})")
+    got = d.execute(f"SELECT hops, rows FROM gg_khop_count({GRAPH}, 1, 2) ORDER BY hops")
+    d.execute("PRAGMA disable_gpu_graph")
+    assert got[:, 1].tolist() == [int(d.execute(R.sql_khop(h))[0, 0]) for h in (1, 2)]
+    assert int(d.execute("SELECT * FROM gg_graph_unpin()")[0, 0]) >= 1
+    assert with_pin < 1.0
