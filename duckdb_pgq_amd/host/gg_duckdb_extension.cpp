@@ -2,7 +2,7 @@
 //
 // Loaded with   LOAD '<repo>/duckdb_pgq_amd/gg_duckdb.duckdb_extension';
 // (PhysicalLoad: dlopen + <basename>_init / <basename>_version,
-//  src/execution/operator/helper/physical_load.cpp:29-70 of the reference).  It registers four table
+//  src/execution/operator/helper/physical_load.cpp:29-70 of the reference).  It registers table
 // functions that the planner wraps in an ordinary PhysicalTableScan, so no reference
 // file changes:
 //
@@ -15,6 +15,8 @@
 //   gg_same_neighbour_paths(vertices_sql, sources_sql, path_table, path_src, path_dst,
 //                           filter_table, filter_src, filter_dst, hops)
 //        -> (w BIGINT, v0 BIGINT, ..., v{hops} BIGINT)      Train Benchmark ConnectedSegments
+//   gg_graph_pin(vertex_table, vertex_key, edge_table, src_col, dst_col) / gg_graph_unpin()
+//        -> keep that graph on the device for later statements (a snapshot; see "Pinned graphs" below)
 //
 // Each function runs the operator classes of gg_operators.hpp exactly the way the reference's
 // PipelineExecutor would (pipeline_executor.cpp:47-131): source chunks -> Sink (per <=1024-row
