@@ -288,6 +288,13 @@ def main():
                             "frac": a / t_expand / HBM_PEAK,
                             "traffic": traffic_tab.get(f"{args.workload}/expand_mid2/n{world}"),
                             "note": "above 1: the product kernel reads each CSR row once and is VALU-bound (DESIGN.md §4.3)"}
+    # the whole step against the same ceiling: SURVEY.md §8d's algorithmic bytes of build + expansion over the
+    # measured step time (north_star's target is stated on this workload: >= 50 % of the HBM roofline)
+    a_step = alg_build + 8 * te_l + 16 * fr_l
+    phases["whole_step"] = {"step_ms": ms_per_step, "algorithmic_bytes": a_step,
+                            "achieved": a_step / (ms_per_step * 1e-3) / 1e9,
+                            "frac": a_step / (ms_per_step * 1e-3) / HBM_PEAK,
+                            "note": "dominated by the expansion's 8 bytes per traversed edge; see roofline_phases.expand"}
     kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
                    "us_per_step": v[1] * 1e3 / TABLE_STEPS, "timed_region": False} for k, v in prof_all.items()}
     kernels.update({k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
