@@ -797,3 +797,27 @@ def test_graph_sharded_bfs_equals_the_whole_graph_bfs(gg, orc, n_parts, V, E, se
             c.close()
     whole.close()
     gg.set_edge_rowid(True)
+
+
+def test_profile_select_times_only_the_named_kernels(gg, orc):
+    vid, src, dst = datagen.small_graph(2000, 30000, 71)
+    gg.staging_clear()
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    gg.profile_reset()
+    gg.profile_select(["densify_hist", "expand_mid2"])
+    gg.profile(True)
+    for _ in range(3):
+        c = gg.build_csr()
+        gg.expand_khop(c, 1, 2)
+        c.close()
+    gg.profile(False)
+    prof = gg.profile_get()
+    assert set(prof) == {"densify_hist", "expand_mid2"} and prof["densify_hist"][0] == 3 and prof["expand_mid2"][1] > 0
+    gg.profile_reset()
+    gg.profile_select(None)
+    gg.profile(True)
+    c = gg.build_csr()
+    c.close()
+    gg.profile(False)
+    assert {"ht_insert", "densify_hist", "radix_scatter", "scan_chained", "row_offsets"} <= set(gg.profile_get())
