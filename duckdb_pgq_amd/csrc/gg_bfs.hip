@@ -288,6 +288,21 @@ __global__ __launch_bounds__(256) void k_bfs_pairs_fill(const DistT *__restrict_
   }
 }
 
+// the same rows as ONE 8-byte word each: lane << 58 | distance << 32 | dense vertex index.  A third of the
+// bytes over PCIe; the host turns lane and dense index back into ids from two small tables it already has.
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_pairs_fill_packed(const DistT *__restrict__ dist, uint64_t V, int n_src,
+                                                               const uint32_t *__restrict__ offsets,
+                                                               int64_t *__restrict__ out) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  uint64_t pos = offsets[v];
+  for (int s = 0; s < n_src; s++) {
+    const DistT d = dist[v * 64 + s];
+    if (d != (DistT)~(DistT)0) out[pos++] = (int64_t)(((uint64_t)s << 58) | ((uint64_t)d << 32) | v);
+  }
+}
+
 }  // namespace gg
 
 // One BFS with DistT distance cells.  *overflow is set (and nothing is returned) if the frontier is
@@ -390,22 +405,29 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
       set_error("gg_bfs64_pairs: more than 2^32-2 reached pairs in one batch");
       rc = GG_ERR_TOO_LARGE;
     }
+    const bool packed = pairs->k_max == 0;  // one packed word per row (table 0) instead of three ids (table 2)
+    const int table = packed ? 0 : 2, ncols = packed ? 1 : 3;
     uint32_t *counts = nullptr;
     if (rc == GG_OK) rc = ctx->dev_alloc((void **)&counts, V * sizeof(uint32_t));
-    for (int c = 0; c < 3 && rc == GG_OK; c++) rc = ctx->dev_alloc((void **)&pairs->cols[2][c], reached * sizeof(int64_t));
+    for (int c = 0; c < ncols && rc == GG_OK; c++)
+      rc = ctx->dev_alloc((void **)&pairs->cols[table][c], reached * sizeof(int64_t));
     if (rc == GG_OK) {
       hipLaunchKernelGGL((k_bfs_pairs_count<DistT>), dim3(vgrid), dim3(256), 0, s, (const DistT *)dist8, V, n_src, counts);
       rc = scan_exclusive_u32(ctx, counts, counts, V, nullptr);
     }
     if (rc == GG_OK) {
-      hipLaunchKernelGGL((k_bfs_pairs_fill<DistT>), dim3(vgrid), dim3(256), 0, s, (const DistT *)dist8, V, n_src,
-                         (const uint32_t *)counts, (const int64_t *)ids_dev, (const int64_t *)csr->vid,
-                         pairs->cols[2][0], pairs->cols[2][1], pairs->cols[2][2]);
+      if (packed)
+        hipLaunchKernelGGL((k_bfs_pairs_fill_packed<DistT>), dim3(vgrid), dim3(256), 0, s, (const DistT *)dist8, V, n_src,
+                           (const uint32_t *)counts, pairs->cols[0][0]);
+      else
+        hipLaunchKernelGGL((k_bfs_pairs_fill<DistT>), dim3(vgrid), dim3(256), 0, s, (const DistT *)dist8, V, n_src,
+                           (const uint32_t *)counts, (const int64_t *)ids_dev, (const int64_t *)csr->vid,
+                           pairs->cols[2][0], pairs->cols[2][1], pairs->cols[2][2]);
       if (hipGetLastError() != hipSuccess) rc = GG_ERR_HIP;
     }
     if (rc == GG_OK) {
-      for (int c = 0; c < 3; c++) ctx->keep(pairs->cols[2][c]);
-      pairs->rows[2] = reached;
+      for (int c = 0; c < ncols; c++) ctx->keep(pairs->cols[table][c]);
+      pairs->rows[table] = reached;
     }
     ctx->dev_free(counts);
   }
@@ -461,14 +483,27 @@ extern "C" int gg_bfs64(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids
   return bfs_dispatch(ctx, csr_c, src_ids, n_src, max_hops, dst_ids, n_dst, out_dist, stats, nullptr);
 }
 
+static int bfs_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
+                     gg_bfs_stats *stats, gg_result **out_result, int table);
+
 extern "C" int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
                               gg_bfs_stats *stats, gg_result **out_result) {
+  return bfs_pairs(ctx, csr, src_ids, n_src, max_hops, stats, out_result, 2);
+}
+
+extern "C" int gg_bfs64_pairs_packed(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
+                                     gg_bfs_stats *stats, gg_result **out_result) {
+  return bfs_pairs(ctx, csr, src_ids, n_src, max_hops, stats, out_result, 0);
+}
+
+static int bfs_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
+                     gg_bfs_stats *stats, gg_result **out_result, int table) {
   if (!out_result) return GG_ERR_INVALID_ARG;
   *out_result = nullptr;
   if (!ctx) return GG_ERR_INVALID_ARG;
   gg_result *res = new gg_result();
   res->ctx = ctx;
-  res->k_min = res->k_max = 2;  // a 3-column table: fetch it as table 2
+  res->k_min = res->k_max = table;  // table 2: three id columns; table 0: one packed column
   int rc = bfs_dispatch(ctx, csr, src_ids, n_src, max_hops, nullptr, 0, nullptr, stats, res);
   if (rc != GG_OK) {
     gg_result_destroy(res);

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gg_debug_force_frontier",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
-    "gg_bfs64", "gg_bfs64_pairs", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
+    "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
     "gg_bfs_sharded_begin", "gg_bfs_sharded_expand", "gg_bfs_sharded_words", "gg_bfs_sharded_commit",
     "gg_bfs_sharded_pairs", "gg_bfs_sharded_end",
     "gg_profile_enable", "gg_profile_select", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
@@ -106,6 +106,7 @@ def load_library(path: str | None = None):
     lib.gg_host_free.restype = None
     lib.gg_csr_lookup.argtypes = [P, P, i64p, u64, C.POINTER(C.c_uint32)]
     lib.gg_bfs64_pairs.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
+    lib.gg_bfs64_pairs_packed.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
     lib.gg_bfs_sharded_begin.argtypes = [P, P, i64p, C.c_int, C.POINTER(P)]
     lib.gg_bfs_sharded_expand.argtypes = [P, C.POINTER(C.c_void_p), C.POINTER(u64), C.POINTER(u64)]
     lib.gg_bfs_sharded_words.argtypes = [P, C.POINTER(C.c_uint64), C.c_int]
@@ -400,6 +401,24 @@ class GG:
         p = C.c_void_p()
         self._chk(self.lib.gg_host_alloc(self.ctx, 8 * max(1, n_int64), C.byref(p)))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64)), shape=(max(1, n_int64),))[:n_int64]
+
+    def bfs64_pairs_packed(self, csr: Csr, sources, max_hops: int) -> np.ndarray:
+        """gg_bfs64_pairs_packed: one word per reached pair, lane << 58 | distance << 32 | dense vertex index."""
+        i64p = C.POINTER(C.c_int64)
+        s, ps = _i64(sources)
+        st, res = BfsStats(), C.c_void_p()
+        self._chk(self.lib.gg_bfs64_pairs_packed(self.ctx, csr.handle, ps, s.size, max_hops, C.byref(st), C.byref(res)))
+        try:
+            n = C.c_uint64()
+            self._chk(self.lib.gg_result_rows(res, 0, C.byref(n)))
+            out = np.empty(n.value, np.int64)
+            if n.value:
+                ptrs = (i64p * 1)(out.ctypes.data_as(i64p))
+                got = C.c_uint32()
+                self._chk(self.lib.gg_result_fetch(res, 0, 0, n.value, ptrs, C.byref(got)))
+        finally:
+            self.lib.gg_result_destroy(res)
+        return out.view(np.uint64)
 
     def bfs64_pairs(self, csr: Csr, sources, max_hops: int):
         """Reached (source id, vertex id, distance) rows of one <=64-source batch, compacted on the device."""

@@ -615,8 +615,9 @@ public:
 		return max_threads;
 	}
 	vector<int64_t> uniq;            // the sources, deduplicated, in 64-lane batches
+	vector<int64_t> vid;             // vertex ids by dense index (the rows come back packed, see RunBatch)
 	idx_t batch_base = 0;            // first source of the batch whose rows are in `result`
-	gg_result *result = nullptr;     // (source, vertex, distance) rows of the current batch, in HBM
+	gg_result *result = nullptr;     // packed (lane, distance, dense vertex) rows of the current batch, in HBM
 	idx_t rows = 0;                  // ... and how many
 	std::atomic<idx_t> fetching {0}; // slab fetches still reading `result`
 	//! seed rows of sources that are not vertices of the graph (lone_sources): served once, at the end
@@ -644,11 +645,13 @@ void PhysicalGGShortestPath::RunBatch(GlobalSourceState &gstate_p) const {
 		state.result = nullptr;
 	}
 	const int n = (int)MinValue<idx_t>(GG_BFS_LANES, state.uniq.size() - state.batch_base);
-	GGGraph::Check(gg_bfs64_pairs(graph->ctx, graph->csr, state.uniq.data() + state.batch_base, n, max_hops, nullptr,
-	                              &state.result),
-	               "gg_bfs64_pairs");
+	// one 8-byte word per row (lane << 58 | distance << 32 | dense vertex): a third of the bytes of three
+	// id columns over PCIe; the pipeline threads turn lane and dense index back into ids as they unpack
+	GGGraph::Check(gg_bfs64_pairs_packed(graph->ctx, graph->csr, state.uniq.data() + state.batch_base, n, max_hops,
+	                                     nullptr, &state.result),
+	               "gg_bfs64_pairs_packed");
 	uint64_t rows = 0;
-	GGGraph::Check(gg_result_rows(state.result, 2, &rows), "gg_result_rows");
+	GGGraph::Check(gg_result_rows(state.result, 0, &rows), "gg_result_rows");
 	state.rows = rows;
 	state.offset = 0;
 }
@@ -680,6 +683,10 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 		}
 	}
 	if (!state->uniq.empty()) {
+		uint64_t V = 0;
+		GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
+		state->vid.resize(V);
+		GGGraph::Check(gg_csr_export(graph->csr, nullptr, nullptr, nullptr, state->vid.data()), "gg_csr_export");
 		RunBatch(*state);
 	}
 	// the first batch's size is the only estimate there is of how much the threads will have to drain
@@ -732,10 +739,11 @@ void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk
 			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.rows - offset);
 			gstate.offset += want;
 			result = gstate.result;
+			slab.table = (int)gstate.batch_base; // lane i of these rows is source uniq[batch_base + i]
 			gstate.fetching++;
 		}
 		uint32_t got = 0;
-		const int rc = gg_result_fetch(result, 2, offset, (uint32_t)want, slab.Columns(3), &got);
+		const int rc = gg_result_fetch(result, 0, offset, (uint32_t)want, slab.Columns(1), &got);
 		gstate.fetching--;
 		GGGraph::Check(rc, "gg_result_fetch");
 		slab.rows = got;
@@ -745,11 +753,17 @@ void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk
 		}
 	}
 	const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, slab.rows - slab.pos);
-	memcpy(FlatVector::GetData<int64_t>(chunk.data[0]), slab.column[0] + slab.pos, n * sizeof(int64_t));
-	memcpy(FlatVector::GetData<int64_t>(chunk.data[1]), slab.column[1] + slab.pos, n * sizeof(int64_t));
+	auto start = FlatVector::GetData<int64_t>(chunk.data[0]);
+	auto frnd = FlatVector::GetData<int64_t>(chunk.data[1]);
 	auto hops = FlatVector::GetData<int32_t>(chunk.data[2]);
-	for (idx_t i = 0; i < n; i++) {
-		hops[i] = (int32_t)slab.column[2][slab.pos + i];
+	const int64_t *lane_source = gstate.uniq.data() + slab.table;
+	const int64_t *vertex_id = gstate.vid.data();
+	const int64_t *packed = slab.column[0] + slab.pos;
+	for (idx_t i = 0; i < n; i++) { // lane << 58 | distance << 32 | dense vertex index
+		const uint64_t w = (uint64_t)packed[i];
+		start[i] = lane_source[w >> 58];
+		frnd[i] = vertex_id[(uint32_t)w];
+		hops[i] = (int32_t)((w >> 32) & 0x3FFFFFFu);
 	}
 	slab.pos += n;
 	chunk.SetCardinality(n);

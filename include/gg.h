@@ -213,6 +213,11 @@ int gg_bfs64(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, 
  * vertices contribute no row. */
 int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
                    gg_bfs_stats *stats, gg_result **out_result);
+/* The same rows as one 8-byte word each — lane << 58 | distance << 32 | dense vertex index, lane = index
+ * into src_ids — in table 0 of *out_result (one column): a third of the bytes over PCIe for hosts that hold
+ * the source list and the vertex ids (gg_csr_export) themselves. */
+int gg_bfs64_pairs_packed(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
+                          gg_bfs_stats *stats, gg_result **out_result);
 
 /* ---- graph-sharded 64-lane BFS (one shard of the graph per GPU) ------------------------------- */
 /* The layout north_star names for graphs that do not fit one GPU: `shard` comes from

@@ -821,3 +821,18 @@ def test_profile_select_times_only_the_named_kernels(gg, orc):
     c.close()
     gg.profile(False)
     assert {"ht_insert", "densify_hist", "radix_scatter", "scan_chained", "row_offsets"} <= set(gg.profile_get())
+
+
+def test_bfs64_pairs_packed_words_decode_to_the_same_rows(gg, orc):
+    vid, src, dst = datagen.small_graph(3000, 40000, 4)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = datagen.pick_sources(vid, 64, 4)
+    rows, _ = gg.bfs64_pairs(csr, sources, -1)
+    words = gg.bfs64_pairs_packed(csr, sources, -1)
+    lane = (words >> np.uint64(58)).astype(np.int64)
+    dist = ((words >> np.uint64(32)) & np.uint64(0x3FFFFFF)).astype(np.int64)
+    dense = (words & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    decoded = np.stack([sources[lane], vid[dense], dist], axis=1)
+    assert np.array_equal(sort_rows(decoded), sort_rows(rows))
+    csr.close()
+    g.close()
