@@ -213,7 +213,14 @@ static void GGFunction(ClientContext &context, const FunctionData *bind_data_p, 
 // ---- parallel scan: the reference's pipeline tasks drain one device-resident result together, each
 // through its own pinned slab (PhysicalTableScan's parallel protocol, physical_table_scan.cpp:22-110)
 static idx_t GGMaxThreads(ClientContext &context, const FunctionData *bind_data) {
-	return ((const GGFunctionData &)*bind_data).parallel_result ? 8 : 1;
+	// the threads that drain the result also run the rest of the pipeline (filters, aggregates above the
+	// scan), so more of them than PCIe alone needs: GG_SCAN_THREADS, default 32
+	static const idx_t threads = [] {
+		auto env = std::getenv("GG_SCAN_THREADS");
+		const idx_t n = env ? (idx_t)std::strtoull(env, nullptr, 10) : 32;
+		return MaxValue<idx_t>(n, 2);
+	}();
+	return ((const GGFunctionData &)*bind_data).parallel_result ? threads : 1;
 }
 
 static unique_ptr<ParallelState> GGInitParallelState(ClientContext &context, const FunctionData *bind_data,
