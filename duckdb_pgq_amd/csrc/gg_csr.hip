@@ -24,18 +24,11 @@
 // ids — for join chains that name no vertex table.
 // All integer work, HBM-bound: algorithmic bytes 40E + 16V (with rowid).
 #include "gg_internal.h"
+#include "gg_dict.h"
 
 using namespace gg;
 
 namespace gg {
-
-struct BuildStatus {  // device-side status block, copied back once per build
-  unsigned long long dup_vertex;   // !=0: duplicate vertex id seen
-  long long min_idx;               // dense index of the vertex with id == HT_EMPTY, or -1
-  unsigned long long kept;         // edges kept in the forward CSR (both endpoints are vertices, source owned)
-  unsigned long long kept_rev;     // edges kept in the reverse CSR (shard builds; destination owned)
-  unsigned long long owned;        // vertices owned by this shard
-};
 
 __global__ __launch_bounds__(256) void k_rowid_iota(int64_t *__restrict__ out, int64_t first, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,77 +103,6 @@ constexpr int RB_ITEMS = GG_RB_ITEMS;              // elements per lane
 constexpr int RB_TILE = RB_THREADS * RB_ITEMS;     // 4096 elements per workgroup
 constexpr int RB_WTILE = RB_TILE / RB_WAVES;       // 1024 per wave
 constexpr int RB_MAX_BITS = 8;                     // <= 256 digits per pass
-
-// ---- direct-address id dictionary -------------------------------------------------------------------
-// The reference switches its join to a perfect hash table — an array indexed by key - min — when the build
-// keys are integers spanning at most 1 000 000 values (CheckForPerfectJoinOpt, src/execution/
-// physical_plan/plan_comparison_join.cpp:35-107; PerfectHashJoinExecutor::BuildPerfectHashTable,
-// src/execution/operator/join/perfect_hash_join_executor.cpp:24-65).  Same idea for the id -> dense index
-// dictionary: if the vertex ids span at most DIRECT_MAX_RANGE values the edge densification reads a
-// uint32 array indexed by id - min (<= 4 MiB: it stays in an XCD's 4 MiB L2, unlike the 16-byte-slot hash
-// table) instead of probing.  Decided on the device from the ids' min/max: no host synchronisation.
-constexpr uint64_t DIRECT_MAX_RANGE = 1u << 20;
-
-struct DirectMap {
-  long long min_id;              // INT64_MAX until k_id_minmax ran
-  long long max_id;
-  unsigned long long enabled;    // ids span <= DIRECT_MAX_RANGE values
-};
-
-__global__ __launch_bounds__(256) void k_id_minmax(const int64_t *__restrict__ vid, uint64_t V,
-                                                   DirectMap *__restrict__ dm) {
-  long long lo = INT64_MAX, hi = INT64_MIN;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (uint64_t)gridDim.x * blockDim.x) {
-    const long long x = vid[i];
-    lo = x < lo ? x : lo;
-    hi = x > hi ? x : hi;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
-    lo = l2 < lo ? l2 : lo;
-    hi = h2 > hi ? h2 : hi;
-  }
-  __shared__ long long s_lo[4], s_hi[4];
-  if ((threadIdx.x & 63) == 0) {
-    s_lo[threadIdx.x >> 6] = lo;
-    s_hi[threadIdx.x >> 6] = hi;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {  // one pair of atomics per workgroup: same-address 64-bit atomics serialise
-    for (int w = 1; w < 4; w++) {
-      lo = s_lo[w] < lo ? s_lo[w] : lo;
-      hi = s_hi[w] > hi ? s_hi[w] : hi;
-    }
-    atomicMin(&dm->min_id, lo);
-    atomicMax(&dm->max_id, hi);
-  }
-}
-
-__global__ void k_direct_decide(DirectMap *__restrict__ dm, uint64_t V) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const uint64_t span = (uint64_t)dm->max_id - (uint64_t)dm->min_id;  // exact in unsigned arithmetic
-    dm->enabled = (V > 0 && dm->max_id >= dm->min_id && span < DIRECT_MAX_RANGE) ? 1ULL : 0ULL;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_direct_init(uint32_t *__restrict__ dir, const DirectMap *__restrict__ dm) {
-  if (!dm->enabled) return;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < DIRECT_MAX_RANGE) dir[i] = INVALID_U32;
-}
-
-__global__ __launch_bounds__(256) void k_direct_fill(const int64_t *__restrict__ vid, uint64_t V,
-                                                     uint32_t *__restrict__ dir, const DirectMap *__restrict__ dm) {
-  if (!dm->enabled) return;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < V) dir[(uint64_t)vid[i] - (uint64_t)dm->min_id] = (uint32_t)i;  // duplicate ids: the hash insert reports them
-}
-
-__device__ __forceinline__ uint32_t direct_lookup(const uint32_t *__restrict__ dir, uint64_t min_id, int64_t key) {
-  const uint64_t off = (uint64_t)key - min_id;
-  return off < DIRECT_MAX_RANGE ? dir[off] : INVALID_U32;
-}
 
 // Densify + pass-0 histogram.  One lane per edge row: two id lookups (hash table is V-sized, L2 /
 // Infinity-Cache resident), dense endpoints written coalesced, digit counted in the tile's LDS histogram.
@@ -739,11 +661,10 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   GG_TRY(ctx->dev_alloc((void **)&csr->vid, (V ? V : 1) * sizeof(int64_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->off, (V + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->nbr, (E ? E : 1) * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&csr->row, (E ? E : 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->epos, (E ? E : 1) * sizeof(uint32_t)));
   BuildStatus *st = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&st, sizeof(BuildStatus)));
-  BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL};
+  BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL, 0ULL};
   memcpy(ctx->pin_scratch, &init, sizeof(init));
   GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch, sizeof(init), hipMemcpyHostToDevice, s));
   if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -752,6 +673,11 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   if (V)
     GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
               csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts);
+
+  // whole graphs of up to 2^22 vertices: forward and reverse CSR by the bucketed build (gg_csr_fast.hip)
+  int fast = 0;
+  if (!shard && !ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));
+  if (!fast) GG_TRY(ctx->dev_alloc((void **)&csr->row, (E ? E : 1) * sizeof(uint32_t)));
 
   unsigned long long *kept_dev = nullptr, *kept_rev_dev = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
@@ -764,7 +690,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
     GG_TRY(ctx->dev_alloc((void **)&csr->rnbr, (E ? E : 1) * sizeof(uint32_t)));
     GG_TRY(ctx->dev_alloc((void **)&rkey_sorted, (E ? E : 1) * sizeof(uint32_t)));
   }
-  if (E) {
+  if (E && !fast) {
     // ---- densify + fused pass-0 histogram --------------------------------------------------------
     const int key_bits = ceil_log2_u64(V < 2 ? 2 : V);
     const int passes = (key_bits + RB_MAX_BITS - 1) / RB_MAX_BITS;
@@ -806,7 +732,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
         const unsigned mm_blocks = (V + 255) / 256 < 64 ? (unsigned)((V + 255) / 256) : 64u;
         GG_LAUNCH(ctx, "id_minmax", k_id_minmax, dim3(mm_blocks), dim3(256), 0, csr->vid, V, dm);
       }
-      GG_LAUNCH(ctx, "direct_decide", k_direct_decide, dim3(1), dim3(64), 0, dm, V);
+      GG_LAUNCH(ctx, "direct_decide", k_dict_decide, dim3(1), dim3(64), 0, dm, V, 0u, 0u);
       GG_LAUNCH(ctx, "direct_init", k_direct_init, dim3((unsigned)(DIRECT_MAX_RANGE / 256)), dim3(256), 0, dir, dm);
       if (V)
         GG_LAUNCH(ctx, "direct_fill", k_direct_fill, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, dir,
@@ -832,10 +758,14 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
     GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0,
               rkey_sorted, (uint64_t)0, (const unsigned long long *)kept_rev_dev, V, csr->roff);
   }
-  GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0, csr->row,
-            (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
-  GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
-            (const uint64_t *)kept_rev_dev, st);
+  if (!fast) {
+    GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0, csr->row,
+              (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
+    GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
+              (const uint64_t *)kept_rev_dev, st);
+  } else {  // the gather of explicit rowids below reads the kept count from kept_dev
+    GG_HIP(hipMemcpyAsync(kept_dev, &st->kept, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+  }
   csr->has_rowid = !shard && ctx->keep_edge_rowid;
   if (ctx->rowid_explicit && E && csr->has_rowid) {
     // rows staged without rowids never wrote the rowid column: their rowid is their position
@@ -857,7 +787,11 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   ctx->dev_free(st);
   ctx->dev_free(kept_dev);
   ctx->dev_free(kept_rev_dev);
-  csr->rrow = rkey_sorted;  // null unless this is a shard build (ensure_reverse fills it lazily otherwise)
+  if (!fast) csr->rrow = rkey_sorted;  // null unless this is a shard build (ensure_reverse fills it lazily otherwise)
+  if (hs.scan_error) {
+    set_error("CSR build: a chained scan gave up waiting for a predecessor tile");
+    return GG_ERR_HIP;
+  }
   if (hs.dup_vertex) {
     set_error("vertex key column is not unique (duplicate vertex id)");
     return GG_ERR_DUPLICATE_VERTEX;

@@ -1,0 +1,927 @@
+// gg_csr_fast.hip — bucketed two-level CSR build: forward and reverse CSR in four kernels.
+//
+// Replaces the same reference work as gg_csr.hip (the hash-join build side, JoinHashTable::Build/Finalize/
+// InsertHashes, src/execution/join_hashtable.cpp:150-302) for graphs of up to 2^22 vertices.  The legacy
+// LSD build sorts (u, v) three times by 7-bit digits per direction (six scatter passes, five histogram
+// passes, six scans, two row-offset passes at SF100).  Here the dense source index u is split into a HIGH
+// part (<= 10 bits: the bucket) and a LOW part (<= 12 bits: the vertex inside the bucket):
+//
+//   D  k_densify_pairs    one read of the (src, dst) id columns; two dictionary probes per edge row
+//                         (gg_dict.h: direct array / packed 8-byte slots / 16-byte slots); writes the dense
+//                         pair (u, v) in rowid order; counts, per tile, the bucket of u (forward) and the
+//                         bucket of v (reverse) in LDS
+//      scan               one chained scan over both directions' (bucket x tile) counters
+//   A  k_partition_dual   one read of the pairs, TWO stable bucket partitions written from one LDS staging
+//                         area: forward (low(u), v[, edge position]) by bucket(u), reverse (low(v), u) by
+//                         bucket(v).  In-tile ranks come from __ballot match masks in element order, runs of
+//                         one bucket go out as contiguous stores (same scheme as k_radix_scatter)
+//   B  k_bucket_rows      one workgroup per (direction, bucket): a wave owns a contiguous eighth of the
+//                         bucket, counts its vertices' entries in a private LDS histogram, the workgroup turns
+//                         the histograms into row offsets (written to off[] / roff[]: no separate row-offset
+//                         pass) and per-wave cursors, then every wave places its entries in order.
+//
+// Stable everywhere: inside a forward row neighbours keep ascending edge-rowid order (bit-identical to the
+// legacy build and to the oracle's counting sort); inside a reverse row in-neighbours are in rowid order too
+// (the order shard builds already produce).  No atomic decides a position.
+// Algorithmic bytes: SURVEY.md §8d, 32E + 8V (densification) + 32E + 16V (CSR without rowid).
+#include "gg_dict.h"
+#include "gg_internal.h"
+
+using namespace gg;
+
+namespace gg {
+
+constexpr int FB_THREADS = 512;
+constexpr int FB_WAVES = FB_THREADS / 64;
+#ifndef GG_FB_ITEMS
+#define GG_FB_ITEMS 16
+#endif
+constexpr int FB_ITEMS = GG_FB_ITEMS;            // edge rows per lane and tile
+constexpr int FB_TILE = FB_THREADS * FB_ITEMS;   // 8192 rows per workgroup (D and A share the tiling)
+constexpr int FB_WTILE = FB_TILE / FB_WAVES;     // contiguous rows per wave in A
+constexpr int FB_MAX_HB = 10;                    // bucket bits
+constexpr int FB_MAX_LOW = 12;                   // vertex-in-bucket bits (8 x 4096 x 4 B of LDS histograms in B)
+#ifndef GG_FB_LOAD_PCT
+#define GG_FB_LOAD_PCT 88                        // load factor of the packed dictionary, percent
+#endif
+#ifndef GG_FB_NT
+#define GG_FB_NT 1                               // streamed columns bypass the caches' retention (nt loads/stores)
+#endif
+#ifndef GG_FB_XCD
+#define GG_FB_XCD 1                              // A: consecutive tiles on one XCD (short runs merge in its L2)
+#endif
+
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+#if GG_FB_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void st_stream(T *p, T v) {
+#if GG_FB_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
+#ifndef GG_FB_MATCH_OR
+#define GG_FB_MATCH_OR 0
+#endif
+// Match mask: which lanes of the wave hold the same small value d as this lane.  Every lane ORs its bit
+// into the wave's private 64-bit LDS word of d and reads the word back (LDS executes a wave's instructions in
+// order, and OR commutes, so the mask is exact whatever order the lanes of one instruction are served in);
+// the lowest lane of each group clears the word again.  ~10 instructions instead of ~7 per key bit with
+// __ballot masks.
+__device__ __forceinline__ uint64_t match_or(unsigned long long *mm, uint32_t d, bool valid, int lane) {
+  if (valid) atomicOr(&mm[d], 1ULL << lane);
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t m = valid ? *reinterpret_cast<volatile unsigned long long *>(&mm[d]) : 0ULL;
+  __builtin_amdgcn_wave_barrier();
+  if (valid && (m & ((1ULL << lane) - 1ULL)) == 0) *reinterpret_cast<volatile unsigned long long *>(&mm[d]) = 0ULL;
+  __builtin_amdgcn_wave_barrier();
+  return m;
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));  // a dense (u, v) pair: one 8-byte access
+
+struct FastGeom {
+  uint32_t key_bits;  // bits of V - 1 (>= 1)
+  uint32_t low;       // vertex-in-bucket bits
+  uint32_t hb;        // bucket bits (key_bits - low)
+  uint32_t pack;      // 1: B's input is one u32 word low(key) << key_bits | payload
+  uint32_t sub;       // low = (sub, leaf): sub-bucket bits (<= 6) ...
+  uint32_t leaf;      // ... and vertex-in-leaf bits (<= 6)
+};
+
+// ---- D: densify + per-tile bucket histograms of both directions ---------------------------------------------
+// counts[(dir * nbuckets + bucket) * nblocks + tile]
+template <int MODE>
+__device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                             uint64_t E, uint64_t base, const HtSlot *__restrict__ ht, uint64_t cap,
+                                             int64_t min_idx, const uint32_t *__restrict__ dir,
+                                             const unsigned long long *__restrict__ tab,
+                                             const DirectMap *__restrict__ dm, u32x2 *__restrict__ pairs,
+                                             uint32_t low, uint32_t *hist_f, uint32_t *hist_r) {
+  constexpr int B = 4;  // edge rows per batch: 2*B independent first probes in flight per lane
+  const int64_t min_id = dm->min_id, max_id = dm->max_id;
+  PkGeom pk;
+  pk.load(dm);
+#pragma unroll 1
+  for (int it0 = 0; it0 < FB_ITEMS; it0 += B) {
+    int64_t ks[B], kd[B];
+    uint32_t us[B], vs[B];
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      const uint64_t e = base + (uint64_t)(it0 + j) * FB_THREADS + threadIdx.x;
+      ks[j] = e < E ? ld_stream(src + e) : HT_EMPTY;
+      kd[j] = e < E ? ld_stream(dst + e) : HT_EMPTY;
+    }
+    if (MODE == 99) {  // timing probe: the streams without the dictionary probes
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        us[j] = (uint32_t)((uint64_t)ks[j] * DIG_GOLD >> 45);
+        vs[j] = (uint32_t)((uint64_t)kd[j] * DIG_GOLD >> 45);
+      }
+    } else if (MODE == DICT_DIRECT) {
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        us[j] = direct_lookup(dir, (uint64_t)min_id, ks[j]);
+        vs[j] = direct_lookup(dir, (uint64_t)min_id, kd[j]);
+      }
+    } else if (MODE == DICT_PACKED8) {
+      uint64_t hs[B], hd[B], ts[B], td[B];
+      uint4 rs[B], rd[B];
+#pragma unroll
+      for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
+        pk.locate(ks[j], &hs[j], &ts[j]);
+        pk.locate(kd[j], &hd[j], &td[j]);
+        rs[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hs[j]]);
+        rd[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hd[j]]);
+      }
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        us[j] = packed_resolve(tab, pk, ks[j] >= min_id && ks[j] <= max_id, hs[j], ts[j], rs[j]);
+        vs[j] = packed_resolve(tab, pk, kd[j] >= min_id && kd[j] <= max_id, hd[j], td[j], rd[j]);
+      }
+    } else {
+      uint64_t ss[B], sd[B];
+      uint4 rs[B], rd[B];
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        ss[j] = ht_slot(ks[j], cap);
+        sd[j] = ht_slot(kd[j], cap);
+        rs[j] = *reinterpret_cast<const uint4 *>(&ht[ss[j]]);
+        rd[j] = *reinterpret_cast<const uint4 *>(&ht[sd[j]]);
+      }
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        us[j] = ht_resolve(ht, cap, min_idx, ks[j], ss[j], rs[j]);
+        vs[j] = ht_resolve(ht, cap, min_idx, kd[j], sd[j], rd[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+      const uint64_t e = base + (uint64_t)(it0 + j) * FB_THREADS + threadIdx.x;
+      if (e >= E) continue;
+      uint32_t u = us[j], v = vs[j];
+      if (u == INVALID_U32 || v == INVALID_U32) {
+        u = INVALID_U32;  // dropped: an endpoint is not a vertex (inner-join semantics)
+        v = INVALID_U32;
+      } else {
+        atomicAdd(&hist_f[u >> low], 1u);
+        atomicAdd(&hist_r[v >> low], 1u);
+      }
+      u32x2 pr;
+      pr.x = u;
+      pr.y = v;
+      st_stream(pairs + e, pr);
+    }
+  }
+}
+
+template <bool PROBE = false>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
+__global__ __launch_bounds__(FB_THREADS) void k_densify_pairs(
+    const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
+    uint64_t cap, const BuildStatus *__restrict__ st, const uint32_t *__restrict__ dir,
+    const unsigned long long *__restrict__ tab, const DirectMap *__restrict__ dm, u32x2 *__restrict__ pairs,
+    FastGeom g, uint64_t nblocks, uint32_t *__restrict__ counts) {
+  __shared__ uint32_t hist[2 << FB_MAX_HB];
+  const uint32_t nb = 1u << g.hb;
+  for (uint32_t i = threadIdx.x; i < 2 * nb; i += FB_THREADS) hist[i] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * FB_TILE;
+  const unsigned long long mode = PROBE ? 99ULL : dm->mode;  // uniform over the grid
+  if (PROBE)
+    densify_tile<99>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+  else if (mode == DICT_DIRECT)
+    densify_tile<DICT_DIRECT>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+  else if (mode == DICT_PACKED8)
+    densify_tile<DICT_PACKED8>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+  else
+    densify_tile<DICT_WIDE16>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 2 * nb; i += FB_THREADS)
+    counts[(uint64_t)i * nblocks + blockIdx.x] = hist[i];  // i = dir * nb + bucket
+}
+
+// ---- A: two stable bucket partitions from one read of the pairs ---------------------------------------------
+// Element order inside a tile: wave w owns rows [w * FB_WTILE, (w + 1) * FB_WTILE), 64 consecutive rows per
+// step.  PACK: output word = low(key) << key_bits | payload; otherwise the pair (low(key), payload).
+template <bool PACK, bool ROWID, int STOP = 0>  // STOP > 0: timing probes that write nothing (GG_FB_A_PROBE builds)
+__global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
+    const u32x2 *__restrict__ pairs, uint64_t E, FastGeom g, uint64_t nblocks, const uint32_t *__restrict__ bases,
+    const BuildStatus *__restrict__ st, uint32_t *__restrict__ out_f, uint32_t *__restrict__ out_r,
+    uint32_t *__restrict__ epos_f) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t nb = 1u << g.hb;
+  uint32_t *xw = lds;                                   // staged words (PACK) or low keys
+  uint32_t *xp = xw + FB_TILE;                          // staged payloads (!PACK)
+  uint32_t *xe = PACK ? xp : xp + FB_TILE;              // staged edge positions (ROWID, forward only)
+  uint32_t *hw = ROWID ? xe + FB_TILE : xe;             // [FB_WAVES][nb] per-wave counts -> running cursors
+  uint32_t *dbase = hw + FB_WAVES * nb;                 // [nb] first staged slot of each bucket
+  uint32_t *gb = dbase + nb;                            // [nb] global position of the bucket's staged slot 0, minus dbase
+  uint32_t *misc = gb + nb;                             // [FB_WAVES + 2]
+  uint16_t *xd = reinterpret_cast<uint16_t *>(misc + FB_WAVES + 2);  // staged bucket numbers
+#if GG_FB_MATCH_OR
+  unsigned long long *mm_all = reinterpret_cast<unsigned long long *>(
+      lds + (((size_t)(misc + FB_WAVES + 2 - lds) + FB_TILE / 2 + 1) & ~(size_t)1));  // [FB_WAVES][nb], 8-byte aligned
+  unsigned long long *mm = mm_all + (size_t)(threadIdx.x >> 6) * nb;
+  for (uint32_t i = threadIdx.x; i < FB_WAVES * nb; i += FB_THREADS) mm_all[i] = 0ULL;
+#endif
+
+#if GG_FB_XCD
+  // blocks b and b + 8 share an XCD (speed only): give each XCD a contiguous range of tiles, so the short
+  // runs that neighbouring tiles append to one bucket meet in one L2 before they are written back
+  const uint64_t chunk = (nblocks + 7) / 8;
+  const uint64_t tile = (uint64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tile >= nblocks) return;
+#else
+  const uint64_t tile = blockIdx.x;
+#endif
+  const uint64_t tile_base = tile * FB_TILE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t kept = (uint32_t)st->kept;
+  const uint32_t low_mask = (1u << g.low) - 1u;
+
+  uint32_t u[FB_ITEMS], v[FB_ITEMS];
+  const uint64_t wbase = tile_base + (uint64_t)wave * FB_WTILE;
+#pragma unroll
+  for (int it = 0; it < FB_ITEMS; it++) {
+    const uint64_t idx = wbase + (uint64_t)it * 64 + lane;
+    u32x2 p;
+    p.x = INVALID_U32;
+    p.y = INVALID_U32;
+    if (idx < E) p = ld_stream(pairs + idx);
+    u[it] = p.x;
+    v[it] = p.y;
+  }
+  const uint64_t lane_lt = (1ULL << lane) - 1ULL;
+  uint32_t *myh = hw + wave * nb;
+  if (STOP == 1) {  // timing probe: loads only
+    uint32_t acc = 0;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) acc += u[it] ^ v[it];
+    if (acc == 0x12345678u && E == 1) out_f[0] = acc;
+    return;
+  }
+
+#pragma unroll 1
+  for (int dir = 0; dir < 2; dir++) {
+    for (uint32_t i = threadIdx.x; i < FB_WAVES * nb; i += FB_THREADS) hw[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) {
+      const uint32_t key = dir ? v[it] : u[it];
+      if (u[it] != INVALID_U32) atomicAdd(&myh[key >> g.low], 1u);
+    }
+    __syncthreads();
+    // per bucket: wave counts -> exclusive offsets across waves; bucket totals -> exclusive scan = dbase
+    {
+      const uint32_t dpt = (nb + FB_THREADS - 1) / FB_THREADS;  // buckets per thread (1 or 2)
+      uint32_t tot[2] = {0, 0};
+      for (uint32_t q = 0; q < dpt; q++) {
+        const uint32_t d = threadIdx.x * dpt + q;
+        if (d < nb) {
+          uint32_t t = 0;
+#pragma unroll
+          for (int w = 0; w < FB_WAVES; w++) {
+            const uint32_t c = hw[w * nb + d];
+            hw[w * nb + d] = t;
+            t += c;
+          }
+          tot[q] = t;
+        }
+      }
+      const uint32_t mine = tot[0] + tot[1];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) misc[wave] = incl;
+      __syncthreads();
+      uint32_t wb = 0, all = 0;
+#pragma unroll
+      for (int w = 0; w < FB_WAVES; w++) {
+        const uint32_t sv = misc[w];
+        if (w < wave) wb += sv;
+        all += sv;
+      }
+      uint32_t ex = wb + incl - mine;
+      for (uint32_t q = 0; q < dpt; q++) {
+        const uint32_t d = threadIdx.x * dpt + q;
+        if (d < nb) {
+          dbase[d] = ex;
+          gb[d] = bases[(uint64_t)(dir * nb + d) * nblocks + tile] - (dir ? kept : 0u) - ex;
+          ex += tot[q];
+        }
+      }
+      if (threadIdx.x == 0) misc[FB_WAVES] = all;  // valid rows in this tile
+    }
+    __syncthreads();
+
+    if (STOP == 2) continue;  // timing probe: counts and scans only
+    // rank inside the tile (stable) and stage in LDS in bucket order
+    volatile uint32_t *cur = myh;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) {
+      const bool valid = u[it] != INVALID_U32;
+      const uint32_t key = dir ? v[it] : u[it], pay = dir ? u[it] : v[it];
+      const uint32_t d = valid ? key >> g.low : 0u;
+#if GG_FB_MATCH_OR
+      const uint64_t m = match_or(mm, d, valid, lane);
+#else
+      uint64_t m = __ballot(valid);
+      for (uint32_t bit = 0; bit < g.hb; bit++) {  // match mask: same bucket within the wave
+        const uint64_t bb = __ballot((d >> bit) & 1u);
+        m &= ((d >> bit) & 1u) ? bb : ~bb;
+      }
+#endif
+      if (valid) {
+        const uint32_t pos = dbase[d] + cur[d] + __popcll(m & lane_lt);
+        if (PACK) {
+          xw[pos] = ((key & low_mask) << g.key_bits) | pay;
+        } else {
+          xw[pos] = key & low_mask;
+          xp[pos] = pay;
+        }
+        if (ROWID && dir == 0) xe[pos] = (uint32_t)(wbase + (uint64_t)it * 64 + lane);
+        xd[pos] = (uint16_t)d;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (m & lane_lt) == 0) cur[d] += __popcll(m);  // lowest lane of each bucket group
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    if (STOP == 3) continue;  // timing probe: no write-out
+    // write out: consecutive staged slots of one bucket -> consecutive global positions
+    const uint32_t nvalid = misc[FB_WAVES];
+    uint32_t *out = dir ? out_r : out_f;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) {
+      const uint32_t i = (uint32_t)it * FB_THREADS + threadIdx.x;
+      if (i < nvalid) {
+        const uint32_t pos = gb[xd[i]] + i;
+        if (PACK) {
+          out[pos] = xw[i];
+        } else {
+          reinterpret_cast<uint2 *>(out)[pos] = make_uint2(xw[i], xp[i]);
+        }
+        if (ROWID && dir == 0) epos_f[pos] = xe[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- B: rows of one bucket, in three kernels ---------------------------------------------------------------------
+// A bucket's entries carry low(key) = (sub, leaf).
+//   k_sub_sort    one workgroup per CHUNK (FB_TILE consecutive entries of one bucket): sorts the chunk, stably,
+//                 by sub-bucket (<= 64) in LDS and writes it back IN PLACE, plus the chunk's 65 sub-bucket offsets
+//   k_sub_totals  per bucket: where each (bucket, sub) leaf starts in the final arrays (sum over the chunks)
+//   k_leaf_rows   one WAVE per leaf (<= 64 vertices, ~1 k entries at SF100): gathers the leaf's run out of every
+//                 chunk of its bucket (chunk order = rowid order), counts per vertex, writes the row offsets, ranks
+//                 the entries stably into a wave-private LDS stage and writes the rows out contiguously
+// Earlier forms of this step, one workgroup per bucket streaming it several times, ran at 1.4-2.0 ms at SF100:
+// scattering single words to their rows kept tens of MB of half-written lines alive per XCD (2.3x the bytes
+// written), and eight waves walking 78 k entries one 2 KB batch at a time were bound by memory latency.
+#ifndef GG_FB_CAPW
+#define GG_FB_CAPW 1536  // entries of a wave's LDS stage in k_leaf_rows (halved when edge positions ride along)
+#endif
+constexpr int LEAF_WAVES = 4;    // waves (= leaves) per workgroup of k_leaf_rows
+constexpr int LEAF_MAXS = 24;    // 64-entry steps a wave keeps in registers
+
+// bucket boundaries of both directions from the scanned counters, the chunk table, kept-edge count.
+//   bstart[dir * (nb + 1) + j]   first position of bucket j in that direction's partitioned array
+//   cstart[i], i = dir * nb + j  first chunk of bucket i (cstart[2 nb] = number of chunks)
+//   part_of[p]                   bucket i of chunk p
+__global__ __launch_bounds__(256) void k_bucket_starts(const uint32_t *__restrict__ bases, uint64_t nblocks,
+                                                       uint32_t nb, const uint64_t *__restrict__ total,
+                                                       uint32_t *__restrict__ bstart, uint32_t *__restrict__ cstart,
+                                                       uint32_t *__restrict__ part_of, BuildStatus *__restrict__ st) {
+  __shared__ uint32_t s_b[2 * ((1 << FB_MAX_HB) + 1)];
+  __shared__ uint32_t s_w[4];
+  const uint32_t kept = (uint32_t)(*total / 2);  // both directions count the same rows
+  for (uint32_t i = threadIdx.x; i < 2 * (nb + 1); i += 256) {
+    const uint32_t dir = i / (nb + 1), j = i % (nb + 1);
+    const uint32_t pos = j < nb ? bases[(uint64_t)(dir * nb + j) * nblocks] : (dir ? 2 * kept : kept);
+    s_b[i] = pos - (dir ? kept : 0u);
+    bstart[i] = s_b[i];
+  }
+  __syncthreads();
+  // chunks per bucket, exclusive scan over the 2 nb buckets (8 consecutive buckets per thread)
+  const uint32_t per = (2 * nb + 255) / 256;
+  uint32_t mine = 0;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t i = threadIdx.x * per + q;
+    if (i < 2 * nb) {
+      const uint32_t dir = i / nb, j = i % nb;
+      const uint32_t len = s_b[dir * (nb + 1) + j + 1] - s_b[dir * (nb + 1) + j];
+      mine += (len + FB_TILE - 1) / FB_TILE;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t ex = incl - mine;
+  for (int w = 0; w < wave; w++) ex += s_w[w];
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t i = threadIdx.x * per + q;
+    if (i < 2 * nb) {
+      const uint32_t dir = i / nb, j = i % nb;
+      const uint32_t len = s_b[dir * (nb + 1) + j + 1] - s_b[dir * (nb + 1) + j];
+      const uint32_t n = (len + FB_TILE - 1) / FB_TILE;
+      cstart[i] = ex;
+      for (uint32_t c = 0; c < n; c++) part_of[ex + c] = i;  // stores are not waited for: cheap even for one huge bucket
+      ex += n;
+    }
+  }
+  if (threadIdx.x == 255) cstart[2 * nb] = ex;
+  if (threadIdx.x == 0) {
+    st->kept = kept;
+    st->kept_rev = kept;
+  }
+}
+
+// Chunk-local stable sort by sub-bucket, in place.  Element order in a chunk: wave w owns entries
+// [w * FB_WTILE, (w + 1) * FB_WTILE), 64 consecutive entries per step.
+template <bool PACK, bool ROWID>
+__global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
+                                                         uint32_t *__restrict__ epos_f,
+                                                         const uint32_t *__restrict__ bstart,
+                                                         const uint32_t *__restrict__ cstart,
+                                                         const uint32_t *__restrict__ part_of, FastGeom g,
+                                                         uint32_t *__restrict__ offs /* [chunk][65] */) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_n;
+  const uint32_t nb = 1u << g.hb;
+  const uint32_t p = blockIdx.x;
+  if (p >= cstart[2 * nb]) return;
+  const uint32_t i = part_of[p], dir = i / nb, j = i % nb;
+  const uint32_t b0 = bstart[dir * (nb + 1) + j], b1 = bstart[dir * (nb + 1) + j + 1];
+  const uint32_t c0 = b0 + (p - cstart[i]) * FB_TILE;
+  const uint32_t c1 = c0 + FB_TILE < b1 ? c0 + FB_TILE : b1;
+  uint32_t *__restrict__ buf = dir ? buf_r : buf_f;
+  const bool with_pos = ROWID && dir == 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ULL << lane) - 1ULL;
+  uint32_t *hw = lds;                         // [FB_WAVES][64] per-wave counts -> cursors (staged slot)
+  uint32_t *dbase = hw + FB_WAVES * 64;       // [65] first staged slot of each sub-bucket
+  uint32_t *xw = dbase + 65;                  // staged words (PACK) or low keys
+  uint32_t *xp = xw + FB_TILE;                // staged payloads (!PACK)
+  uint32_t *xe = PACK ? xp : xp + FB_TILE;    // staged edge positions (ROWID)
+  uint32_t *myh = hw + wave * 64;
+  myh[lane] = 0;
+
+  uint32_t k[FB_ITEMS], w[FB_ITEMS], ep[FB_ITEMS];
+  const uint32_t wbase = c0 + (uint32_t)wave * FB_WTILE;
+#pragma unroll
+  for (int it = 0; it < FB_ITEMS; it++) {
+    const uint32_t e = wbase + it * 64 + lane;
+    k[it] = INVALID_U32;
+    w[it] = 0;
+    ep[it] = 0;
+    if (e < c1) {
+      if (PACK) {
+        w[it] = buf[e];
+        k[it] = w[it] >> g.key_bits;
+      } else {
+        const uint2 x = reinterpret_cast<const uint2 *>(buf)[e];
+        k[it] = x.x;
+        w[it] = x.y;
+      }
+      if (with_pos) ep[it] = epos_f[e];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < FB_ITEMS; it++)
+    if (k[it] != INVALID_U32) atomicAdd(&myh[k[it] >> g.leaf], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {  // <= 64 sub-buckets: wave 0 turns the counts into staged-slot cursors
+    uint32_t tot = 0, cw[FB_WAVES];
+#pragma unroll
+    for (int q = 0; q < FB_WAVES; q++) {
+      cw[q] = hw[q * 64 + lane];
+      tot += cw[q];
+    }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    uint32_t run = incl - tot;
+    dbase[lane] = run;
+    offs[(uint64_t)p * 65 + lane] = run;
+#pragma unroll
+    for (int q = 0; q < FB_WAVES; q++) {
+      hw[q * 64 + lane] = run;
+      run += cw[q];
+    }
+    if (lane == 63) {
+      dbase[64] = incl;
+      offs[(uint64_t)p * 65 + 64] = incl;
+      s_n = incl;
+    }
+  }
+  __syncthreads();
+  volatile uint32_t *cur = myh;
+#pragma unroll
+  for (int it = 0; it < FB_ITEMS; it++) {
+    const bool valid = k[it] != INVALID_U32;
+    const uint32_t sb = valid ? k[it] >> g.leaf : 0u;
+    uint64_t m = __ballot(valid);
+    for (uint32_t bit = 0; bit < g.sub; bit++) {  // match mask: same sub-bucket within the wave
+      const uint64_t bb = __ballot((sb >> bit) & 1u);
+      m &= ((sb >> bit) & 1u) ? bb : ~bb;
+    }
+    if (valid) {
+      const uint32_t pos = cur[sb] + __popcll(m & lane_lt);
+      if (PACK) {
+        xw[pos] = w[it];
+      } else {
+        xw[pos] = k[it];
+        xp[pos] = w[it];
+      }
+      if (with_pos) xe[pos] = ep[it];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[sb], (uint32_t)__popcll(m));
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+#pragma unroll
+  for (int it = 0; it < FB_ITEMS; it++) {
+    const uint32_t s = (uint32_t)it * FB_THREADS + threadIdx.x;
+    if (s < n) {
+      if (PACK) {
+        buf[c0 + s] = xw[s];
+      } else {
+        reinterpret_cast<uint2 *>(buf)[c0 + s] = make_uint2(xw[s], xp[s]);
+      }
+      if (with_pos) epos_f[c0 + s] = xe[s];
+    }
+  }
+}
+
+// substart[i * 65 + s] = first final position of leaf (bucket i, sub s); [i * 65 + 64] = end of the bucket
+__global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ offs,
+                                                   const uint32_t *__restrict__ bstart,
+                                                   const uint32_t *__restrict__ cstart, FastGeom g, uint64_t V,
+                                                   uint32_t *__restrict__ substart, uint32_t *__restrict__ off,
+                                                   uint32_t *__restrict__ roff) {
+  const uint32_t nb = 1u << g.hb, i = blockIdx.x, dir = i / nb, j = i % nb;
+  const int lane = threadIdx.x;
+  const uint32_t p0 = cstart[i], p1 = cstart[i + 1];
+  uint32_t tot = 0;
+  for (uint32_t p = p0; p < p1; p++) tot += offs[(uint64_t)p * 65 + lane + 1] - offs[(uint64_t)p * 65 + lane];
+  uint32_t incl = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const uint32_t b0 = bstart[dir * (nb + 1) + j];
+  substart[(uint64_t)i * 65 + lane] = b0 + incl - tot;
+  if (lane == 63) substart[(uint64_t)i * 65 + 64] = b0 + incl;
+  // no leaf holds vertex V when V is a multiple of the bucket width: the last bucket closes the offsets
+  if (lane == 0 && j == nb - 1 && ((uint64_t)nb << g.low) == V) (dir ? roff : off)[V] = bstart[dir * (nb + 1) + nb];
+}
+
+template <bool PACK, bool ROWID>
+__global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
+    const uint32_t *__restrict__ buf_f, const uint32_t *__restrict__ buf_r, const uint32_t *__restrict__ epos_f,
+    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ offs,
+    const uint32_t *__restrict__ substart, FastGeom g, uint64_t V, uint32_t *__restrict__ off,
+    uint32_t *__restrict__ nbr, uint32_t *__restrict__ epos, uint32_t *__restrict__ roff,
+    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t nb = 1u << g.hb, nsub = 1u << g.sub, leafW = 1u << g.leaf;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t unit = blockIdx.x * LEAF_WAVES + wave;  // (bucket i, sub s): waves are independent from here on
+  if (unit >= 2 * nb * nsub) return;
+  const uint32_t i = unit / nsub, s = unit % nsub, dir = i / nb, j = i % nb;
+  const uint32_t *__restrict__ buf = dir ? buf_r : buf_f;
+  uint32_t *__restrict__ o_off = dir ? roff : off;
+  uint32_t *__restrict__ o_nbr = dir ? rnbr : nbr;
+  const bool with_pos = ROWID && dir == 0;
+  constexpr uint32_t CAPW = ROWID ? GG_FB_CAPW / 2 : GG_FB_CAPW;
+  uint32_t *lc = lds + (size_t)wave * (64 + GG_FB_CAPW);  // [64] vertex counters -> cursors
+  uint32_t *stage = lc + 64;
+  uint32_t *stage_e = stage + CAPW;
+  const uint64_t lane_lt = (1ULL << lane) - 1ULL;
+  const uint32_t leaf_mask = leafW - 1u;
+  const uint32_t pay_mask = g.key_bits >= 32 ? 0xFFFFFFFFu : (1u << g.key_bits) - 1u;
+  const uint32_t t0 = substart[(uint64_t)i * 65 + s], t1 = substart[(uint64_t)i * 65 + s + 1], n = t1 - t0;
+  const uint32_t b0 = bstart[dir * (nb + 1) + j];
+  const uint32_t p0 = cstart[i], nch = cstart[i + 1] - p0;
+  const uint64_t vfirst = ((uint64_t)j << g.low) + ((uint64_t)s << g.leaf);  // first vertex of the leaf
+  lc[lane] = 0;
+  const bool staged = n <= CAPW;  // wave-uniform
+
+  // The leaf's entries: run `s` of every chunk of the bucket, chunk after chunk.  Chunks are taken 64 at a time
+  // (lane c holds chunk c's run); a run is walked in 64-entry steps.  pass 0 counts, pass 1 places; when the
+  // whole leaf fits LEAF_MAXS steps the entries stay in registers between the two.
+  uint32_t incl_keep = 0;  // lane d: end of vertex d's run (relative), set after pass 0
+  uint32_t kw[LEAF_MAXS], pw[PACK ? 1 : LEAF_MAXS], ew[ROWID ? LEAF_MAXS : 1];
+  bool single = false;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t cg = 0; cg < nch || cg == 0; cg += 64) {
+      const uint32_t c = cg + lane;
+      uint32_t so = 0, len = 0;
+      if (c < nch) {
+        so = offs[(uint64_t)(p0 + c) * 65 + s];
+        len = offs[(uint64_t)(p0 + c) * 65 + s + 1] - so;
+      }
+      const uint32_t src = b0 + c * FB_TILE + so;  // position of the run's first entry
+      const uint32_t st_c = (len + 63) / 64;       // steps of this run
+      uint32_t sincl = st_c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(sincl, o, 64);
+        if (lane >= o) sincl += t;
+      }
+      const uint32_t sexcl = sincl - st_c;
+      const uint32_t T = __shfl(sincl, 63, 64);  // steps in this group of chunks
+      if (pass == 0) single = nch <= 64 && T <= LEAF_MAXS;
+      for (uint32_t r = 0; r < T; r += LEAF_MAXS) {
+        if (pass == 0 || !single) {
+#pragma unroll
+          for (int q = 0; q < LEAF_MAXS; q++) {  // all loads of the round issue back to back
+            const uint32_t t = r + q;
+            kw[q] = INVALID_U32;
+            if (!PACK) pw[PACK ? 0 : q] = 0;
+            if (ROWID) ew[ROWID ? q : 0] = 0;
+            if (t < T) {  // uniform
+              const int cc = __popcll(__ballot(sincl <= t));  // the run this step belongs to
+              const uint32_t kidx = (t - (uint32_t)__shfl(sexcl, cc, 64)) * 64 + lane;
+              const uint32_t e = (uint32_t)__shfl(src, cc, 64) + kidx;
+              if (kidx < (uint32_t)__shfl(len, cc, 64)) {
+                if (PACK) {
+                  kw[q] = buf[e];
+                } else {
+                  const uint2 x = reinterpret_cast<const uint2 *>(buf)[e];
+                  kw[q] = x.x;
+                  pw[PACK ? 0 : q] = x.y;
+                }
+                if (with_pos) ew[ROWID ? q : 0] = epos_f[e];
+              }
+            }
+          }
+        }
+        if (pass == 0) {
+#pragma unroll
+          for (int q = 0; q < LEAF_MAXS; q++)
+            if (kw[q] != INVALID_U32) atomicAdd(&lc[(PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask], 1u);
+        } else {
+          volatile uint32_t *cur = lc;
+#pragma unroll
+          for (int q = 0; q < LEAF_MAXS; q++) {
+            if (r + q >= T) continue;  // uniform
+            const bool valid = kw[q] != INVALID_U32;
+            const uint32_t d = valid ? (PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask : 0u;
+            const uint32_t pay = PACK ? kw[q] & pay_mask : pw[PACK ? 0 : q];
+            uint64_t m = __ballot(valid);
+            for (uint32_t bit = 0; bit < g.leaf; bit++) {  // match mask: same vertex within the wave
+              const uint64_t bb = __ballot((d >> bit) & 1u);
+              m &= ((d >> bit) & 1u) ? bb : ~bb;
+            }
+            if (valid) {
+              const uint32_t rel = cur[d] + __popcll(m & lane_lt);
+              if (staged) {
+                stage[rel] = pay;
+                if (with_pos) stage_e[rel] = ew[ROWID ? q : 0];
+              } else {
+                o_nbr[t0 + rel] = pay;
+                if (dir) rrow[t0 + rel] = (uint32_t)vfirst + d;
+                if (with_pos) epos[t0 + rel] = ew[ROWID ? q : 0];
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+      // row offsets of the leaf's vertices (lane d = vertex d); lc becomes the relative cursor
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t cnt = (uint32_t)lane < leafW ? lc[lane] : 0u;
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if ((uint32_t)lane < leafW) {
+        const uint64_t vtx = vfirst + (uint32_t)lane;
+        if (vtx <= V) o_off[vtx] = t0 + incl - cnt;  // vtx == V: the closing offset
+      }
+      __builtin_amdgcn_wave_barrier();
+      lc[lane] = incl - cnt;
+      __builtin_amdgcn_wave_barrier();
+      incl_keep = incl;  // (single: the entries are still in registers, pass 1 skips its loads)
+    }
+  }
+  if (staged) {
+    // the vertex of staged slot x is the number of runs that end at or before x
+    for (uint32_t x0 = 0; x0 < n; x0 += 64) {
+      const uint32_t x = x0 + lane;
+      if (dir) {
+        uint32_t d = 0;  // binary search: the first vertex whose run ends after x
+        for (uint32_t step = leafW >> 1; step; step >>= 1)
+          if (x >= (uint32_t)__shfl(incl_keep, (int)(d + step - 1), 64)) d += step;
+        if (x < n) rrow[t0 + x] = (uint32_t)vfirst + d;
+      }
+      if (x < n) {
+        o_nbr[t0 + x] = stage[x];
+        if (with_pos) epos[t0 + x] = stage_e[x];
+      }
+    }
+  }
+}
+
+static int bits_of(uint64_t v) {  // bits needed for values 0..v
+  int b = 0;
+  while (b < 64 && (v >> b)) b++;
+  return b;
+}
+
+int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
+  *taken = 0;
+  const uint64_t V = csr->V, E = csr->E_cap;
+  if (E == 0 || V == 0 || E >= (1ull << 31)) return GG_OK;  // positions of both directions share one u32 scan
+  FastGeom g;
+  int kb = bits_of(V - 1);
+  if (kb < 1) kb = 1;
+  int low = kb - 9;
+  if (low < 6) low = kb < 6 ? kb : 6;
+  if (low > FB_MAX_LOW) low = FB_MAX_LOW;
+  const int hb = kb - low;
+  if (hb > FB_MAX_HB) return GG_OK;  // more than 2^22 vertices: the multi-pass build
+  g.key_bits = (uint32_t)kb;
+  g.low = (uint32_t)low;
+  g.hb = (uint32_t)hb;
+  g.pack = (low + kb <= 32) ? 1u : 0u;
+  g.sub = (uint32_t)(low < 6 ? low : 6);
+  g.leaf = (uint32_t)low - g.sub;
+  *taken = 1;
+  const uint32_t nb = 1u << hb;
+  const bool rowid = ctx->keep_edge_rowid;
+  hipStream_t s = ctx->stream;
+  const uint64_t nblocks64 = (E + FB_TILE - 1) / FB_TILE;
+  const unsigned nblocks = (unsigned)nblocks64;
+
+  // ---- dictionary (device-side choice) ---------------------------------------------------------------------
+  DirectMap *dm = nullptr;
+  uint32_t *dir = nullptr;
+  unsigned long long *tab = nullptr;
+  const uint32_t idx_bits = (uint32_t)bits_of(V - 1);
+  uint32_t q = 9;  // slot pairs = 2^q: the smallest power of two with a load factor <= GG_FB_LOAD_PCT
+  while ((2ull << q) * GG_FB_LOAD_PCT < V * 100) q++;
+  const uint64_t npairs = 1ull << q;
+  GG_TRY(ctx->dev_alloc((void **)&dm, sizeof(DirectMap)));
+  GG_TRY(ctx->dev_alloc((void **)&dir, DIRECT_MAX_RANGE * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&tab, 2 * npairs * sizeof(unsigned long long)));
+  const DirectMap dm_init{INT64_MAX, INT64_MIN, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+  memcpy(ctx->pin_scratch + 8, &dm_init, sizeof(dm_init));  // (the first words carry the BuildStatus seed)
+  GG_HIP(hipMemcpyAsync(dm, ctx->pin_scratch + 8, sizeof(dm_init), hipMemcpyHostToDevice, s));
+  const unsigned mm_blocks = (V + 255) / 256 < 64 ? (unsigned)((V + 255) / 256) : 64u;
+  GG_LAUNCH(ctx, "id_minmax", k_id_minmax, dim3(mm_blocks), dim3(256), 0, csr->vid, V, dm);
+  GG_LAUNCH(ctx, "dict_decide", k_dict_decide, dim3(1), dim3(64), 0, dm, V, idx_bits, q);
+  GG_LAUNCH(ctx, "direct_init", k_direct_init, dim3((unsigned)(DIRECT_MAX_RANGE / 256)), dim3(256), 0, dir, dm);
+  GG_LAUNCH(ctx, "direct_fill", k_direct_fill, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, dir, dm);
+  GG_LAUNCH(ctx, "packed_init", k_packed_init, dim3((unsigned)((2 * npairs + 255) / 256)), dim3(256), 0, tab, dm);
+  GG_LAUNCH(ctx, "packed_insert", k_packed_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, tab,
+            dm);
+
+  // ---- D ----------------------------------------------------------------------------------------------------
+  u32x2 *pairs = nullptr;
+  uint32_t *counts = nullptr, *bstart = nullptr;
+  uint64_t *total = nullptr;
+  const uint64_t ncount = 2ull * nb * nblocks64;
+  GG_TRY(ctx->dev_alloc((void **)&pairs, E * sizeof(u32x2)));
+  GG_TRY(ctx->dev_alloc((void **)&counts, ncount * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&bstart, 2 * (nb + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&total, sizeof(uint64_t)));
+#ifdef GG_FB_PROBES
+  GG_LAUNCH(ctx, "probe_densify_streams", k_densify_pairs<true>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
+            ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
+            (const DirectMap *)dm, pairs, g, nblocks64, counts);
+#endif
+  GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev, ctx->c_dst.dev, E,
+            csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab, (const DirectMap *)dm,
+            pairs, g, nblocks64, counts);
+  GG_TRY(scan_exclusive_u32(ctx, counts, counts, ncount, total));
+  const uint64_t pmax = 2 * (nblocks64 + nb);  // chunks: every bucket may end in a partial one
+  uint32_t *cstart = nullptr, *part_of = nullptr, *offs = nullptr, *substart = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&cstart, (2 * nb + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&offs, pmax * 65 * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * 65 * sizeof(uint32_t)));
+  GG_LAUNCH(ctx, "bucket_starts", k_bucket_starts, dim3(1), dim3(256), 0, (const uint32_t *)counts, nblocks64, nb,
+            (const uint64_t *)total, bstart, cstart, part_of, st);
+
+  // ---- A ----------------------------------------------------------------------------------------------------
+  const size_t words = g.pack ? 1 : 2;
+  uint32_t *part_f = nullptr, *part_r = nullptr, *epos_f = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&part_f, E * words * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&part_r, E * words * sizeof(uint32_t)));
+  if (rowid) GG_TRY(ctx->dev_alloc((void **)&epos_f, E * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->roff, (V + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->rnbr, E * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&csr->rrow, E * sizeof(uint32_t)));
+  const size_t lds_a = ((size_t)FB_TILE * (words + (rowid ? 1 : 0)) + (size_t)(FB_WAVES + 2) * nb + FB_WAVES + 2) *
+                           sizeof(uint32_t) +
+                       (size_t)FB_TILE * sizeof(uint16_t) + 16 + (GG_FB_MATCH_OR ? (size_t)FB_WAVES * nb * 8 : 0);
+#if GG_FB_XCD
+  const unsigned grid_a = (unsigned)(((nblocks64 + 7) / 8) * 8);
+#else
+  const unsigned grid_a = nblocks;
+#endif
+#define GG_FB_LAUNCH_A(P, R)                                                                                        \
+  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<P, R>),                                 \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));                                \
+  GG_LAUNCH(ctx, "partition_dual", (k_partition_dual<P, R>), dim3(grid_a), dim3(FB_THREADS), lds_a,                  \
+            (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r, \
+            epos_f)
+#ifdef GG_FB_PROBES
+  if (g.pack && !rowid) {
+    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    GG_LAUNCH(ctx, "probe_A_loads", (k_partition_dual<true, false, 1>), dim3(grid_a), dim3(FB_THREADS), lds_a,
+              (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
+              epos_f);
+    GG_LAUNCH(ctx, "probe_A_counts", (k_partition_dual<true, false, 2>), dim3(grid_a), dim3(FB_THREADS), lds_a,
+              (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
+              epos_f);
+    GG_LAUNCH(ctx, "probe_A_rank", (k_partition_dual<true, false, 3>), dim3(grid_a), dim3(FB_THREADS), lds_a,
+              (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
+              epos_f);
+  }
+#endif
+  if (g.pack && rowid) {
+    GG_FB_LAUNCH_A(true, true);
+  } else if (g.pack) {
+    GG_FB_LAUNCH_A(true, false);
+  } else if (rowid) {
+    GG_FB_LAUNCH_A(false, true);
+  } else {
+    GG_FB_LAUNCH_A(false, false);
+  }
+#undef GG_FB_LAUNCH_A
+
+  // ---- B ----------------------------------------------------------------------------------------------------
+  const size_t lds_s = (size_t)(FB_WAVES * 64 + 65 + FB_TILE * (words + (rowid ? 1 : 0))) * sizeof(uint32_t);
+  const size_t lds_l = (size_t)LEAF_WAVES * (64 + GG_FB_CAPW) * sizeof(uint32_t);
+  const unsigned grid_l = (unsigned)((2ull * nb * (1u << g.sub) + LEAF_WAVES - 1) / LEAF_WAVES);
+#define GG_FB_LAUNCH_B(P, R)                                                                                          \
+  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<P, R>),                                         \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
+  GG_LAUNCH(ctx, "sub_sort", (k_sub_sort<P, R>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, epos_f, \
+            (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint32_t *)part_of, g, offs);                    \
+  GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,                         \
+            (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);                   \
+  GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<P, R>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,                          \
+            (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,     \
+            (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,     \
+            csr->epos, csr->roff, csr->rnbr, csr->rrow)
+  if (g.pack && rowid) {
+    GG_FB_LAUNCH_B(true, true);
+  } else if (g.pack) {
+    GG_FB_LAUNCH_B(true, false);
+  } else if (rowid) {
+    GG_FB_LAUNCH_B(false, true);
+  } else {
+    GG_FB_LAUNCH_B(false, false);
+  }
+#undef GG_FB_LAUNCH_B
+
+  for (void *p : {(void *)dm, (void *)dir, (void *)tab, (void *)pairs, (void *)counts, (void *)bstart, (void *)total,
+                  (void *)part_f, (void *)part_r, (void *)epos_f, (void *)cstart, (void *)part_of, (void *)offs,
+                  (void *)substart})
+    ctx->dev_free(p);
+  return GG_OK;
+}
+
+}  // namespace gg

@@ -1,0 +1,194 @@
+// gg_dict.h — id -> dense index dictionaries of the CSR build (device code shared by gg_csr.hip and
+// gg_csr_fast.hip; every kernel is `static`, each translation unit carries its own copy).
+//
+// The reference switches its join to a perfect hash table — an array indexed by key - min — when the build
+// keys are integers spanning at most 1 000 000 values (CheckForPerfectJoinOpt, src/execution/
+// physical_plan/plan_comparison_join.cpp:35-107; PerfectHashJoinExecutor::BuildPerfectHashTable,
+// src/execution/operator/join/perfect_hash_join_executor.cpp:24-65).  Same idea for the id -> dense index
+// dictionary the edge densification probes twice per edge row, in three forms chosen ON THE DEVICE from the
+// vertex ids' min/max (no host synchronisation):
+//   DICT_DIRECT   ids span < 2^20 values: a uint32 array indexed by id - min (<= 4 MiB, stays in an XCD's L2)
+//   DICT_PACKED8  ids spanning up to ~2^54: open addressing with 8-byte slots that hold the quotient of a
+//                 bijective hash of id - min (exact), the pair displacement and the dense index — half the
+//                 footprint of the general table, two slots per 16-byte probe
+//   DICT_WIDE16   anything else: 16-byte slots {id, dense index} (gg_internal.h ht_lookup)
+#pragma once
+#include "gg_internal.h"
+
+namespace gg {
+
+static __global__ __launch_bounds__(256) void k_id_minmax(const int64_t *__restrict__ vid, uint64_t V,
+                                                          DirectMap *__restrict__ dm) {
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (uint64_t)gridDim.x * blockDim.x) {
+    const long long x = vid[i];
+    lo = x < lo ? x : lo;
+    hi = x > hi ? x : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  __shared__ long long s_lo[4], s_hi[4];
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one pair of atomics per workgroup: same-address 64-bit atomics serialise
+    for (int w = 1; w < 4; w++) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+    atomicMin(&dm->min_id, lo);
+    atomicMax(&dm->max_id, hi);
+  }
+}
+
+// idx_bits = bits of V - 1; q = log2(slot pairs) of the packed table (0: the caller has no packed table)
+static __global__ void k_dict_decide(DirectMap *__restrict__ dm, uint64_t V, uint32_t idx_bits, uint32_t q) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t span = (uint64_t)dm->max_id - (uint64_t)dm->min_id;  // exact in unsigned arithmetic
+    const bool any = V > 0 && dm->max_id >= dm->min_id;
+    const uint32_t span_bits = span ? 64u - (uint32_t)__clzll((long long)span) : 0u;
+    unsigned long long mode = DICT_WIDE16;
+    if (any && span < DIRECT_MAX_RANGE)
+      mode = DICT_DIRECT;
+    else if (any && q && span_bits >= q && span_bits <= 57u && span_bits - q + 6u /* PK_DISP_BITS */ + idx_bits <= 63u)
+      mode = DICT_PACKED8;
+    dm->mode = mode;
+    dm->enabled = mode == DICT_DIRECT ? 1ULL : 0ULL;
+    dm->idx_bits = idx_bits;
+    dm->span_bits = span_bits;
+    dm->q = q;
+  }
+}
+
+static __global__ __launch_bounds__(256) void k_direct_init(uint32_t *__restrict__ dir,
+                                                            const DirectMap *__restrict__ dm) {
+  if (!dm->enabled) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < DIRECT_MAX_RANGE) dir[i] = INVALID_U32;
+}
+
+static __global__ __launch_bounds__(256) void k_direct_fill(const int64_t *__restrict__ vid, uint64_t V,
+                                                            uint32_t *__restrict__ dir,
+                                                            const DirectMap *__restrict__ dm) {
+  if (!dm->enabled) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < V) dir[(uint64_t)vid[i] - (uint64_t)dm->min_id] = (uint32_t)i;  // duplicate ids: the hash insert reports them
+}
+
+__device__ __forceinline__ uint32_t direct_lookup(const uint32_t *__restrict__ dir, uint64_t min_id, int64_t key) {
+  const uint64_t off = (uint64_t)key - min_id;
+  return off < DIRECT_MAX_RANGE ? dir[off] : INVALID_U32;
+}
+
+// ---- packed 8-byte slots --------------------------------------------------------------------------------
+// Exact with 8 bytes per vertex for ids spanning up to ~2^54: quotienting.  rel = id - min has S = span_bits
+// significant bits; pk_mix is a BIJECTION on S-bit values (odd multiplications mod 2^S and xor-shifts), so
+// h = pk_mix(rel) identifies the id.  The table has 2^q slot pairs (one aligned 16-byte granule each: a probe
+// loads both slots with one dwordx4); the home pair is the top q bits of h and only the remaining S - q bits
+// (rem) are stored, next to the pair displacement from home (PK_DISP_BITS, linear probing over pairs) and the
+// dense index:   slot = ((rem << PK_DISP_BITS | disp) << idx_bits) | idx,   bit 63 clear, empty = all ones.
+// A lookup scans pairs from home and stops at the first empty slot.  If some key would be displaced further
+// than the field allows, the insert kernel flips the mode back to DICT_WIDE16 (nothing has read it yet).
+constexpr unsigned long long PK_EMPTY = ~0ULL;
+constexpr uint32_t PK_DISP_BITS = 6;
+#ifndef GG_PK_MAX_DISP
+#define GG_PK_MAX_DISP 12
+#endif
+constexpr uint64_t PK_MAX_DISP = GG_PK_MAX_DISP;  // pairs a key may sit away from home before the table is given up
+
+#ifndef GG_PK_MIX
+#define GG_PK_MIX 1
+#endif
+__device__ __forceinline__ uint64_t pk_mix(uint64_t rel, uint32_t S) {  // 21 <= S <= 57
+  const uint64_t mask = (1ULL << S) - 1ULL;
+#if GG_PK_MIX == 1
+  // Fibonacci hashing on S bits: ids that are (pieces of) arithmetic progressions — the usual shape of
+  // database keys — spread almost evenly over the home pairs, far better than a random function would at a
+  // load factor near 0.9; k_packed_insert gives the table up if some key is displaced more than PK_MAX_DISP
+  return (rel * 0x9E3779B97F4A7C15ULL) & mask;
+#else
+  const uint32_t r = S >> 1;
+  uint64_t x = rel;
+  x ^= x >> r;
+  x = (x * 0x9E3779B97F4A7C15ULL) & mask;
+  x ^= x >> r;
+  x = (x * 0xD6E8FEB86659FD93ULL) & mask;
+  x ^= x >> r;
+  return x;
+#endif
+}
+
+struct PkGeom {  // uniform values of a packed table, read once per kernel
+  uint64_t min_id, max_id;
+  uint32_t S, q, b;
+  __device__ __forceinline__ void load(const DirectMap *dm) {
+    min_id = (uint64_t)dm->min_id;
+    max_id = (uint64_t)dm->max_id;
+    S = (uint32_t)dm->span_bits;
+    q = (uint32_t)dm->q;
+    b = (uint32_t)dm->idx_bits;
+  }
+  // home pair and the tag of displacement 0 for a key inside [min, max]
+  __device__ __forceinline__ void locate(int64_t key, uint64_t *home, uint64_t *tag0) const {
+    const uint64_t h = pk_mix((uint64_t)key - min_id, S);
+    *home = h >> (S - q);
+    *tag0 = (h & ((1ULL << (S - q)) - 1ULL)) << PK_DISP_BITS;
+  }
+};
+
+static __global__ __launch_bounds__(256) void k_packed_init(unsigned long long *__restrict__ tab,
+                                                            const DirectMap *__restrict__ dm) {
+  if (dm->mode != DICT_PACKED8) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (2ULL << dm->q)) tab[i] = PK_EMPTY;
+}
+
+static __global__ __launch_bounds__(256) void k_packed_insert(const int64_t *__restrict__ vid, uint64_t V,
+                                                              unsigned long long *__restrict__ tab,
+                                                              DirectMap *__restrict__ dm) {
+  if (*(volatile unsigned long long *)&dm->mode != DICT_PACKED8) return;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V) return;
+  PkGeom pk;
+  pk.load(dm);
+  uint64_t home, tag0;
+  pk.locate(vid[i], &home, &tag0);
+  const uint64_t pmask = (1ULL << pk.q) - 1ULL;
+  for (uint64_t disp = 0; disp <= PK_MAX_DISP; disp++) {
+    const uint64_t g = (home + disp) & pmask;
+    const unsigned long long entry = ((tag0 | disp) << pk.b) | i;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const unsigned long long prev = atomicCAS(&tab[2 * g + s], PK_EMPTY, entry);
+      if (prev == PK_EMPTY) return;
+      if ((prev >> pk.b) == (tag0 | disp)) return;  // duplicate vertex id: k_ht_insert reports it, the build fails
+    }
+  }
+  dm->mode = DICT_WIDE16;  // displaced too far: the edge densification uses the 16-byte table instead
+}
+
+// finish a packed lookup whose first probe (pair `home`, raw) is already loaded
+__device__ __forceinline__ uint32_t packed_resolve(const unsigned long long *__restrict__ tab, const PkGeom &pk,
+                                                   bool in_range, uint64_t home, uint64_t tag0, uint4 raw) {
+  if (!in_range) return INVALID_U32;
+  const unsigned long long idx_mask = (1ULL << pk.b) - 1ULL;
+  const uint64_t pmask = (1ULL << pk.q) - 1ULL;
+  for (uint64_t disp = 0;;) {
+    const unsigned long long e0 = ((unsigned long long)raw.y << 32) | raw.x;
+    const unsigned long long e1 = ((unsigned long long)raw.w << 32) | raw.z;
+    if ((e0 >> pk.b) == (tag0 | disp)) return (uint32_t)(e0 & idx_mask);
+    if (e0 == PK_EMPTY) return INVALID_U32;
+    if ((e1 >> pk.b) == (tag0 | disp)) return (uint32_t)(e1 & idx_mask);
+    if (e1 == PK_EMPTY) return INVALID_U32;
+    if (++disp > PK_MAX_DISP) return INVALID_U32;
+    raw = *reinterpret_cast<const uint4 *>(&tab[2 * ((home + disp) & pmask)]);
+  }
+}
+
+}  // namespace gg

@@ -64,6 +64,30 @@ struct Column {
   size_t cap = 0;  // rows
 };
 
+struct BuildStatus {  // device-side status block of a CSR build, copied back once per build
+  unsigned long long dup_vertex;   // !=0: duplicate vertex id seen
+  long long min_idx;               // dense index of the vertex with id == HT_EMPTY, or -1
+  unsigned long long kept;         // edges kept in the forward CSR (both endpoints are vertices, source owned)
+  unsigned long long kept_rev;     // edges kept in the reverse CSR (shard builds; destination owned)
+  unsigned long long owned;        // vertices owned by this shard
+  unsigned long long scan_error;   // !=0: a chained scan gave up waiting for a predecessor tile (gg_runtime.hip)
+};
+
+// id -> dense index dictionary used while densifying edge rows, chosen on the device from the vertex ids'
+// min/max (no host synchronisation): a direct-address array, a hash table of packed 8-byte slots, or the
+// general 16-byte-slot table (gg_csr.hip, gg_csr_fast.hip)
+constexpr uint64_t DIRECT_MAX_RANGE = 1u << 20;
+enum DictMode : unsigned long long { DICT_WIDE16 = 0, DICT_PACKED8 = 1, DICT_DIRECT = 2 };
+struct DirectMap {
+  long long min_id;              // INT64_MAX until k_id_minmax ran
+  long long max_id;
+  unsigned long long enabled;    // ids span < DIRECT_MAX_RANGE values (mode == DICT_DIRECT)
+  unsigned long long mode;       // DictMode
+  unsigned long long idx_bits;   // packed slots: bits of the dense index field
+  unsigned long long span_bits;  // bits of max_id - min_id
+  unsigned long long q;          // packed table: log2 of the number of 16-byte slot pairs
+};
+
 }  // namespace gg
 
 namespace gg {
@@ -135,6 +159,7 @@ struct gg_ctx {
 
   // ---- profiling ----
   bool force_frontier = false;  // gg_debug_force_frontier
+  bool legacy_build = false;    // gg_debug_force_legacy_build: the multi-pass LSD build (also taken for > 2^22 vertices)
   bool keep_edge_rowid = true;  // gg_ctx_set_edge_rowid
   bool profiling = false;
   std::vector<std::string> prof_names;
@@ -226,6 +251,9 @@ int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t 
 int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows);
 // build csr->roff / csr->rnbr if absent (gg_csr.hip)
 int ensure_reverse(gg_ctx *ctx, gg_csr *csr);
+// bucketed two-level build of forward + reverse CSR (gg_csr_fast.hip); *taken = 0 if the graph is outside
+// its range (> 2^22 vertices) and nothing was launched
+int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken);
 
 __device__ __forceinline__ uint64_t fmix64(uint64_t x) {
   x ^= x >> 33;
@@ -243,7 +271,12 @@ __device__ __forceinline__ uint64_t dig_leaf(uint64_t q, uint32_t d) {
 // slot of a key in a table of `cap` slots (any capacity, not only powers of two): multiplicative hash,
 // then multiply-high range reduction; linear probing wraps at cap
 __device__ __forceinline__ uint64_t ht_slot(int64_t key, uint64_t cap) {
-  return __umul64hi((uint64_t)key * DIG_GOLD, cap);
+  // one multiplication leaves arithmetic progressions (ids that are multiples of 10^5, say) in long probe
+  // runs: 332 us instead of 32 us to insert 448 k such ids; fold the high half down and multiply again
+  uint64_t h = (uint64_t)key * DIG_GOLD;
+  h ^= h >> 32;
+  h *= 0xD6E8FEB86659FD93ULL;
+  return __umul64hi(h, cap);
 }
 __device__ __forceinline__ uint64_t ht_next(uint64_t slot, uint64_t cap) { return slot + 1 == cap ? 0 : slot + 1; }
 

@@ -188,6 +188,12 @@ extern "C" int gg_debug_force_frontier(gg_ctx *ctx, int on) {
   return GG_OK;
 }
 
+extern "C" int gg_debug_force_legacy_build(gg_ctx *ctx, int on) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  ctx->legacy_build = on != 0;
+  return GG_OK;
+}
+
 extern "C" int gg_profile_enable(gg_ctx *ctx, int on) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   GG_TRY(ctx->prof_flush());

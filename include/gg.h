@@ -245,6 +245,9 @@ void gg_bfs_sharded_end(gg_bfs_run *run);
 /* Testing knob: force gg_expand_khop to use the frontier kernels even where the product kernel
  * applies (both must give identical results). */
 int gg_debug_force_frontier(gg_ctx *ctx, int on);
+/* Testing knob: force gg_csr_build onto the multi-pass LSD build that graphs of more than 2^22 vertices
+ * (and shard builds) take; both builds must export identical arrays. */
+int gg_debug_force_legacy_build(gg_ctx *ctx, int on);
 
 int gg_profile_enable(gg_ctx *ctx, int on);
 /* Time only the kernels named in the comma-separated list (NULL: every kernel).  Two event records per

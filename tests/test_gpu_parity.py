@@ -836,3 +836,73 @@ def test_bfs64_pairs_packed_words_decode_to_the_same_rows(gg, orc):
     assert np.array_equal(sort_rows(decoded), sort_rows(rows))
     csr.close()
     g.close()
+
+
+def _ids_for(kind, V, rng):
+    if kind == "sparse":      # LDBC-like magnitude: packed 8-byte dictionary slots
+        return datagen.person_ids(V, 11)
+    if kind == "dense":       # span < 2^20: direct-address array
+        return (np.arange(V, dtype=np.int64) * 2 - 77)[rng.permutation(V)]
+    if kind == "wide":        # arbitrary 64-bit ids: 16-byte slots
+        ids = np.unique(rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, V + V // 8, dtype=np.int64))
+        return ids[rng.permutation(ids.size)][:V]
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("kind,V,E", [
+    ("sparse", 1, 7), ("sparse", 33, 500), ("sparse", 64, 3000), ("sparse", 65, 3000), ("sparse", 1024, 50_000),
+    ("sparse", 1025, 50_000), ("sparse", 70_000, 600_000), ("sparse", 300_000, 2_000_000),
+    ("dense", 300_000, 1_000_000), ("wide", 40_000, 400_000),
+    ("sparse32", 2_200_000, 3_000_000),   # 22 key bits: buckets of 4096 vertices, unpacked (low, payload) pairs
+    ("wide", 1_100_000, 1_500_000),       # 21 key bits + 12 low bits > 32: unpacked pairs, 16-byte slots
+])
+@pytest.mark.parametrize("rowid", [False, True])
+def test_bucketed_build_and_multipass_build_both_equal_the_oracle(gg, orc, kind, V, E, rowid):
+    """gg_csr_build has two builds: the bucketed two-level one (gg_csr_fast.hip, <= 2^22 vertices) and the
+    multi-pass LSD one (gg_csr.hip).  Both must export the oracle's arrays bit for bit, whichever id
+    dictionary the device picks; the reverse CSR is checked through the 2-hop product kernel and the pull
+    levels of the BFS."""
+    rng = np.random.default_rng(V * 31 + E)
+    if kind == "sparse32":  # small span, many vertices: packed slots, but low + key bits > 32
+        vid = (np.arange(V, dtype=np.int64) * 3 + 7)[rng.permutation(V)]
+    else:
+        vid = _ids_for(kind, V, rng)
+    src = vid[rng.integers(0, V, E)]
+    dst = vid[rng.integers(0, V, E)]
+    # a few hubs, self loops, duplicate rows and dangling endpoints
+    src[: E // 10] = vid[rng.integers(0, min(V, 3), E // 10)]
+    dst[E // 2: E // 2 + E // 20] = vid[0]
+    bad = np.array([np.iinfo(np.int64).max - 3, int(vid.min()) - 1 if int(vid.min()) > np.iinfo(np.int64).min else 5], np.int64)
+    bad = bad[~np.isin(bad, vid)]
+    src = np.concatenate([src, bad, vid[: bad.size]])
+    dst = np.concatenate([dst, vid[: bad.size], bad])
+    gg.set_edge_rowid(rowid)
+    try:
+        rc, g = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        o_off, o_nbr, o_eid, o_vid = g.arrays()
+        want = g.khop(1, 2) if E <= 600_000 else None
+        sources = vid[:: max(1, V // 64)][:64]
+        o_dist, o_st = g.bfs64(g.lookup(sources), 4) if E <= 2_000_000 else (None, None)
+        for legacy in (False, True):
+            gg.force_legacy_build(legacy)
+            gg.staging_clear()
+            gg.append_vertices(vid)
+            gg.append_edges(src, dst)
+            csr = gg.build_csr()
+            off, nbr, eid, v2 = csr.export()
+            assert csr.V == g.V and csr.E == g.E and csr.dropped == g.dropped, legacy
+            assert np.array_equal(off, o_off), legacy
+            assert np.array_equal(nbr, o_nbr), legacy
+            assert np.array_equal(v2, o_vid), legacy
+            assert np.array_equal(eid, o_eid) if rowid else np.all(eid == -1), legacy
+            if want is not None:
+                assert gg.expand_khop(csr, 1, 2) == want, legacy
+            if o_dist is not None:
+                dist, st = gg.bfs64(csr, sources, 4)
+                assert np.array_equal(dist, o_dist) and st == o_st, legacy
+            csr.close()
+        g.close()
+    finally:
+        gg.force_legacy_build(False)
+        gg.set_edge_rowid(True)
