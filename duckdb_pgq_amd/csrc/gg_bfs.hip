@@ -425,6 +425,9 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
                            pairs->cols[2][0], pairs->cols[2][1], pairs->cols[2][2]);
       if (hipGetLastError() != hipSuccess) rc = GG_ERR_HIP;
     }
+    if (rc == GG_OK) rc = scan_error_fetch(ctx);
+    if (rc == GG_OK && hipStreamSynchronize(s) != hipSuccess) rc = GG_ERR_HIP;
+    if (rc == GG_OK) rc = scan_error_test(ctx);
     if (rc == GG_OK) {
       for (int c = 0; c < ncols; c++) ctx->keep(pairs->cols[table][c]);
       pairs->rows[table] = reached;
@@ -708,7 +711,9 @@ extern "C" int gg_bfs_sharded_pairs(gg_bfs_run *run, gg_result **out_result) {
               (const uint8_t *)run->dist8, V, run->n_src, counts);
     GG_TRY(scan_exclusive_u32(ctx, counts, counts, V, total));
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    GG_TRY(scan_error_fetch(ctx));
     GG_HIP(hipStreamSynchronize(s));
+    GG_TRY(scan_error_test(ctx));
     const uint64_t rows = ctx->pin_scratch[0];
     if (rows) {
       for (int c = 0; c < 3; c++) GG_TRY(ctx->dev_alloc((void **)&res->cols[2][c], rows * sizeof(int64_t)));

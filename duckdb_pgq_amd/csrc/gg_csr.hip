@@ -348,8 +348,12 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
     const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ a_in, const uint32_t *__restrict__ b_in,
     uint64_t n_host, const unsigned long long *__restrict__ n_dev, uint32_t lo_bit, uint32_t bits, uint64_t nblocks,
     const uint32_t *__restrict__ bases, const uint32_t *__restrict__ tile_valid /* nullable: valid prefix per tile */,
-    uint32_t *__restrict__ key_out, uint32_t *__restrict__ a_out, uint32_t *__restrict__ b_out) {
+    uint32_t *__restrict__ key_out, uint32_t *__restrict__ a_out, uint32_t *__restrict__ b_out,
+    const unsigned long long *__restrict__ err) {
   extern __shared__ uint32_t lds[];
+  // a scan that gave up leaves prefixes that are too small: this pass would leave slots of its output unwritten,
+  // and the next kernels would take whatever those slots hold for keys.  Nothing is written after an error.
+  if (*err) return;
   const uint32_t ndig = 1u << bits;
   uint32_t *xk = lds;                                  // staged keys, digit order
   uint32_t *xa = xk + RB_TILE;
@@ -469,7 +473,9 @@ __global__ __launch_bounds__(RB_THREADS) void k_radix_scatter(
 // Each thread owns 4 consecutive keys (one 16-byte load) and looks one key back.
 __global__ __launch_bounds__(256) void k_row_offsets(const uint32_t *__restrict__ key, uint64_t n_host,
                                                      const unsigned long long *__restrict__ n_dev, uint64_t V,
-                                                     uint32_t *__restrict__ off) {
+                                                     uint32_t *__restrict__ off,
+                                                     const unsigned long long *__restrict__ err) {
+  if (*err) return;  // the keys are not a sorted column after a scan error (see k_radix_scatter)
   const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n == 0) {
@@ -513,8 +519,10 @@ __global__ __launch_bounds__(64) void k_publish_kept(const uint64_t *__restrict_
 __global__ __launch_bounds__(256) void k_gather_rowid(const uint32_t *__restrict__ epos,
                                                       const int64_t *__restrict__ rowid,
                                                       const unsigned long long *__restrict__ n_dev,
-                                                      int64_t *__restrict__ eid) {
+                                                      int64_t *__restrict__ eid,
+                                                      const unsigned long long *__restrict__ err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (*err) return;  // epos is not valid after a scan error
   if (i < *n_dev) eid[i] = rowid[epos[i]];
 }
 
@@ -586,13 +594,16 @@ int radix_sort_stable(gg_ctx *ctx, const RadixIO &io, uint64_t n, bool has_b, bo
     const unsigned long long *nd = (p == 0) ? nullptr : total_dev;
     if (has_b && gen_b && p == 0)
       GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true, true>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
-                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout);
+                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout,
+                (const unsigned long long *)ctx->dev_err);
     else if (has_b)
       GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<true, false>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
-                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout);
+                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout,
+                (const unsigned long long *)ctx->dev_err);
     else
       GG_LAUNCH(ctx, "radix_scatter", (k_radix_scatter<false, false>), dim3(nblocks), dim3(RB_THREADS), lds, kin, ain,
-                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout);
+                bin, n, nd, lo_bit, bits, nblocks64, counts, p == 0 ? tile_valid0 : nullptr, kout, aout, bout,
+                (const unsigned long long *)ctx->dev_err);
     if (!(p == 0 && counts0)) ctx->dev_free(counts);
     kin = kout;
     ain = aout;
@@ -756,11 +767,11 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   }
   if (shard) {
     GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0,
-              rkey_sorted, (uint64_t)0, (const unsigned long long *)kept_rev_dev, V, csr->roff);
+              rkey_sorted, (uint64_t)0, (const unsigned long long *)kept_rev_dev, V, csr->roff, (const unsigned long long *)ctx->dev_err);
   }
   if (!fast) {
     GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0, csr->row,
-              (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off);
+              (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off, (const unsigned long long *)ctx->dev_err);
     GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
               (const uint64_t *)kept_rev_dev, st);
   } else {  // the gather of explicit rowids below reads the kept count from kept_dev
@@ -775,11 +786,13 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
                 ctx->c_rowid.dev + range.first, (int64_t)range.first, range.second);
     GG_TRY(ctx->dev_alloc((void **)&csr->eid, E * sizeof(int64_t)));
     GG_LAUNCH(ctx, "gather_rowid", k_gather_rowid, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, csr->epos,
-              ctx->c_rowid.dev, (const unsigned long long *)kept_dev, csr->eid);
+              ctx->c_rowid.dev, (const unsigned long long *)kept_dev, csr->eid,
+              (const unsigned long long *)ctx->dev_err);
   }
 
   // status back to the host (the only synchronisation of the build): duplicate check, sentinel
   // vertex, kept-edge count
+  GG_HIP(hipMemcpyAsync(&st->scan_error, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
   GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, s));
   GG_HIP(hipStreamSynchronize(s));
   BuildStatus hs;
@@ -789,7 +802,8 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   ctx->dev_free(kept_rev_dev);
   if (!fast) csr->rrow = rkey_sorted;  // null unless this is a shard build (ensure_reverse fills it lazily otherwise)
   if (hs.scan_error) {
-    set_error("CSR build: a chained scan gave up waiting for a predecessor tile");
+    GG_HIP(hipMemsetAsync(ctx->dev_err, 0, sizeof(unsigned long long), s));
+    set_error("CSR build: a chained prefix scan gave up waiting for a predecessor tile");
     return GG_ERR_HIP;
   }
   if (hs.dup_vertex) {
@@ -849,7 +863,10 @@ int ensure_reverse(gg_ctx *ctx, gg_csr *csr) {
     ctx->dev_free(tot);
   }
   GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0, rkey, E,
-            (const unsigned long long *)nullptr, V, csr->roff);
+            (const unsigned long long *)nullptr, V, csr->roff, (const unsigned long long *)ctx->dev_err);
+  GG_TRY(scan_error_fetch(ctx));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  GG_TRY(scan_error_test(ctx));
   csr->rrow = rkey;
   ctx->keep(csr->roff);
   ctx->keep(csr->rnbr);
@@ -1041,7 +1058,9 @@ extern "C" int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uin
     memcpy(ctx->pin_scratch, &only, sizeof(only));
     GG_HIP(hipMemcpyAsync(ctx->c_vid.dev, ctx->pin_scratch, sizeof(only), hipMemcpyHostToDevice, s));
   }
+  GG_TRY(scan_error_fetch(ctx));
   GG_HIP(hipStreamSynchronize(s));
+  GG_TRY(scan_error_test(ctx));
   ctx->n_vertices = V;
   if (n_vertices) *n_vertices = V;
   return GG_OK;

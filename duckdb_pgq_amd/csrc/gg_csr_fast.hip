@@ -42,7 +42,7 @@ constexpr int FB_WTILE = FB_TILE / FB_WAVES;     // contiguous rows per wave in 
 constexpr int FB_MAX_HB = 10;                    // bucket bits
 constexpr int FB_MAX_LOW = 12;                   // vertex-in-bucket bits (8 x 4096 x 4 B of LDS histograms in B)
 #ifndef GG_FB_LOAD_PCT
-#define GG_FB_LOAD_PCT 88                        // load factor of the packed dictionary, percent
+#define GG_FB_LOAD_PCT 50                        // load factor of the packed dictionary, percent
 #endif
 #ifndef GG_FB_NT
 #define GG_FB_NT 1                               // streamed columns bypass the caches' retention (nt loads/stores)
@@ -106,7 +106,10 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
                                              const unsigned long long *__restrict__ tab,
                                              const DirectMap *__restrict__ dm, u32x2 *__restrict__ pairs,
                                              uint32_t low, uint32_t *hist_f, uint32_t *hist_r) {
-  constexpr int B = 4;  // edge rows per batch: 2*B independent first probes in flight per lane
+#ifndef GG_FB_DB
+#define GG_FB_DB 4
+#endif
+  constexpr int B = GG_FB_DB;  // edge rows per batch: 2*B independent first probes in flight per lane
   const int64_t min_id = dm->min_id, max_id = dm->max_id;
   PkGeom pk;
   pk.load(dm);
@@ -215,8 +218,9 @@ template <bool PACK, bool ROWID, int STOP = 0>  // STOP > 0: timing probes that 
 __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
     const u32x2 *__restrict__ pairs, uint64_t E, FastGeom g, uint64_t nblocks, const uint32_t *__restrict__ bases,
     const BuildStatus *__restrict__ st, uint32_t *__restrict__ out_f, uint32_t *__restrict__ out_r,
-    uint32_t *__restrict__ epos_f) {
+    uint32_t *__restrict__ epos_f, const unsigned long long *__restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  if (*err) return;  // scan error: see k_bucket_starts
   const uint32_t nb = 1u << g.hb;
   uint32_t *xw = lds;                                   // staged words (PACK) or low keys
   uint32_t *xp = xw + FB_TILE;                          // staged payloads (!PACK)
@@ -404,8 +408,13 @@ constexpr int LEAF_MAXS = 24;    // 64-entry steps a wave keeps in registers
 __global__ __launch_bounds__(256) void k_bucket_starts(const uint32_t *__restrict__ bases, uint64_t nblocks,
                                                        uint32_t nb, const uint64_t *__restrict__ total,
                                                        uint32_t *__restrict__ bstart, uint32_t *__restrict__ cstart,
-                                                       uint32_t *__restrict__ part_of, BuildStatus *__restrict__ st) {
+                                                       uint32_t *__restrict__ part_of, BuildStatus *__restrict__ st,
+                                                       const unsigned long long *__restrict__ err) {
   __shared__ uint32_t s_b[2 * ((1 << FB_MAX_HB) + 1)];
+  if (*err) {  // the scan gave up: its prefixes are too small, positions derived from them could leave the arrays
+    for (uint32_t i = threadIdx.x; i <= 2 * nb; i += 256) cstart[i] = 0;  // no chunks: the kernels below do nothing
+    return;
+  }
   __shared__ uint32_t s_w[4];
   const uint32_t kept = (uint32_t)(*total / 2);  // both directions count the same rows
   for (uint32_t i = threadIdx.x; i < 2 * (nb + 1); i += 256) {
@@ -583,7 +592,9 @@ __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ bstart,
                                                    const uint32_t *__restrict__ cstart, FastGeom g, uint64_t V,
                                                    uint32_t *__restrict__ substart, uint32_t *__restrict__ off,
-                                                   uint32_t *__restrict__ roff) {
+                                                   uint32_t *__restrict__ roff,
+                                                   const unsigned long long *__restrict__ err) {
+  if (*err) return;  // scan error: see k_bucket_starts
   const uint32_t nb = 1u << g.hb, i = blockIdx.x, dir = i / nb, j = i % nb;
   const int lane = threadIdx.x;
   const uint32_t p0 = cstart[i], p1 = cstart[i + 1];
@@ -608,8 +619,9 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ offs,
     const uint32_t *__restrict__ substart, FastGeom g, uint64_t V, uint32_t *__restrict__ off,
     uint32_t *__restrict__ nbr, uint32_t *__restrict__ epos, uint32_t *__restrict__ roff,
-    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow) {
+    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow, const unsigned long long *__restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  if (*err) return;  // scan error: see k_bucket_starts
   const uint32_t nb = 1u << g.hb, nsub = 1u << g.sub, leafW = 1u << g.leaf;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t unit = blockIdx.x * LEAF_WAVES + wave;  // (bucket i, sub s): waves are independent from here on
@@ -836,7 +848,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_TRY(ctx->dev_alloc((void **)&offs, pmax * 65 * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * 65 * sizeof(uint32_t)));
   GG_LAUNCH(ctx, "bucket_starts", k_bucket_starts, dim3(1), dim3(256), 0, (const uint32_t *)counts, nblocks64, nb,
-            (const uint64_t *)total, bstart, cstart, part_of, st);
+            (const uint64_t *)total, bstart, cstart, part_of, st, (const unsigned long long *)ctx->dev_err);
 
   // ---- A ----------------------------------------------------------------------------------------------------
   const size_t words = g.pack ? 1 : 2;
@@ -860,7 +872,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));                                \
   GG_LAUNCH(ctx, "partition_dual", (k_partition_dual<P, R>), dim3(grid_a), dim3(FB_THREADS), lds_a,                  \
             (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r, \
-            epos_f)
+            epos_f, (const unsigned long long *)ctx->dev_err)
 #ifdef GG_FB_PROBES
   if (g.pack && !rowid) {
     GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 1>),
@@ -871,13 +883,13 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     GG_LAUNCH(ctx, "probe_A_loads", (k_partition_dual<true, false, 1>), dim3(grid_a), dim3(FB_THREADS), lds_a,
               (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f);
+              epos_f, (const unsigned long long *)ctx->dev_err);
     GG_LAUNCH(ctx, "probe_A_counts", (k_partition_dual<true, false, 2>), dim3(grid_a), dim3(FB_THREADS), lds_a,
               (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f);
+              epos_f, (const unsigned long long *)ctx->dev_err);
     GG_LAUNCH(ctx, "probe_A_rank", (k_partition_dual<true, false, 3>), dim3(grid_a), dim3(FB_THREADS), lds_a,
               (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f);
+              epos_f, (const unsigned long long *)ctx->dev_err);
   }
 #endif
   if (g.pack && rowid) {
@@ -901,11 +913,12 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_LAUNCH(ctx, "sub_sort", (k_sub_sort<P, R>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, epos_f, \
             (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint32_t *)part_of, g, offs);                    \
   GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,                         \
-            (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);                   \
+            (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff,                    \
+            (const unsigned long long *)ctx->dev_err);                                                                  \
   GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<P, R>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,                          \
             (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,     \
             (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,     \
-            csr->epos, csr->roff, csr->rnbr, csr->rrow)
+            csr->epos, csr->roff, csr->rnbr, csr->rrow, (const unsigned long long *)ctx->dev_err)
   if (g.pack && rowid) {
     GG_FB_LAUNCH_B(true, true);
   } else if (g.pack) {

@@ -102,7 +102,9 @@ extern "C" int gg_result_filter_common_neighbour(gg_ctx *ctx, const gg_result *r
               (const uint64_t *)nullptr, oc);
     GG_TRY(scan_exclusive_u64(ctx, counts, counts, n_rows, tot));
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tot, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_TRY(scan_error_fetch(ctx));
     GG_HIP(hipStreamSynchronize(ctx->stream));
+    GG_TRY(scan_error_test(ctx));
     total = ctx->pin_scratch[0];
     for (int c = 0; c <= ncols; c++) {
       GG_TRY(ctx->dev_alloc((void **)&o->cols[hops + 1][c], (total ? total : 1) * sizeof(int64_t)));

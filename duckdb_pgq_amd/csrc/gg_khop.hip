@@ -693,7 +693,9 @@ int offsets_from_deg(gg_ctx *ctx, uint64_t *deg_then_off /* n+1 */, uint64_t n, 
   GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(uint64_t)));
   GG_TRY(scan_exclusive_u64(ctx, deg_then_off, deg_then_off, n, tot));
   GG_HIP(hipMemcpyAsync(deg_then_off + n, tot, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  GG_TRY(scan_error_fetch(ctx));
   GG_TRY(read_u64(ctx, tot, total_host));
+  GG_TRY(scan_error_test(ctx));
   ctx->dev_free(tot);
   return GG_OK;
 }

@@ -194,6 +194,13 @@ extern "C" int gg_debug_force_legacy_build(gg_ctx *ctx, int on) {
   return GG_OK;
 }
 
+extern "C" int gg_debug_scan_fault(gg_ctx *ctx, uint32_t spin_limit, uint64_t mute_tile) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  ctx->scan_spin_limit = spin_limit ? spin_limit : (1u << 24);
+  ctx->scan_mute_tile = mute_tile;
+  return GG_OK;
+}
+
 extern "C" int gg_profile_enable(gg_ctx *ctx, int on) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   GG_TRY(ctx->prof_flush());
@@ -252,6 +259,9 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   }
   ctx->eblk[0].state = gg_ctx::EdgeBlock::OPEN;
   GG_HIP(hipHostMalloc((void **)&ctx->pin_scratch, 64 * sizeof(uint64_t), hipHostMallocDefault));
+  memset(ctx->pin_scratch, 0, 64 * sizeof(uint64_t));
+  GG_HIP(hipMalloc((void **)&ctx->dev_err, sizeof(unsigned long long)));
+  GG_HIP(hipMemset(ctx->dev_err, 0, sizeof(unsigned long long)));
   *out = ctx;
   return GG_OK;
 }
@@ -270,6 +280,7 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
     if (ctx->eblk[i].free_ev) (void)hipEventDestroy(ctx->eblk[i].free_ev);
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
+  if (ctx->dev_err) (void)hipFree(ctx->dev_err);
   for (auto ev : ctx->prof_event_pool) (void)hipEventDestroy(ev);
   for (auto &h : ctx->host_blocks)
     if (h.ptr) (void)hipHostFree(h.ptr);
@@ -602,7 +613,9 @@ template <typename TIn, typename TOut>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const TIn *__restrict__ in, TOut *__restrict__ out,
                                                                uint64_t n, uint64_t nb,
                                                                unsigned long long *__restrict__ status /* nb + 1 */,
-                                                               uint64_t *__restrict__ total_dev) {
+                                                               uint64_t *__restrict__ total_dev,
+                                                               unsigned long long *__restrict__ err, uint32_t spin_limit,
+                                                               uint64_t mute_tile /* fault injection: never publishes */) {
   __shared__ uint64_t lds[4];
   __shared__ uint64_t s_tile, s_prefix;
   if (threadIdx.x == 0) s_tile = atomicAdd(&status[nb], 1ULL);  // the ticket counter lives behind the status words
@@ -622,7 +635,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const TIn *__rest
   uint64_t ex = block_excl_scan<uint64_t>(sum, &tot, lds);
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
-    if (tile > 0 && lane == 0)
+    const bool mute = tile == mute_tile;
+    if (tile > 0 && lane == 0 && !mute)
       __hip_atomic_store(&status[tile], SCAN_FLAG_SUM | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t run = 0;
     int64_t hi = (int64_t)tile - 1;  // nearest predecessor not yet accounted for
@@ -633,11 +647,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const TIn *__rest
         uint32_t spins = 0;
         do {
           w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((w >> 62) == 0 && ++spins < (1u << 24));  // predecessors hold lower tickets: they are running
+        } while ((w >> 62) == 0 && ++spins < spin_limit);  // predecessors hold lower tickets: they are running
+        // gave up (a predecessor never published): the prefix is wrong from here on — say so, the host turns
+        // the flag into GG_ERR_HIP at its next synchronisation (scan_error_fetch / scan_error_test)
+        if ((w >> 62) == 0) atomicOr(err, 1ULL);
       }
       const unsigned long long is_prefix = __ballot((w >> 62) == 2);
       // lanes up to (and including) the nearest tile that knows its prefix contribute; a lane that gave
-      // up waiting contributes nothing (the result is then wrong, but the grid still drains)
+      // up waiting contributes nothing (the grid still drains; the error word above is set)
       const int stop = is_prefix ? __ffsll((long long)is_prefix) - 1 : 63;
       uint64_t part = (lane <= stop && (w >> 62) != 0) ? (uint64_t)(w & SCAN_VALUE_MASK) : 0;
 #pragma unroll
@@ -647,8 +664,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chained(const TIn *__rest
       hi -= 64;
     }
     if (lane == 0) {
-      __hip_atomic_store(&status[tile], SCAN_FLAG_PREFIX | ((run + tot) & SCAN_VALUE_MASK), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      if (!mute)
+        __hip_atomic_store(&status[tile], SCAN_FLAG_PREFIX | ((run + tot) & SCAN_VALUE_MASK), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       s_prefix = run;
       if (tile == nb - 1 && total_dev) *total_dev = run + tot;
     }
@@ -674,9 +692,24 @@ static int scan_impl(gg_ctx *ctx, const TIn *in, TOut *out, uint64_t n, uint64_t
   GG_TRY(ctx->dev_alloc((void **)&status, (nb + 1) * sizeof(unsigned long long)));
   GG_HIP(hipMemsetAsync(status, 0, (nb + 1) * sizeof(unsigned long long), ctx->stream));
   GG_LAUNCH(ctx, "scan_chained", (k_scan_chained<TIn, TOut>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, in, out, n, nb,
-            status, total_dev);
+            status, total_dev, ctx->dev_err, ctx->scan_spin_limit, ctx->scan_mute_tile);
   ctx->dev_free(status);  // stream-ordered reuse: later work on the same stream runs after this kernel
   return GG_OK;
+}
+
+// A chained scan that gave up waiting sets ctx->dev_err.  Callers enqueue scan_error_fetch before a
+// synchronisation they do anyway and call scan_error_test after it.
+int scan_error_fetch(gg_ctx *ctx) {
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch + 63, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  return GG_OK;
+}
+int scan_error_test(gg_ctx *ctx) {
+  if (ctx->pin_scratch[63] == 0) return GG_OK;
+  ctx->pin_scratch[63] = 0;
+  GG_HIP(hipMemsetAsync(ctx->dev_err, 0, sizeof(unsigned long long), ctx->stream));
+  set_error("a chained prefix scan gave up waiting for a predecessor tile: the result of this call is not valid");
+  return GG_ERR_HIP;
 }
 
 int scan_exclusive_u32(gg_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint64_t *total_dev) {

@@ -248,6 +248,11 @@ int gg_debug_force_frontier(gg_ctx *ctx, int on);
 /* Testing knob: force gg_csr_build onto the multi-pass LSD build that graphs of more than 2^22 vertices
  * (and shard builds) take; both builds must export identical arrays. */
 int gg_debug_force_legacy_build(gg_ctx *ctx, int on);
+/* Testing knob (fault injection): tile `mute_tile` of every chained prefix scan never publishes its sum and the
+ * tiles behind it give up after `spin_limit` polls instead of 2^24; the call that ran the scan must then
+ * fail with GG_ERR_HIP instead of returning a wrong result.  spin_limit 0 and mute_tile UINT64_MAX restore
+ * normal operation. */
+int gg_debug_scan_fault(gg_ctx *ctx, uint32_t spin_limit, uint64_t mute_tile);
 
 int gg_profile_enable(gg_ctx *ctx, int on);
 /* Time only the kernels named in the comma-separated list (NULL: every kernel).  Two event records per

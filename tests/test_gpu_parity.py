@@ -805,7 +805,7 @@ def test_profile_select_times_only_the_named_kernels(gg, orc):
     gg.append_vertices(vid)
     gg.append_edges(src, dst)
     gg.profile_reset()
-    gg.profile_select(["densify_hist", "expand_mid2"])
+    gg.profile_select(["densify_pairs", "expand_mid2"])
     gg.profile(True)
     for _ in range(3):
         c = gg.build_csr()
@@ -813,14 +813,24 @@ def test_profile_select_times_only_the_named_kernels(gg, orc):
         c.close()
     gg.profile(False)
     prof = gg.profile_get()
-    assert set(prof) == {"densify_hist", "expand_mid2"} and prof["densify_hist"][0] == 3 and prof["expand_mid2"][1] > 0
+    assert set(prof) == {"densify_pairs", "expand_mid2"} and prof["densify_pairs"][0] == 3 and prof["expand_mid2"][1] > 0
     gg.profile_reset()
     gg.profile_select(None)
     gg.profile(True)
     c = gg.build_csr()
     c.close()
     gg.profile(False)
-    assert {"ht_insert", "densify_hist", "radix_scatter", "scan_chained", "row_offsets"} <= set(gg.profile_get())
+    assert {"ht_insert", "densify_pairs", "partition_dual", "scan_chained", "sub_sort", "leaf_rows"} <= set(gg.profile_get())
+    gg.force_legacy_build(True)
+    try:
+        gg.profile_reset()
+        gg.profile(True)
+        c = gg.build_csr()
+        c.close()
+        gg.profile(False)
+        assert {"ht_insert", "densify_hist", "radix_scatter", "scan_chained", "row_offsets"} <= set(gg.profile_get())
+    finally:
+        gg.force_legacy_build(False)
 
 
 def test_bfs64_pairs_packed_words_decode_to_the_same_rows(gg, orc):
@@ -906,3 +916,32 @@ def test_bucketed_build_and_multipass_build_both_equal_the_oracle(gg, orc, kind,
     finally:
         gg.force_legacy_build(False)
         gg.set_edge_rowid(True)
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_a_scan_tile_that_never_publishes_is_an_error_not_a_wrong_csr(gg, orc, legacy):
+    """The chained prefix scan bounds its look-back spin.  If a predecessor tile never publishes (injected here),
+    the tiles behind it give up — and the build must fail with GG_ERR_HIP instead of returning offsets computed
+    from a wrong prefix.  Afterwards the context works again."""
+    from duckdb_pgq_amd import GGError
+
+    vid, src, dst = datagen.ldbc_knows(20_000, 1_500_000, 5)
+    gg.force_legacy_build(legacy)
+    try:
+        gg.staging_clear()
+        gg.append_vertices(vid)
+        gg.append_edges(src, dst)
+        gg.scan_fault(spin_limit=64, mute_tile=1)
+        with pytest.raises(GGError) as e:
+            gg.build_csr()
+        assert e.value.code == -2 and "scan" in str(e.value)
+        gg.scan_fault()
+        csr = gg.build_csr()
+        rc, g = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        assert_csr_equal(csr, g)
+        csr.close()
+        g.close()
+    finally:
+        gg.scan_fault()
+        gg.force_legacy_build(False)
