@@ -2,7 +2,8 @@
 """bench.py — traversed edges/sec on LDBC SNB 2-hop MATCH (Person-KNOWS*1..2-Person), MI355X.
 
 One "step" = one pass of the hot path over the synthetic LDBC-shaped tables already resident in HBM:
-    gg_csr_build (densify ids, histogram, scan, stable radix scatter)  +  gg_expand_khop_range(1..2)
+    gg_csr_build (densify ids, bucket partition, sub-bucket sort, rows: forward + reverse CSR)  +
+    gg_expand_khop_range(1..2)
 i.e. what the reference does per query as hash-join build + probe chain.  With N > 1 ranks the
 vertices are hash-partitioned (owner = hash(person id) mod N) and so is the edge table: a rank holds the
 `knows` rows whose source or destination it owns (every row on at most two ranks; the 3.6 MB person
@@ -11,18 +12,27 @@ the walks whose middle vertex it owns; there is no data-path collective, only on
 (rows, digest, TE) per step, so `value` = total traversed edges of the whole query / max-over-ranks
 time ("strong" scaling: the query is fixed, ranks split it).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sf100|sf10|sf1] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sf100|sf10|sf1] [--no-cpu] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (largest total time among densify / radix scatter / expansion; algorithmic bytes per SURVEY.md
-§8d divided by the kernel's average duration measured with HIP events on the library's own stream) and
-`cpu_baseline` (the compiled reference — oracle/_ref/libduckdb.so — or, if absent, the C oracle,
-timed on this box's host cores on a bounded sample of the same workload).
+Prints ONE JSON line on rank 0 (contract in the task statement):
+  roofline           the kernel with the largest total time in the timed region.  HBM-bound kernels (the CSR
+                     build): algorithmic bytes per launch / average launch time / 8 TB/s.  The 2-hop
+                     product kernel moves 0.6 GB for 12.8 G walks and is bound by vector-ALU issue, so its record is
+                     {"bound": "valu"}: one v_xad_u32 per walk against the measured issue rate of that instruction
+                     (scripts/ubench_valu.hip).  No record ever divides bytes that are not moved by the HBM peak.
+  roofline_kernels   the same record for every kernel of the step that is charged algorithmic work
+  roofline_phases    csr_build (all build kernels, HBM) and expand (VALU)
+  cpu_baseline       the compiled reference (oracle/_ref/libduckdb.so; else the C oracle) on this box's host cores,
+                     benchmark_runner protocol (1 cold + 5 hot runs, median hot: benchmark/benchmark_runner.cpp:132-147)
+                     on a bounded sample, plus a threads=1 figure and the CPU model
+  materialised, bfs64, connectedsegments   the other BASELINE.json configs on this GPU, each with its own parity
+                     boolean (N = 1 only; --no-extras skips them)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,18 +43,33 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+# v_xad_u32 (xor + add, one per walk in k_expand_mid2) issues once per 4.9 cycles per wave on gfx950
+# (scripts/ubench_valu.hip): 256 CUs x 4 SIMDs x 64 lanes x 2.4e9 / 4.9 lane-ops per second
+VALU_XAD_PEAK = 256 * 4 * 64 * 2.4e9 / 4.9
 MASK64 = (1 << 64) - 1
+PROFILE_TAG = "r02"
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(vid, src, dst, V, want_seconds=15.0, with_reference=True):
-    """Timed CPU path on a bounded sample (sources = first S vertices in table order).
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    kind "reference": the compiled reference runs the 1-hop and 2-hop join chains (count(*)) with all
-    host threads; its counts are also checked against the GPU's counts for the same source range.
+
+def cpu_baseline(vid, src, dst, V, want_seconds=6.0, with_reference=True):
+    """Timed CPU path on a bounded sample (first-hop edges = the first S rows of knows).
+
+    kind "reference": the compiled reference runs the 1-hop and 2-hop join chains (count(*)) with all host
+    threads, 1 cold + 5 hot runs, median of the hot runs (benchmark/benchmark_runner.cpp:132-147); its counts are
+    checked against the oracle's for the same rows.  Also one threads=1 figure on a smaller sample.
     kind "port": the C oracle's CSR formulation (OpenMP), when oracle/_ref is not present."""
     from oracle import ref_duckdb as R
     from tests import oracle_lib
@@ -61,23 +86,16 @@ def cpu_baseline(vid, src, dst, V, want_seconds=15.0, with_reference=True):
     ost = g.khop(1, 2)
     t_khop = time.perf_counter() - t
     port = {"value": ost["traversed_edges"] / (t_build + t_khop), "unit": "traversed edges/s",
-            "cores": orc.num_threads(), "kind": "port",
-            "sample": f"full workload: CSR build {t_build:.2f}s (1 thread) + 1..2-hop count/digest {t_khop:.2f}s (OpenMP)"}
+            "cores": orc.num_threads(), "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"full workload: CSR build {t_build:.2f}s (<=32 threads) + 1..2-hop count/digest {t_khop:.2f}s (OpenMP)"}
     out["oracle_stats"] = ost
+    out["oracle_graph"] = g
     oracle_off = g.arrays()[0]
-    g.close()
     if not with_reference:  # N > 1: only the parity check of the combined result; the baseline is an N = 1 figure
         return out
     if not R.available():
         out["cpu_baseline"] = port
         return out
-    # -- the compiled reference on a bounded sample: the first S rows of `knows` as first-hop edges
-    #    (a filter on k1.rowid is pushed into the scan, so the sample really bounds the join work; a filter
-    #    on the source persons does not — the optimizer still joins knows x knows first)
-    db = R.RefDuckDB(threads=cores)
-    t = time.perf_counter()
-    db.load_ldbc(vid, src, dst)
-    t_load = time.perf_counter() - t
     order = np.argsort(vid, kind="stable")
     svid = vid[order]
 
@@ -95,30 +113,194 @@ def cpu_baseline(vid, src, dst, V, want_seconds=15.0, with_reference=True):
         ok = (u >= 0) & (v >= 0)
         return int(ok.sum()), int(deg[v[ok]].sum())
 
-    def run(S):
-        c1, t1 = db.timed(R.sql_khop(1, where_extra=f"k1.rowid < {S}"))
-        c2, t2 = db.timed(R.sql_khop(2, where_extra=f"k1.rowid < {S}"))
-        return int(c1[0, 0]), int(c2[0, 0]), t1 + t2
+    db = R.RefDuckDB(threads=cores)
+    t0 = time.perf_counter()
+    db.load_ldbc(vid, src, dst)
+    t_load = time.perf_counter() - t0
 
-    # two calibration points -> fixed cost (hash-table builds over all of knows) + slope
-    S1, S2 = max(1, E // 512), max(2, E // 128)
-    _, _, ta = run(S1)
-    _, _, tb = run(S2)
-    slope = max((tb - ta) / (S2 - S1), 1e-9)
-    fixed = max(ta - slope * S1, 0.0)
-    S = int(min(E, max(S2, (want_seconds - fixed) / slope))) if want_seconds > fixed else S2
-    c1, c2, tt = run(S)
+    def leg(threads, seconds, hot_runs=5, calibrate=True):
+        """(sample rows S, counts, [cold, hot...] seconds, fixed seconds) at `threads`."""
+        db.execute(f"PRAGMA threads={threads}")
+
+        def run(S):  # a filter on k1.rowid is pushed into the scan, so the sample really bounds the join work
+            c1, t1 = db.timed(R.sql_khop(1, where_extra=f"k1.rowid < {S}"))
+            c2, t2 = db.timed(R.sql_khop(2, where_extra=f"k1.rowid < {S}"))
+            return int(c1[0, 0]), int(c2[0, 0]), t1 + t2
+
+        # two calibration points -> fixed cost (hash-table builds over all of knows) + slope
+        S1, S2 = max(1, E // 512), max(2, E // 128)
+        if calibrate:
+            _, _, ta = run(S1)
+            _, _, tb = run(S2)
+            slope = max((tb - ta) / (S2 - S1), 1e-9)
+            fixed = max(ta - slope * S1, 0.0)
+            S = int(min(E, max(S2, (seconds - fixed) / slope))) if seconds > fixed else S2
+        else:  # one thread: the hash-table builds over all of knows alone take seconds per run; keep the sample small
+            S, fixed = S1, float("nan")
+        times, counts = [], None
+        for _ in range(1 + hot_runs):  # the first run at this sample size is the cold one
+            c1, c2, tt = run(S)
+            times.append(tt)
+            counts = (c1, c2)
+        return S, counts, times, fixed, t_load
+
+    S, (c1, c2), times, fixed, t_load = leg(cores, want_seconds)
     r1, r2 = sample_counts(S)
+    hot = statistics.median(times[1:])
+    S1t, (d1, d2), times1, fixed1, _ = leg(1, want_seconds, hot_runs=2, calibrate=False)
     db.close()
+    q1, q2 = sample_counts(S1t)
+    hot1 = statistics.median(times1[1:])
     out["cpu_baseline"] = {
-        "value": (r1 + r2) / tt, "unit": "traversed edges/s", "cores": cores, "kind": "reference",
+        "value": (r1 + r2) / hot, "unit": "traversed edges/s", "cores": cores, "kind": "reference",
+        "cpu_model": cpu_model(),
+        "protocol": "1 cold + 5 hot runs, median of the hot runs (benchmark/benchmark_runner.cpp:132-147)",
+        "cold_s": times[0], "hot_s": times[1:], "median_hot_s": hot,
         "sample": (f"reference DuckDB (oracle/_ref/libduckdb.so, PRAGMA threads={cores}) count(*) of the 1-hop and 2-hop "
-                   f"join chains restricted to the first {S} of {E} knows rows as first-hop edges: TE={r1 + r2} in {tt:.2f}s "
+                   f"join chains restricted to the first {S} of {E} knows rows as first-hop edges: TE={r1 + r2} per run "
                    f"(its hash-table builds over all knows rows included, ~{fixed:.1f}s; table load {t_load:.1f}s excluded)"),
         "counts_match_oracle": bool(c1 == r1 and c2 == r2),
+        "threads_1": {"value": (q1 + q2) / hot1, "unit": "traversed edges/s", "cores": 1, "median_hot_s": hot1,
+                      "cold_s": times1[0],
+                      "hot_s": times1[1:],
+                      "sample": f"same statements, PRAGMA threads=1, first {S1t} knows rows as first-hop edges: TE={q1 + q2} per "
+                                f"run, 1 cold + 2 hot runs (the hash-table builds over all knows rows dominate a run)",
+                      "counts_match_oracle": bool(d1 == q1 and d2 == q2)},
     }
     out["cpu_port"] = port
     return out
+
+
+# ---- the other BASELINE.json configs (N = 1, after the timed region) --------------------------------------------
+def extra_bfs64(pkg, gg, csr, vid, oracle_graph, batches=16):
+    """configs[2]: SF100 shortest_path, 64-source bitset BFS to fixpoint, 16 batches on the benchmark's CSR."""
+    srcs = [pkg.datagen.pick_sources(vid, 64, 0x5EED, batch=b) for b in range(batches)]
+    gg.bfs64(csr, srcs[0], -1, fetch=False)  # warm-up
+    gg.profile_reset()
+    gg.profile_select(None)
+    gg.profile(True)
+    t0 = time.perf_counter()
+    te = act = lv = 0
+    for b in srcs:
+        _, st = gg.bfs64(csr, b, -1, fetch=False)
+        te += st["traversed_edges"]
+        act += st["active_vertices"]
+        lv += st["levels"]
+    dt = time.perf_counter() - t0
+    gg.profile(False)
+    prof = gg.profile_get()
+    kern_ms = sum(v[1] for k, v in prof.items() if k.startswith("bfs_"))
+    V = csr.V
+    alg = 8 * V * lv + 16 * act + 24 * te + 24 * V * lv  # SURVEY.md §8d per-level formula summed over the levels
+    out = {"workload": "LDBC SNB SF100 shortest_path(Person, Person): 64-source bitset BFS to fixpoint",
+           "batches": batches, "wall_ms_per_batch": dt / batches * 1e3, "kernel_ms_per_batch": kern_ms / batches,
+           "levels_per_batch": lv / batches, "value": te / dt, "unit": "traversed edges/s",
+           "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": alg / (kern_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                        "note": "per-level algorithmic bytes 8V + 16Va + 24TE + 24V over the BFS kernels' time"},
+           "kernels_us_per_batch": {k: v[1] * 1e3 / batches for k, v in prof.items() if k.startswith("bfs_")}}
+    if oracle_graph is not None:
+        t0 = time.perf_counter()
+        d, ost = oracle_graph.bfs64(oracle_graph.lookup(srcs[0]), -1)
+        cdt = time.perf_counter() - t0
+        dist, gst = gg.bfs64(csr, srcs[0], -1)
+        out["parity"] = bool(np.array_equal(d, dist) and ost == gst)
+        out["cpu_port"] = {"value": ost["traversed_edges"] / cdt, "unit": "traversed edges/s", "cores": 1,
+                           "sample": f"one 64-source batch, C oracle bitset BFS, {cdt:.2f}s"}
+    return out
+
+
+def extra_materialised(pkg, orc, device):
+    """configs[1]: SF10 Person-KNOWS*2..2-Person with the rows written to HBM as int64 id columns."""
+    vid, src, dst = pkg.datagen.ldbc("sf10")
+    gg = pkg.GG(device)
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    csr = gg.build_csr()
+    gg.expand_khop_result(csr, 2).close()  # warm-up (allocations)
+    gg.profile_reset()
+    gg.profile_select(None)
+    gg.profile(True)
+    t0 = time.perf_counter()
+    res = gg.expand_khop_result(csr, 2)
+    dt = time.perf_counter() - t0
+    gg.profile(False)
+    prof = gg.profile_get()
+    rows = res.rows(2)
+    written = rows * 24
+    k = prof.get("mat_last", (0, 0.0))
+    out = {"workload": "LDBC SNB SF10 Person-KNOWS-Person-KNOWS-Person, all persons as sources, rows materialised in HBM "
+                       "(3 int64 id columns)",
+           "rows": rows, "bytes_written": written, "wall_ms": dt * 1e3,
+           "kernels_ms": {n: v[1] for n, v in prof.items() if v[1] > 0.02}}
+    if k[0]:
+        out["roofline"] = {"bound": "hbm", "kernel": "mat_last", "achieved": written / (k[1] * 1e-3) / 1e9,
+                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": written / (k[1] * 1e-3) / HBM_PEAK,
+                           "traffic": None, "avg_launch_ms": k[1] / k[0],
+                           "note": "bytes actually written by the kernel (rows x 3 x 8) over its time"}
+    # parity: row count against the oracle's join count; sampled 1024-row slices must be walks of the graph
+    rc, g = orc.csr_build(vid, src, dst)
+    ost = g.khop(2, 2)
+    off, nbr, _, ovid = g.arrays()
+    ok = rows == ost["rows"][2]
+    order = np.argsort(ovid, kind="stable")
+    sv = ovid[order]
+    for o in np.linspace(0, max(rows - 1024, 0), 9).astype(np.int64):
+        sl = res.fetch(2, int(o))
+        d = order[np.searchsorted(sv, sl)]  # dense indices of the three columns
+        for a, b in ((0, 1), (1, 2)):
+            for u, v in zip(d[::97, a], d[::97, b]):
+                ok = ok and bool(np.any(nbr[off[u]:off[u + 1]] == v))
+    out["parity"] = bool(ok)
+    out["parity_note"] = "row count == oracle join count; every 97th row of 9 sampled 1024-row slices is a walk of the oracle's CSR"
+    res.close()
+    g.close()
+    csr.close()
+    gg.close()
+    return out
+
+
+def extra_connectedsegments(pkg, device, copies=1024, steps=10):
+    """configs[4]: Train Benchmark ConnectedSegments at SF1024: both CSR builds + 5-hop walks + same-sensor filter."""
+    from duckdb_pgq_amd import datagen
+    from tests import trainbenchmark as tb
+
+    t = tb.tables()
+    base = {"te": tb.load("TrackElement")[:, 0], "sensors": tb.load("Sensor")[:, 0], "seg": t["Segment"][:, 0],
+            "ct": t["connectsTo"], "mb": t["monitoredBy"]}
+    r = datagen.replicate_tables(base, copies)
+    gg = pkg.GG(device)
+    gg.set_edge_rowid(False)
+    vertices = np.concatenate([r["te"], r["sensors"]])
+
+    def step():
+        gg.staging_clear()
+        gg.append_vertices(vertices)
+        gg.append_edges(r["ct"][:, 0], r["ct"][:, 1])
+        path_csr = gg.build_csr()
+        gg.staging_clear_edges()
+        gg.append_edges(r["mb"][:, 0], r["mb"][:, 1])
+        filter_csr = gg.build_csr()
+        rows = gg.connected_paths_same_neighbour(path_csr, filter_csr, 5, sources=r["seg"])
+        path_csr.close()
+        filter_csr.close()
+        return rows
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rows = step()
+    dt = time.perf_counter() - t0
+    shift = np.arange(copies, dtype=np.int64) * r["_stride"]
+    want = (tb.CONNECTEDSEGMENTS_GOLDEN[None, :, :] + shift[:, None, None]).reshape(-1, 7)
+    key = lambda a: a[np.lexsort(a.T[::-1])]  # noqa: E731
+    ok = bool(rows.shape == want.shape and np.array_equal(key(rows), key(want)))
+    gg.close()
+    return {"workload": f"Train Benchmark ConnectedSegments SF{copies} (the reference's SF1 tables x{copies}, shifted ids): "
+                        "staging + 2 CSR builds + 5-hop walks + same-sensor filter per step",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "result_rows": int(rows.shape[0]),
+            "connectsTo_rows": int(r["ct"].shape[0]), "monitoredBy_rows": int(r["mb"].shape[0]), "parity": ok,
+            "parity_note": "result == the reference's four golden rows (connectedsegments.benchmark:34-38), shifted per copy"}
 
 
 def main():
@@ -128,7 +310,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sf100", choices=["sf0.1", "sf1", "sf10", "sf100"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the materialised / bfs64 / connectedsegments sections")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="target seconds per reference run (6 + 2 runs per leg)")
+    ap.add_argument("--legacy-build", action="store_true", help="diagnostic: the multi-pass LSD build")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="diagnostic: time rank 0's share of an N-rank run on one GPU (output is not a bench line)")
     args = ap.parse_args()
@@ -179,6 +363,8 @@ def main():
     gg = pkg.GG(device_index)
     # the benchmarked MATCH binds no edge variable: like the reference's build side, carry only the key columns
     gg.set_edge_rowid(False)
+    if args.legacy_build:
+        gg.force_legacy_build(True)
     t0 = time.perf_counter()
     gg.chunk_rows = 122_880  # one DuckDB row group per append (storage/table/row_group.hpp:38-39)
     gg.append_vertices(vid)
@@ -203,12 +389,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP events around a launch are not free (two records per launch: ~0.3 ms of a 3.9 ms step when all
-    # ~35 launches of a step are timed), so the timed region times only the kernels the roofline can name;
-    # the per-kernel table of everything else comes from a few extra, untimed steps afterwards.
-    ROOFLINE_KERNELS = ["densify_hist", "densify_shard", "radix_scatter", "expand_mid2", "expand_fused2"]
+    # HIP events around a launch are not free (two records per launch: ~0.3 ms of a step when all ~25 launches
+    # are timed), so the timed region times only the kernels the roofline can name; the per-kernel table of
+    # everything else comes from a few extra, untimed steps afterwards.
+    BUILD_KERNELS = ["densify_pairs", "partition_dual", "sub_sort", "leaf_rows",     # bucketed build
+                     "densify_hist", "densify_shard", "radix_scatter"]                # multi-pass build (shards, > 2^22 vertices)
+    EXPAND_KERNELS = ["expand_mid2", "expand_fused2"]
     gg.profile_reset()
-    gg.profile_select(ROOFLINE_KERNELS)
+    gg.profile_select(BUILD_KERNELS + EXPAND_KERNELS)
     gg.profile(True)
     torch.cuda.synchronize()
     barrier()
@@ -239,21 +427,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = te_total * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel on this rank ---------------------------------------------------
-    # dominant kernel = largest total time in the timed region; algorithmic bytes per launch:
-    # SURVEY.md §8d's figures — expansion 8*TE + 16*frontier entries; densification 32E + 8V; CSR scatter
-    # 16E read + 8E write = 24E per CSR, which our LSD sort spreads over 3 passes (x2 CSRs = 6 launches),
-    # so one radix_scatter launch is charged 8E: the multi-pass overhead shows up as a low fraction.
+    # ---- rooflines -------------------------------------------------------------------------------------------------
+    # HBM-bound kernels, algorithmic bytes per launch: densification 32E + 8V; one CSR
+    # without rowid 32E + 16V, which the bucketed build spreads over three kernels (partition, sub-bucket sort, rows)
+    # and the multi-pass build over three scatter passes — each launch is charged a third (the reverse CSR the product
+    # kernel needs is built by the same launches and is NOT in the algorithmic count).
+    # VALU-bound kernel: the 2-hop product kernel performs one v_xad_u32 per 2-hop walk.
     te_l, fr_l = st_local["traversed_edges"], st_local["frontier_entries"]
-    alg = {
-        "expand_mid2": 8 * te_l + 16 * fr_l,
-        "expand_fused2": 8 * te_l + 16 * fr_l,
-        "densify_hist": 32 * R_local + 8 * V,
-        "densify_shard": 32 * R_local + 8 * V,
-        "radix_scatter": 8 * R_local,
-    }
-    dom = max((k for k in prof if k in alg), key=lambda k: prof[k][1], default=None)
-    launches, total_ms = prof.get(dom, (0, 0.0)) if dom else (0, 0.0)
+    walks2_l = st_local["rows"][2]
+    csr_bytes = 32 * R_local + 16 * V
+    alg_hbm = {"densify_pairs": 32 * R_local + 8 * V, "densify_hist": 32 * R_local + 8 * V,
+               "densify_shard": 32 * R_local + 8 * V, "partition_dual": csr_bytes / 3, "sub_sort": csr_bytes / 3,
+               "leaf_rows": csr_bytes / 3, "radix_scatter": 8 * R_local}
     traffic_tab = {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -261,40 +446,49 @@ def main():
             traffic_tab = json.load(open(tpath))
         except Exception:
             traffic_tab = {}
-    roof = None
-    if launches:
+    traffic_src = traffic_tab.get("_source", "profiles/pmc_traffic.json") + " (rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
+
+    def record(name):
+        launches, total_ms = prof.get(name, (0, 0.0))
+        if not launches:
+            return None
         avg_s = total_ms / launches * 1e-3
-        achieved = alg[dom] / avg_s
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic_tab.get(f"{args.workload}/{dom}/n{world}"),
+        tr = traffic_tab.get(f"{args.workload}/{name}/n{world}")
+        if name in EXPAND_KERNELS:
+            ops = walks2_l
+            return {"bound": "valu", "kernel": name, "achieved": ops / avg_s / 1e9, "peak": VALU_XAD_PEAK / 1e9,
+                    "unit": "Gop/s", "frac": ops / avg_s / VALU_XAD_PEAK, "traffic": tr, "traffic_source": traffic_src if tr else None,
+                    "avg_launch_ms": avg_s * 1e3, "launches_per_step": launches / args.steps, "ops_per_launch": int(ops),
+                    "note": "one v_xad_u32 per 2-hop walk; peak = measured issue rate of that instruction (scripts/ubench_valu.hip); "
+                            "the kernel reads each CSR row once (traffic), so an HBM fraction would not describe it"}
+        a = alg_hbm[name]
+        return {"bound": "hbm", "kernel": name, "achieved": a / avg_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": a / avg_s / HBM_PEAK, "traffic": tr, "traffic_source": traffic_src if tr else None,
                 "avg_launch_ms": avg_s * 1e3, "launches_per_step": launches / args.steps,
-                "algorithmic_bytes_per_launch": alg[dom]}
-    # the same figure per phase of the step (all kernels of the phase together)
-    # phase totals: the timed region's figure where a kernel was timed there, the untimed pass's otherwise
+                "algorithmic_bytes_per_launch": int(a)}
+
+    recs = {k: record(k) for k in prof}
+    recs = {k: v for k, v in recs.items() if v}
+    dom = max(recs, key=lambda k: prof[k][1], default=None)
+    roof = recs.get(dom)
+    # phases: the timed region's figure where a kernel was timed there, the untimed pass's otherwise
     per_step_ms = {k: v[1] / TABLE_STEPS for k, v in prof_all.items()}
     per_step_ms.update({k: v[1] / args.steps for k, v in prof.items()})
     expand_names = {"expand_mid2", "expand_fused2", "reduce_partials", "tile_partition"}
     t_expand = sum(ms for k, ms in per_step_ms.items() if k in expand_names) * 1e-3
     t_build = sum(ms for k, ms in per_step_ms.items() if k not in expand_names) * 1e-3
-    alg_build = (32 * R_local + 8 * V) + (32 * R_local + 16 * V)  # densification + one CSR without rowid
+    alg_build = (32 * R_local + 8 * V) + csr_bytes  # densification + one CSR without rowid
     phases = {}
     if t_build > 0:
-        phases["csr_build"] = {"kernel_ms": t_build * 1e3, "algorithmic_bytes": alg_build,
-                               "achieved": alg_build / t_build / 1e9, "frac": alg_build / t_build / HBM_PEAK,
-                               "note": "our build also makes the reverse CSR the product kernel needs; it is not in the algorithmic count"}
+        phases["csr_build"] = {"bound": "hbm", "kernel_ms": t_build * 1e3, "algorithmic_bytes": alg_build,
+                               "achieved": alg_build / t_build / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": alg_build / t_build / HBM_PEAK,
+                               "note": "all build kernels; the build also makes the reverse CSR, which is not in the algorithmic count"}
     if t_expand > 0:
-        a = 8 * te_l + 16 * fr_l
-        phases["expand"] = {"kernel_ms": t_expand * 1e3, "algorithmic_bytes": a, "achieved": a / t_expand / 1e9,
-                            "frac": a / t_expand / HBM_PEAK,
-                            "traffic": traffic_tab.get(f"{args.workload}/expand_mid2/n{world}"),
-                            "note": "above 1: the product kernel reads each CSR row once and is VALU-bound (DESIGN.md §4.3)"}
-    # the whole step against the same ceiling: SURVEY.md §8d's algorithmic bytes of build + expansion over the
-    # measured step time (north_star's target is stated on this workload: >= 50 % of the HBM roofline)
-    a_step = alg_build + 8 * te_l + 16 * fr_l
-    phases["whole_step"] = {"step_ms": ms_per_step, "algorithmic_bytes": a_step,
-                            "achieved": a_step / (ms_per_step * 1e-3) / 1e9,
-                            "frac": a_step / (ms_per_step * 1e-3) / HBM_PEAK,
-                            "note": "dominated by the expansion's 8 bytes per traversed edge; see roofline_phases.expand"}
+        phases["expand"] = {"bound": "valu", "kernel_ms": t_expand * 1e3, "ops": int(walks2_l),
+                            "achieved": walks2_l / t_expand / 1e9, "peak": VALU_XAD_PEAK / 1e9, "unit": "Gop/s",
+                            "frac": walks2_l / t_expand / VALU_XAD_PEAK,
+                            "traffic": traffic_tab.get(f"{args.workload}/expand_mid2/n{world}")}
     kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
                    "us_per_step": v[1] * 1e3 / TABLE_STEPS, "timed_region": False} for k, v in prof_all.items()}
     kernels.update({k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
@@ -303,18 +497,39 @@ def main():
     if args.shard_of > 1:
         log(f"shard 0 of {args.shard_of}: {ms_per_step:.3f} ms/step; kernels us/step:",
             {k: round(v["us_per_step"]) for k, v in kernels.items()})
+        print(json.dumps({"diagnostic": f"shard 0 of {args.shard_of}", "ms_per_step": ms_per_step,
+                          "kernels_us_per_step": {k: v["us_per_step"] for k, v in kernels.items()}}), flush=True)
         gg.close()
         return
     if rank == 0:
         extra = {}
+        oracle_graph = None
         if not args.no_cpu:
             extra = cpu_baseline(vid, src_all, dst_all, V, args.cpu_seconds, with_reference=(world == 1))
             ost = extra.pop("oracle_stats")
+            oracle_graph = extra.pop("oracle_graph")
             parity = (ost["rows"][1] == rows1 and ost["rows"][2] == rows2 and ost["digest"][1] == dig1
                       and ost["digest"][2] == dig2 and ost["traversed_edges"] == te_total)
             extra["parity_vs_oracle"] = bool(parity)
             if not parity:
                 log("PARITY FAILURE", ost, tot)
+        if world == 1 and not args.no_extras:
+            try:
+                if args.workload == "sf100":
+                    c = gg.build_csr()
+                    extra["bfs64"] = extra_bfs64(pkg, gg, c, vid, oracle_graph)
+                    c.close()
+                if oracle_graph is not None:
+                    oracle_graph.close()
+                    oracle_graph = None
+                from tests import oracle_lib
+
+                extra["materialised"] = extra_materialised(pkg, oracle_lib.load(), device_index)
+                extra["connectedsegments"] = extra_connectedsegments(pkg, device_index)
+            except Exception as e:  # an extra section must not cost the headline line
+                extra["extras_error"] = repr(e)
+        if oracle_graph is not None:
+            oracle_graph.close()
         line = {
             "metric": "traversed edges/sec on LDBC SNB 2-hop MATCH",
             "value": value,
@@ -332,6 +547,7 @@ def main():
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
                        "traversed_edges": int(te_total), "parallelism": f"vertex-ownership shards x{world} (edge table hash-partitioned by endpoint owner, vertex table replicated, CSR + expansion sharded, no data-path collective)"},
             "roofline": roof,
+            "roofline_kernels": recs,
             "roofline_phases": phases,
             "kernels": kernels,
             "staging_ms_pcie": t_stage * 1e3,

@@ -185,6 +185,30 @@ class ShardedBfs:
             self.handle = None
 
 
+class KhopResult:
+    """Materialised walks left in HBM (gg_expand_khop_result): row counts and <=1024-row slices on demand."""
+
+    def __init__(self, gg: "GG", handle, stats):
+        self.gg, self.handle, self.stats = gg, handle, stats
+
+    def rows(self, h: int) -> int:
+        n = C.c_uint64()
+        self.gg._chk(self.gg.lib.gg_result_rows(self.handle, h, C.byref(n)))
+        return int(n.value)
+
+    def fetch(self, h: int, offset: int, max_rows: int = GG_CHUNK_ROWS) -> np.ndarray:
+        bufs = [np.empty(GG_CHUNK_ROWS, np.int64) for _ in range(h + 1)]
+        ptrs = (C.POINTER(C.c_int64) * (h + 1))(*[b.ctypes.data_as(C.POINTER(C.c_int64)) for b in bufs])
+        got = C.c_uint32()
+        self.gg._chk(self.gg.lib.gg_result_fetch(self.handle, h, offset, min(max_rows, GG_CHUNK_ROWS), ptrs, C.byref(got)))
+        return np.stack([b[: got.value] for b in bufs], axis=1)
+
+    def close(self):
+        if self.handle:
+            self.gg.lib.gg_result_destroy(self.handle)
+            self.handle = None
+
+
 class Csr:
     def __init__(self, gg: "GG", handle):
         self.gg, self.handle = gg, handle
@@ -319,6 +343,18 @@ class GG:
         if materialise:
             d["tables"] = self._collect(res, k_min, k_max)
         return d
+
+    def expand_khop_result(self, csr: Csr, k: int, sources=None) -> KhopResult:
+        """k-hop walks from `sources` (None: all vertices) materialised in HBM; nothing crosses PCIe."""
+        st = KhopStats()
+        res = C.c_void_p()
+        if sources is None:
+            sp, ns = None, 0
+        else:
+            a, sp = _i64(sources)
+            ns = a.size
+        self._chk(self.lib.gg_expand_khop_result(self.ctx, csr.handle, sp, ns, k, k, C.byref(st), C.byref(res)))
+        return KhopResult(self, res, self._stats_dict(st))
 
     def staging_clear_edges(self):
         self._chk(self.lib.gg_staging_clear_edges(self.ctx))

@@ -476,33 +476,74 @@ int orc_csr_build(orc_csr *g, const int64_t *vid, uint64_t V, const int64_t *esr
   uint32_t *dv = (uint32_t *)malloc((size_t)(E ? E : 1) * sizeof(uint32_t));
   g->off = (int64_t *)calloc((size_t)V + 2, sizeof(int64_t));
   if (!su || !dv || !g->off) return -3;
+  /* The lookups and the counting sort run on up to 32 threads, each owning a contiguous chunk of the edge rows;
+   * per-thread degree counts turn into per-thread start positions, so the placement is the same stable one
+   * (ascending edge position within a row) whatever the thread count. */
+  int T = 1;
+#ifdef _OPENMP
+  T = omp_get_max_threads();
+  if (T > 32) T = 32;
+  if (T < 1) T = 1;
+  if (E < 100000) T = 1;
+#endif
+  int64_t *h = (int64_t *)calloc((size_t)T * (size_t)(V + 1), sizeof(int64_t));
+  if (!h) return -3;
   uint64_t kept = 0;
-  for (uint64_t e = 0; e < E; e++) {
-    int64_t u = orc_csr_lookup(g, esrc[e]), v = orc_csr_lookup(g, edst[e]);
-    if (u < 0 || v < 0) {
-      su[e] = 0xFFFFFFFFu;
-      continue;
+#pragma omp parallel num_threads(T) reduction(+ : kept)
+  {
+    int t = 0;
+#ifdef _OPENMP
+    t = omp_get_thread_num();
+#endif
+    const uint64_t e0 = E * (uint64_t)t / (uint64_t)T, e1 = E * (uint64_t)(t + 1) / (uint64_t)T;
+    int64_t *ht = h + (size_t)t * (size_t)(V + 1);
+    for (uint64_t e = e0; e < e1; e++) {
+      int64_t u = orc_csr_lookup(g, esrc[e]), v = orc_csr_lookup(g, edst[e]);
+      if (u < 0 || v < 0) {
+        su[e] = 0xFFFFFFFFu;
+        continue;
+      }
+      su[e] = (uint32_t)u;
+      dv[e] = (uint32_t)v;
+      ht[u]++;
+      kept++;
     }
-    su[e] = (uint32_t)u;
-    dv[e] = (uint32_t)v;
-    g->off[u + 1]++;
-    kept++;
   }
   g->E = kept;
   g->dropped = E - kept;
-  for (uint64_t u = 0; u < V; u++) g->off[u + 1] += g->off[u];
+  for (uint64_t u = 0; u < V; u++) {
+    int64_t d = 0;
+    for (int t = 0; t < T; t++) d += h[(size_t)t * (size_t)(V + 1) + u];
+    g->off[u + 1] = g->off[u] + d;
+  }
   g->nbr = (uint32_t *)malloc((size_t)(kept ? kept : 1) * sizeof(uint32_t));
   g->eid = (int64_t *)malloc((size_t)(kept ? kept : 1) * sizeof(int64_t));
-  int64_t *cur = (int64_t *)malloc((size_t)(V + 1) * sizeof(int64_t));
-  if (!g->nbr || !g->eid || !cur) return -3;
-  memcpy(cur, g->off, (size_t)(V + 1) * sizeof(int64_t));
-  for (uint64_t e = 0; e < E; e++) { /* stable: ascending edge position within a row */
-    if (su[e] == 0xFFFFFFFFu) continue;
-    int64_t p = cur[su[e]]++;
-    g->nbr[p] = dv[e];
-    g->eid[p] = rowid ? rowid[e] : (int64_t)e;
+  if (!g->nbr || !g->eid) return -3;
+#pragma omp parallel for num_threads(T) schedule(static)
+  for (uint64_t u = 0; u < V; u++) { /* per-thread counts -> per-thread first positions */
+    int64_t run = g->off[u];
+    for (int t = 0; t < T; t++) {
+      int64_t c = h[(size_t)t * (size_t)(V + 1) + u];
+      h[(size_t)t * (size_t)(V + 1) + u] = run;
+      run += c;
+    }
   }
-  free(cur);
+#pragma omp parallel num_threads(T)
+  {
+    int t = 0;
+#ifdef _OPENMP
+    t = omp_get_thread_num();
+#endif
+    const uint64_t e0 = E * (uint64_t)t / (uint64_t)T, e1 = E * (uint64_t)(t + 1) / (uint64_t)T;
+    int64_t *cur = h + (size_t)t * (size_t)(V + 1);
+    for (uint64_t e = e0; e < e1; e++) { /* stable: ascending edge position within a row */
+      if (su[e] == 0xFFFFFFFFu) continue;
+      int64_t p = cur[su[e]]++;
+      g->nbr[p] = dv[e];
+      g->eid[p] = rowid ? rowid[e] : (int64_t)e;
+    }
+  }
+  free(h);
   free(su);
   free(dv);
   return 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Copy the judged summaries out of gpurun_out/ into profiles/ (tracked):
-   summarize_profiles.py <tag>   expects gpurun_out/prof_<tag>, pmc_fetch_<tag>, pmc_write_<tag> (rocprofv3 csv output)"""
+   summarize_profiles.py <tag> [round]   expects gpurun_out/prof_<tag>, pmc_fetch_<tag>, pmc_write_<tag> (rocprofv3 csv output)"""
 import collections
 import csv
 import glob
@@ -11,10 +11,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out = os.path.join(ROOT, "profiles")
 ks = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*", "*kernel_stats.csv"))
 if ks:
-    shutil.copy(ks[0], os.path.join(out, f"r01_{tag}_sf100_kernel_stats.csv"))
+    shutil.copy(ks[0], os.path.join(out, f"{rnd}_{tag}_sf100_kernel_stats.csv"))
 res = {}
 lines = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --no-cpu (SF100, 1 MI355X)",
          "# raw counter values are KB per dispatch (avg over dispatches); gfx950: FETCH_SIZE under-reports wide coalesced streams by 2x (MI355X_MICROARCH.md HBM section)"]
@@ -29,11 +30,12 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in d.items():
         lines.append("  %-70s n=%3d avg=%14.1f KB" % (k, len(v), sum(v) / len(v)))
         res.setdefault(k, {})[name] = sum(v) / len(v)
-open(os.path.join(out, f"r01_{tag}_sf100_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
-traffic = {"_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, "
-           f"profiles/r01_{tag}_sf100_pmc_summary.txt): (2*FETCH_SIZE + WRITE_SIZE) * 1024; the factor 2 on FETCH_SIZE is the "
+open(os.path.join(out, f"{rnd}_{tag}_sf100_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+traffic = {"_source": f"profiles/{rnd}_{tag}_sf100_pmc_summary.txt", "_note": "HBM-side bytes per launch from rocprofv3 PMC (separate FETCH_SIZE / WRITE_SIZE passes, "
+           f"profiles/{rnd}_{tag}_sf100_pmc_summary.txt): (2*FETCH_SIZE + WRITE_SIZE) * 1024; the factor 2 on FETCH_SIZE is the "
            "gfx950 correction of MI355X_MICROARCH.md (upper bound for our 4-byte-per-lane coalesced loads)"}
-short = {"k_expand_mid2": "expand_mid2", "k_densify_hist": "densify_hist", "k_radix_scatter": "radix_scatter"}
+short = {"k_expand_mid2": "expand_mid2", "k_densify_hist": "densify_hist", "k_radix_scatter": "radix_scatter",
+         "k_densify_pairs": "densify_pairs", "k_partition_dual": "partition_dual", "k_sub_sort": "sub_sort", "k_leaf_rows": "leaf_rows"}
 acc = collections.defaultdict(list)
 for k, v in res.items():
     n = k.split("::")[-1].split("<")[0]

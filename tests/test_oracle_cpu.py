@@ -119,3 +119,27 @@ def test_recursive_cte_restatement_on_the_references_own_vectors(orc):
     # a cycle 1 -> 2 -> 3 -> 1 terminates by dedupe too and keeps the shortest hop of every vertex
     cyc = orc.cte_shortest(vid[:3], vid[:3], np.roll(vid[:3], -1), np.array([2], np.int64), 50)
     assert sort_rows(cyc).tolist() == [[2, 1, 2], [2, 2, 0], [2, 3, 1]]
+
+
+def test_threaded_csr_build_of_the_oracle_is_the_stable_counting_sort(orc):
+    """orc_csr_build splits the edge rows over threads above 100 000 rows; the CSR must still be the stable
+    counting sort by source (ascending edge position inside a row), here re-derived with numpy."""
+    import numpy as np
+
+    from duckdb_pgq_amd import datagen
+
+    vid, src, dst = datagen.ldbc_knows(5000, 400_000, 17)
+    src[::97] = -5  # dangling rows are dropped
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    off, nbr, eid, v2 = g.arrays()
+    order = np.argsort(vid, kind="stable")
+    pos = np.searchsorted(vid[order], src)
+    ok = (pos < vid.size) & (vid[order][np.minimum(pos, vid.size - 1)] == src)
+    u = order[np.minimum(pos, vid.size - 1)][ok]
+    v = order[np.searchsorted(vid[order], dst[ok])]
+    k = np.argsort(u, kind="stable")
+    assert np.array_equal(nbr, v[k]) and np.array_equal(eid, np.flatnonzero(ok)[k])
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(np.bincount(u, minlength=vid.size))]))
+    assert g.dropped == int((~ok).sum())
+    g.close()
