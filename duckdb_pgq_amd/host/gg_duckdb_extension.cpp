@@ -15,7 +15,7 @@
 //   gg_same_neighbour_paths(vertices_sql, sources_sql, path_table, path_src, path_dst,
 //                           filter_table, filter_src, filter_dst, hops)
 //        -> (w BIGINT, v0 BIGINT, ..., v{hops} BIGINT)      Train Benchmark ConnectedSegments
-//   gg_graph_pin(vertex_table, vertex_key, edge_table, src_col, dst_col) / gg_graph_unpin()
+//   gg_graph_pin(vertex_table, vertex_key, edge_table, src_col, dst_col) / gg_graph_unpin() / gg_graph_pins()
 //        -> keep that graph on the device for later statements (a snapshot; see "Pinned graphs" below)
 //
 // Each function runs the operator classes of gg_operators.hpp exactly the way the reference's
@@ -39,6 +39,7 @@
 #include "duckdb/parallel/parallel_state.hpp"
 #include "duckdb/parallel/thread_context.hpp"
 #include "duckdb/parser/parsed_data/create_table_function_info.hpp"
+#include "duckdb/transaction/transaction.hpp"
 #include "gg_extension.hpp"
 
 namespace duckdb {
@@ -79,11 +80,20 @@ struct PhaseTimer {
 // Every statement reads its base tables again (like the hash-join builds it replaces), which makes a
 // selective query — one source, two hops — pay for the whole edge table.  `gg_graph_pin(...)` builds the
 // graph of a (vertex table, key, edge table, src, dst) combination once and keeps it on the device, the way
-// a property graph or an index is declared once; table functions and planner rules that need exactly that
-// graph then skip ingest and build.  A pinned graph is a SNAPSHOT (this version of the reference has no
-// per-table modification counter to hang an invalidation on): it is dropped when a table's row count no
-// longer matches — which catches appends, not updates or deletes — and by gg_graph_unpin(); pin again
-// after changing the tables.
+// a property graph or an index is declared once.  A pinned graph is a SNAPSHOT of what the pinning
+// transaction saw, and this version of the reference has no per-table modification counter to hang an
+// invalidation on, so its use is hedged:
+//   - nothing uses a pinned graph unless the connection asked for it: PRAGMA gg_use_pinned_graphs (per
+//     connection, off by default; PRAGMA gg_ignore_pinned_graphs turns it off again).  Without it planner
+//     rules and table functions read the tables, in the statement's own transaction, like the joins they replace;
+//   - a transaction that has changed anything (Transaction::ChangesMade: local appends, updates, deletes)
+//     neither creates nor uses pinned graphs;
+//   - an INSERT, DELETE or UPDATE planned on a pinned table — by any connection of this process, committed or
+//     not — drops the pins on it (gg_plan_hook.c observes the three CreatePlan overloads; without the shim there
+//     are no planner rules either, only the table functions);
+//   - a changed row count (appends by other means) drops the pin as well.
+// What remains is the caller's business and is documented in INTEGRATION.md: a graph pinned while another
+// connection holds an uncommitted change does not see that change when it commits — unpin before such work.
 struct PinnedGraph {
 	idx_t vertex_oid, edge_oid; // catalog oids (never reused), vertex_oid = 0: vertex set = endpoint ids
 	column_t vertex_key, src, dst;
@@ -107,9 +117,10 @@ static bool PinKey(const GGGraphSpec &spec, PinnedGraph &key) {
 	return true;
 }
 
-static shared_ptr<GGGraph> FindPinned(const GGGraphSpec &spec) {
+static shared_ptr<GGGraph> FindPinned(ClientContext &context, const GGGraphSpec &spec) {
 	PinnedGraph key;
-	if (!PinKey(spec, key)) {
+	if (!GGGetConnectionFlags(context).pinned_graphs || Transaction::GetTransaction(context).ChangesMade() ||
+	    !PinKey(spec, key)) {
 		return nullptr;
 	}
 	lock_guard<mutex> guard(g_pinned_lock);
@@ -144,10 +155,64 @@ static shared_ptr<GGGraph> BuildGraphNow(ClientContext &context, const GGGraphSp
 }
 
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec) {
-	if (auto pinned = FindPinned(spec)) {
+	if (auto pinned = FindPinned(context, spec)) {
 		return pinned;
 	}
 	return BuildGraphNow(context, spec);
+}
+
+void GGDropPinsOfTable(idx_t table_oid) {
+	lock_guard<mutex> guard(g_pinned_lock);
+	for (idx_t i = 0; i < g_pinned.size();) {
+		if (g_pinned[i].edge_oid == table_oid || g_pinned[i].vertex_oid == table_oid) {
+			g_pinned.erase(g_pinned.begin() + i);
+		} else {
+			i++;
+		}
+	}
+}
+
+// ---- per-connection switches
+static mutex g_flags_lock;
+static vector<std::pair<weak_ptr<ClientContext>, GGConnectionFlags>> g_flags;
+
+static bool GGDefaultRules() {
+	static const bool on = [] {
+		auto env = std::getenv("GG_PLAN_RULE"); // process-wide default for connections that never said otherwise
+		return env && env[0] == '1';
+	}();
+	return on;
+}
+
+GGConnectionFlags GGGetConnectionFlags(ClientContext &context) {
+	lock_guard<mutex> guard(g_flags_lock);
+	for (auto &entry : g_flags) {
+		auto owner = entry.first.lock();
+		if (owner.get() == &context) {
+			return entry.second;
+		}
+	}
+	GGConnectionFlags flags;
+	flags.rules = GGDefaultRules();
+	return flags;
+}
+
+void GGSetConnectionFlags(ClientContext &context, const GGConnectionFlags &flags) {
+	lock_guard<mutex> guard(g_flags_lock);
+	for (idx_t i = 0; i < g_flags.size();) { // connections that are gone take their entries with them
+		if (g_flags[i].first.expired()) {
+			g_flags.erase(g_flags.begin() + i);
+		} else {
+			i++;
+		}
+	}
+	for (auto &entry : g_flags) {
+		if (entry.first.lock().get() == &context) {
+			entry.second = flags;
+			return;
+		}
+	}
+	g_flags.emplace_back(weak_ptr<ClientContext>(context.shared_from_this()), flags);
 }
 
 //! (vertex_table, vertex_key, edge_table, src_col, dst_col) arguments -> scans, resolved at execution time
@@ -408,6 +473,10 @@ static unique_ptr<FunctionData> GraphPinBind(ClientContext &context, vector<Valu
 	if (!PinKey(spec, pin)) {
 		throw BinderException("gg_graph_pin: only base tables can be pinned");
 	}
+	if (Transaction::GetTransaction(context).ChangesMade()) {
+		throw BinderException("gg_graph_pin: this transaction has uncommitted changes; a pinned graph would keep "
+		                      "them whether or not they commit — commit or roll back first");
+	}
 	auto t0 = std::chrono::steady_clock::now();
 	pin.graph = BuildGraphNow(context, spec);
 	auto result = make_unique<PinResultData>();
@@ -473,6 +542,21 @@ static void GraphUnpinFunction(ClientContext &context, const FunctionData *bind_
 	output.SetCardinality(1);
 }
 
+//! gg_graph_pins() -> number of graphs currently pinned (tests; monitoring)
+static unique_ptr<FunctionData> GraphPinsBind(ClientContext &context, vector<Value> &inputs,
+                                              unordered_map<string, Value> &named_parameters,
+                                              vector<LogicalType> &input_table_types, vector<string> &input_table_names,
+                                              vector<LogicalType> &return_types, vector<string> &names) {
+	auto result = make_unique<PinResultData>();
+	{
+		lock_guard<mutex> guard(g_pinned_lock);
+		result->vertices = (int64_t)g_pinned.size();
+	}
+	return_types = {LogicalType::BIGINT};
+	names = {"pinned"};
+	return move(result);
+}
+
 static void LoadInternal(DatabaseInstance &db) {
 	const vector<LogicalType> graph_args = {LogicalType::VARCHAR, LogicalType::VARCHAR, LogicalType::VARCHAR,
 	                                        LogicalType::VARCHAR, LogicalType::VARCHAR};
@@ -493,8 +577,9 @@ static void LoadInternal(DatabaseInstance &db) {
 	                               FilteredPathsBind);
 	TableFunction pin("gg_graph_pin", graph_args, GraphPinFunction, GraphPinBind);
 	TableFunction unpin("gg_graph_unpin", {}, GraphUnpinFunction, GraphUnpinBind);
+	TableFunction pins("gg_graph_pins", {}, GraphUnpinFunction, GraphPinsBind);
 	CreateTableFunctionInfo khop_info(khop), khop_count_info(khop_count), shortest_info(shortest),
-	    filtered_info(filtered), pin_info(pin), unpin_info(unpin);
+	    filtered_info(filtered), pin_info(pin), unpin_info(unpin), pins_info(pins);
 
 	Connection con(db);
 	con.BeginTransaction();
@@ -505,6 +590,7 @@ static void LoadInternal(DatabaseInstance &db) {
 	catalog.CreateTableFunction(*con.context, &filtered_info);
 	catalog.CreateTableFunction(*con.context, &pin_info);
 	catalog.CreateTableFunction(*con.context, &unpin_info);
+	catalog.CreateTableFunction(*con.context, &pins_info);
 	GGRegisterPlanRules(*con.context);
 	con.Commit();
 }

@@ -60,8 +60,20 @@ vector<int64_t> GGScanInt64Column(ClientContext &context, const GGScanSource &so
 //! (schema.)table resolved in the catalog, or a SQL fallback `SELECT columns FROM name` for views
 GGScanSource GGTableSource(ClientContext &context, const string &table_name, const vector<string> &columns,
                            bool with_rowid);
-//! Builds the graph — or hands back the pinned one for exactly these tables and columns (gg_graph_pin).
+//! Builds the graph — or hands back the pinned one for exactly these tables and columns (gg_graph_pin), if this
+//! connection asked for pinned graphs (PRAGMA gg_use_pinned_graphs) and its transaction has changed nothing.
 shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec);
+
+//! Per-connection switches (the reference's pragmas act on one ClientContext, client_context.hpp:61-95; so do
+//! ours).  Entries die with their connection: they are held by weak_ptr.
+struct GGConnectionFlags {
+	bool rules = false;        // PRAGMA enable_gpu_graph / disable_gpu_graph
+	bool pinned_graphs = false; // PRAGMA gg_use_pinned_graphs / gg_ignore_pinned_graphs
+};
+GGConnectionFlags GGGetConnectionFlags(ClientContext &context);
+void GGSetConnectionFlags(ClientContext &context, const GGConnectionFlags &flags);
+//! a statement is about to change `table_oid`: graphs pinned on it are dropped
+void GGDropPinsOfTable(idx_t table_oid);
 
 //! first column of `sql` (run on a side connection) as int64, NULLs skipped
 vector<int64_t> GGQueryInt64Column(ClientContext &context, const string &sql, const char *what);

@@ -11,6 +11,20 @@
 
 namespace duckdb {
 
+//! A slab fetch in flight: the counter was raised under the state's lock when the range was claimed; it comes
+//! down when the fetch is over — also when it ends in an exception, or the next claimer would wait for ever.
+struct FetchClaim {
+	std::atomic<idx_t> &counter;
+	FetchClaim(std::atomic<idx_t> &counter_p, bool already_counted) : counter(counter_p) {
+		if (!already_counted) {
+			counter++;
+		}
+	}
+	~FetchClaim() {
+		counter--;
+	}
+};
+
 //===--------------------------------------------------------------------===//
 // GGGraph
 //===--------------------------------------------------------------------===//
@@ -510,8 +524,11 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 			gstate.fetching++;
 		}
 		uint32_t got = 0;
-		const int rc = gg_result_fetch(result, slab.table, offset, (uint32_t)want, slab.Columns(slab.table + 1), &got);
-		gstate.fetching--;
+		int rc;
+		{
+			FetchClaim claim(gstate.fetching, true); // released also when slab.Columns() throws (pinned allocation)
+			rc = gg_result_fetch(result, slab.table, offset, (uint32_t)want, slab.Columns(slab.table + 1), &got);
+		}
 		GGGraph::Check(rc, "gg_result_fetch");
 		slab.rows = got;
 		slab.pos = 0;
@@ -743,8 +760,11 @@ void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk
 			gstate.fetching++;
 		}
 		uint32_t got = 0;
-		const int rc = gg_result_fetch(result, 0, offset, (uint32_t)want, slab.Columns(1), &got);
-		gstate.fetching--;
+		int rc;
+		{
+			FetchClaim claim(gstate.fetching, true);
+			rc = gg_result_fetch(result, 0, offset, (uint32_t)want, slab.Columns(1), &got);
+		}
 		GGGraph::Check(rc, "gg_result_fetch");
 		slab.rows = got;
 		slab.pos = 0;

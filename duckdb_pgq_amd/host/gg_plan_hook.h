@@ -6,7 +6,16 @@
 extern "C" {
 #endif
 
-enum { GG_PLAN_HOOK_JOIN = 0, GG_PLAN_HOOK_AGGREGATE = 1, GG_PLAN_HOOK_KINDS = 2 };
+enum {
+  GG_PLAN_HOOK_JOIN = 0,
+  GG_PLAN_HOOK_AGGREGATE = 1,
+  /* INSERT / DELETE / UPDATE plans are only OBSERVED (the rule returns 0): a statement that is about to change a
+   * table drops the graphs pinned on it (gg_duckdb_extension.cpp, Pinned graphs) */
+  GG_PLAN_HOOK_INSERT = 2,
+  GG_PLAN_HOOK_DELETE = 3,
+  GG_PLAN_HOOK_UPDATE = 4,
+  GG_PLAN_HOOK_KINDS = 5
+};
 
 /* A rule looks at the logical operator about to be planned.  To take it over it constructs a
  * std::unique_ptr<duckdb::PhysicalOperator> in *ret_slot (placement new) and returns non-zero; returning

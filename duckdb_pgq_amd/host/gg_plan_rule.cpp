@@ -48,7 +48,6 @@
 #include "duckdb/execution/operator/filter/physical_filter.hpp"
 #include "duckdb/execution/operator/projection/physical_projection.hpp"
 #include "duckdb/execution/operator/scan/physical_table_scan.hpp"
-#include "duckdb/execution/physical_plan_generator.hpp"
 #include "duckdb/function/pragma_function.hpp"
 #include "duckdb/function/table/table_scan.hpp"
 #include "duckdb/parser/parsed_data/create_pragma_function_info.hpp"
@@ -57,6 +56,8 @@
 #include "duckdb/planner/expression/bound_aggregate_expression.hpp"
 #include "duckdb/planner/expression/bound_case_expression.hpp"
 #include "duckdb/planner/expression/bound_comparison_expression.hpp"
+#include <unordered_set>
+
 #include "duckdb/planner/expression/bound_conjunction_expression.hpp"
 #include "duckdb/planner/expression/bound_constant_expression.hpp"
 #include "duckdb/planner/expression/bound_function_expression.hpp"
@@ -74,12 +75,20 @@
 #include "duckdb/planner/operator/logical_projection.hpp"
 #include "duckdb/planner/operator/logical_recursive_cte.hpp"
 #include "duckdb/planner/operator/logical_get.hpp"
+#include "duckdb/planner/operator/logical_insert.hpp"
+#include "duckdb/planner/operator/logical_delete.hpp"
+#include "duckdb/planner/operator/logical_update.hpp"
 #include "gg_extension.hpp"
 #include "gg_plan_hook.h"
+// The rule needs the ClientContext a plan is made for (the switches are per connection), and the generator keeps
+// it private.  Included last, so that only this one class definition is read with the access specifier widened;
+// the layout does not change.
+#define private public
+#include "duckdb/execution/physical_plan_generator.hpp"
+#undef private
 
 namespace duckdb {
 
-static std::atomic<bool> g_rules_enabled {false};
 static std::atomic<uint64_t> g_rules_fired {0};
 
 namespace {
@@ -207,6 +216,99 @@ bool IsEqualityWithConstant(TableFilter &filter, int64_t &value) {
 }
 
 //! A pushed-down filter over an integer column as SQL text; false if the filter is of an unknown kind.
+//! The same filters as a host-side predicate over int64 keys: the seeds of a shortest-path plan are read from the
+//! vertex table in the statement's OWN transaction (a side connection would see another snapshot) and filtered here.
+struct KeyPredicate {
+	enum Kind { IS_NOT_NULL, COMPARE, AND, OR } kind = IS_NOT_NULL;
+	ExpressionType comparison = ExpressionType::COMPARE_EQUAL;
+	int64_t constant = 0;
+	vector<KeyPredicate> children;
+	bool Accepts(int64_t v) const {
+		switch (kind) {
+		case IS_NOT_NULL:
+			return true; // NULL keys never reach here
+		case COMPARE:
+			switch (comparison) {
+			case ExpressionType::COMPARE_EQUAL:
+				return v == constant;
+			case ExpressionType::COMPARE_NOTEQUAL:
+				return v != constant;
+			case ExpressionType::COMPARE_LESSTHAN:
+				return v < constant;
+			case ExpressionType::COMPARE_LESSTHANOREQUALTO:
+				return v <= constant;
+			case ExpressionType::COMPARE_GREATERTHAN:
+				return v > constant;
+			default:
+				return v >= constant;
+			}
+		case AND:
+			for (auto &c : children) {
+				if (!c.Accepts(v)) {
+					return false;
+				}
+			}
+			return true;
+		default:
+			for (auto &c : children) {
+				if (c.Accepts(v)) {
+					return true;
+				}
+			}
+			return false;
+		}
+	}
+};
+
+bool FilterToPredicate(TableFilter &filter, KeyPredicate &out) {
+	switch (filter.filter_type) {
+	case TableFilterType::IS_NOT_NULL:
+		out.kind = KeyPredicate::IS_NOT_NULL;
+		return true;
+	case TableFilterType::CONSTANT_COMPARISON: {
+		auto &constant = (ConstantFilter &)filter;
+		if (constant.constant.is_null || !constant.constant.type().IsIntegral()) {
+			return false;
+		}
+		switch (constant.comparison_type) {
+		case ExpressionType::COMPARE_EQUAL:
+		case ExpressionType::COMPARE_NOTEQUAL:
+		case ExpressionType::COMPARE_LESSTHAN:
+		case ExpressionType::COMPARE_LESSTHANOREQUALTO:
+		case ExpressionType::COMPARE_GREATERTHAN:
+		case ExpressionType::COMPARE_GREATERTHANOREQUALTO:
+			break;
+		default:
+			return false;
+		}
+		out.kind = KeyPredicate::COMPARE;
+		out.comparison = constant.comparison_type;
+		out.constant = constant.constant.GetValue<int64_t>();
+		return true;
+	}
+	case TableFilterType::CONJUNCTION_AND:
+	case TableFilterType::CONJUNCTION_OR: {
+		const bool is_and = filter.filter_type == TableFilterType::CONJUNCTION_AND;
+		auto &children = is_and ? ((ConjunctionAndFilter &)filter).child_filters
+		                        : ((ConjunctionOrFilter &)filter).child_filters;
+		if (children.empty()) {
+			return false;
+		}
+		out.kind = is_and ? KeyPredicate::AND : KeyPredicate::OR;
+		for (auto &child : children) {
+			KeyPredicate c;
+			if (!FilterToPredicate(*child, c)) {
+				return false;
+			}
+			out.children.push_back(move(c));
+		}
+		return true;
+	}
+	default:
+		return false;
+	}
+}
+
 bool FilterToSQL(TableFilter &filter, const string &column, string &out) {
 	switch (filter.filter_type) {
 	case TableFilterType::IS_NOT_NULL:
@@ -1600,13 +1702,17 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	}
 	// filters pushed into the seed's scan (`key = c`, or the bounds the optimizer derives from an IN list)
 	vector<string> seed_predicates;
+	vector<KeyPredicate> seed_filters;
 	for (auto &entry : seed_get.table_filters.filters) {
 		string predicate;
+		KeyPredicate key_predicate;
 		if (entry.first != vertex_key ||
-		    !FilterToSQL(*entry.second, GGQuote(vertex_table->columns[vertex_key].name), predicate)) {
+		    !FilterToSQL(*entry.second, GGQuote(vertex_table->columns[vertex_key].name), predicate) ||
+		    !FilterToPredicate(*entry.second, key_predicate)) {
 			return nullptr;
 		}
 		seed_predicates.push_back(predicate);
+		seed_filters.push_back(move(key_predicate));
 	}
 
 	// ---- step: SELECT f.start, f.hop + 1, <next vertex> FROM friends f JOIN edge [JOIN vertex] ...
@@ -1777,24 +1883,37 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	}
 	spec.edges = TableColumns(edge_table, {src, dst});
 	g_plan_tables.push_back(vertex_table); // the seed rows are read from it by key
-	// the seeds are rows of the vertex table: constants that are nobody's key start nothing
-	string sources_sql = "SELECT " + key_name + " FROM " + QualifiedName(*vertex_table);
+	// the seeds are rows of the vertex table (constants that are nobody's key start nothing), read in the
+	// statement's own transaction like the edge table: the key column is scanned through the ingest path and
+	// the pushed-down filters and the IN list are applied to it here
 	if (!all_vertices) {
 		string in_list = key_name + " IN (";
 		for (idx_t i = 0; i < seed_constants.size(); i++) {
 			in_list += (i ? ", " : "") + to_string(seed_constants[i]);
 		}
-		seed_predicates.push_back(in_list + ")");
+		seed_predicates.push_back(in_list + ")"); // (for EXPLAIN only)
 	}
-	for (idx_t i = 0; i < seed_predicates.size(); i++) {
-		sources_sql += (i ? " AND " : " WHERE ") + seed_predicates[i];
-	}
+	const auto seed_scan = TableColumns(vertex_table, {vertex_key});
 	const int max_hops = (int)in.max_hops;
 	const bool lone_sources = !validated;
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &context, GGOpened &opened) {
 		opened.graph = GGBuildGraph(context, spec);
-		auto sources = GGQueryInt64Column(context, sources_sql, "shortest path seed");
+		auto sources = GGScanInt64Column(context, seed_scan);
+		if (!all_vertices || !seed_filters.empty()) {
+			std::unordered_set<int64_t> wanted(seed_constants.begin(), seed_constants.end());
+			idx_t kept = 0;
+			for (auto id : sources) {
+				bool keep = all_vertices || wanted.count(id);
+				for (idx_t f = 0; keep && f < seed_filters.size(); f++) {
+					keep = seed_filters[f].Accepts(id);
+				}
+				if (keep) {
+					sources[kept++] = id;
+				}
+			}
+			sources.resize(kept);
+		}
 		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), max_hops, 0, lone_sources);
 	};
 	data->description = edge_table->name + ": " + edge_table->columns[src].name + " -> " + edge_table->columns[dst].name +
@@ -1827,8 +1946,8 @@ unique_ptr<PhysicalOperator> PlanAggregate(LogicalAggregate &op) {
 
 template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
 int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
-	if (!g_rules_enabled) {
-		return 0;
+	if (!GGGetConnectionFlags(((PhysicalPlanGenerator *)generator)->context).rules) {
+		return 0; // PRAGMA enable_gpu_graph was not issued on THIS connection
 	}
 	unique_ptr<PhysicalOperator> plan;
 	g_plan_tables.clear();
@@ -1848,11 +1967,38 @@ int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 }
 
 void PragmaEnableGpuGraph(ClientContext &context, const FunctionParameters &parameters) {
-	g_rules_enabled = true;
+	auto flags = GGGetConnectionFlags(context);
+	flags.rules = true;
+	GGSetConnectionFlags(context, flags);
 }
 
 void PragmaDisableGpuGraph(ClientContext &context, const FunctionParameters &parameters) {
-	g_rules_enabled = false;
+	auto flags = GGGetConnectionFlags(context);
+	flags.rules = false;
+	GGSetConnectionFlags(context, flags);
+}
+
+void PragmaUsePinnedGraphs(ClientContext &context, const FunctionParameters &parameters) {
+	auto flags = GGGetConnectionFlags(context);
+	flags.pinned_graphs = true;
+	GGSetConnectionFlags(context, flags);
+}
+
+void PragmaIgnorePinnedGraphs(ClientContext &context, const FunctionParameters &parameters) {
+	auto flags = GGGetConnectionFlags(context);
+	flags.pinned_graphs = false;
+	GGSetConnectionFlags(context, flags);
+}
+
+//! INSERT / DELETE / UPDATE about to be planned: drop the graphs pinned on the target table (never takes the
+//! plan over)
+template <class OP>
+int WriteObserver(void *ret_slot, void *generator, void *logical_operator) {
+	auto table = ((OP *)logical_operator)->table;
+	if (table) {
+		GGDropPinsOfTable(table->oid);
+	}
+	return 0;
 }
 
 } // namespace
@@ -1861,8 +2007,13 @@ void GGRegisterPlanRules(ClientContext &context) {
 	// same style as the reference's enable_profiling / disable_profiling (pragma_functions.cpp:280-345)
 	CreatePragmaFunctionInfo enable(PragmaFunction::PragmaStatement("enable_gpu_graph", PragmaEnableGpuGraph));
 	CreatePragmaFunctionInfo disable(PragmaFunction::PragmaStatement("disable_gpu_graph", PragmaDisableGpuGraph));
+	CreatePragmaFunctionInfo use_pins(PragmaFunction::PragmaStatement("gg_use_pinned_graphs", PragmaUsePinnedGraphs));
+	CreatePragmaFunctionInfo no_pins(
+	    PragmaFunction::PragmaStatement("gg_ignore_pinned_graphs", PragmaIgnorePinnedGraphs));
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &enable);
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &disable);
+	Catalog::GetCatalog(context).CreatePragmaFunction(context, &use_pins);
+	Catalog::GetCatalog(context).CreatePragmaFunction(context, &no_pins);
 
 	// the shim is optional: without it the extension only offers its table functions
 	auto reg = (int (*)(int, gg_plan_rule_fn))dlsym(RTLD_DEFAULT, "gg_plan_hook_register");
@@ -1871,10 +2022,10 @@ void GGRegisterPlanRules(ClientContext &context) {
 	}
 	reg(GG_PLAN_HOOK_JOIN, RuleEntry<LogicalComparisonJoin, PlanJoinChain>);
 	reg(GG_PLAN_HOOK_AGGREGATE, RuleEntry<LogicalAggregate, PlanAggregate>);
-	auto env = std::getenv("GG_PLAN_RULE");
-	if (env && env[0] == '1') {
-		g_rules_enabled = true;
-	}
+	reg(GG_PLAN_HOOK_INSERT, WriteObserver<LogicalInsert>);
+	reg(GG_PLAN_HOOK_DELETE, WriteObserver<LogicalDelete>);
+	reg(GG_PLAN_HOOK_UPDATE, WriteObserver<LogicalUpdate>);
+	// GG_PLAN_RULE=1 in the environment is the default of connections that issue no pragma (gg_duckdb_extension.cpp)
 }
 
 } // namespace duckdb

@@ -41,8 +41,12 @@
  *     into a duckdb::IOException, mirroring how the reference reports operator errors.
  *   - all pointers are HOST memory unless the name ends in _dev; inputs are copied, outputs are
  *     written into caller-allocated arrays.
- *   - gg_vertices_append / gg_edges_append are thread-safe; everything else on one gg_ctx is
- *     externally serialised (DuckDB calls Finalize/GetData single-threaded per operator).
+ *   - thread safety: gg_vertices_append / gg_edges_append (concurrent Sink calls), gg_result_rows /
+ *     gg_result_fetch / gg_result_destroy (several pipeline threads drain one result into their own buffers)
+ *     and gg_host_alloc / gg_host_free may be called concurrently on one gg_ctx; they use nothing but
+ *     their own locks and thread-safe HIP calls.  Everything else on one gg_ctx is externally serialised
+ *     (DuckDB calls Finalize single-threaded per operator; the source operators hold the graph's lock
+ *     around expansion calls).
  *   - vertex ids are arbitrary int64 (LDBC person ids are sparse); the *dense index* of a vertex
  *     is its 0-based position in the vertex table as appended (= DuckDB rowid of the vertex row).
  *   - an edge whose src or dst id is not in the vertex table is dropped (inner-join semantics of

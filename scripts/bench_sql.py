@@ -61,11 +61,13 @@ def main():
         rec["gpu_s"] = round(best, 4)
         rec["result"] = gpu.tolist()
         # the same statement with the graph pinned on the device (gg_graph_pin): no ingest, no build
+        d.execute("PRAGMA gg_use_pinned_graphs")  # pinned graphs are opt-in per connection (snapshot semantics)
         d.execute("SELECT * FROM gg_graph_pin('', '', 'knows', 'k_person1id', 'k_person2id')")
         pinned, best = d.timed(sql, runs=a.gpu_runs)
         rec["gpu_pinned_s"] = round(best, 5)
         assert np.array_equal(pinned, gpu)
         d.execute("SELECT * FROM gg_graph_unpin()")
+        d.execute("PRAGMA gg_ignore_pinned_graphs")
         d.execute("PRAGMA disable_gpu_graph")
         if not a.skip_cpu:
             cpu, best = d.timed(sql, runs=a.cpu_runs)

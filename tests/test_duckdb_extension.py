@@ -310,6 +310,8 @@ def test_plan_rule_prepared_statements_and_concurrent_connections(db):
     def work():
         try:
             c = d.connect()
+            c.execute("PRAGMA enable_gpu_graph")  # per connection, like the reference's own pragmas
+            assert "GG_" in c.explain(sql)
             for _ in range(4):
                 results.append(int(c.execute(sql)[0, 0]))
             c.close()
@@ -426,6 +428,7 @@ def test_pinned_graphs_are_reused_and_dropped_when_rows_are_appended(db):
     one = "SELECT k2.b FROM pk k1, pk k2 WHERE k1.b = k2.a AND k1.a = %d" % int(vid[5])
     expect_one = sort_rows(d.execute(one))
     d.execute("PRAGMA enable_gpu_graph")
+    d.execute("PRAGMA gg_use_pinned_graphs")  # pinned graphs are opt-in, per connection
     assert int(d.execute(sql)[0, 0]) == expect
     pinned = d.execute("SELECT vertices, edges FROM gg_graph_pin('', '', 'pk', 'a', 'b')")
     assert pinned[0, 1] == int(d.execute("SELECT count(*) FROM pk")[0, 0])
@@ -441,6 +444,8 @@ def test_pinned_graphs_are_reused_and_dropped_when_rows_are_appended(db):
     def work():
         try:
             c = d.connect()
+            c.execute("PRAGMA enable_gpu_graph")  # the switches belong to a connection
+            c.execute("PRAGMA gg_use_pinned_graphs")
             for _ in range(3):
                 out.append(int(c.execute(sql)[0, 0]))
                 out.append(sort_rows(c.execute(one)).shape[0])
@@ -464,4 +469,84 @@ def test_pinned_graphs_are_reused_and_dropped_when_rows_are_appended(db):
     d.execute("PRAGMA disable_gpu_graph")
     assert got[:, 1].tolist() == [int(d.execute(R.sql_khop(h))[0, 0]) for h in (1, 2)]
     assert int(d.execute("SELECT * FROM gg_graph_unpin()")[0, 0]) >= 1
+    d.execute("PRAGMA gg_ignore_pinned_graphs")
     assert with_pin < 1.0
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_pinned_graphs_are_opt_in_and_never_outlive_a_write(db):
+    """A pinned graph is a snapshot.  Nothing uses one unless the connection said PRAGMA gg_use_pinned_graphs; an
+    INSERT, UPDATE or DELETE planned on a pinned table drops the pin (also when the transaction rolls back); a
+    transaction with changes of its own neither pins nor uses pins.  Whatever happens, a substituted plan
+    returns what the reference's own plan returns on the same tables."""
+    d, vid = db
+    d.execute("CREATE TABLE pw (a BIGINT NOT NULL, b BIGINT NOT NULL)")
+    d.execute("INSERT INTO pw SELECT k_person1id, k_person2id FROM knows WHERE k_person1id >= 0 AND k_person2id >= 0")
+    sql = "SELECT count(*), sum(k2.b) FROM pw k1, pw k2 WHERE k1.b = k2.a"
+
+    def cpu():
+        d.execute("PRAGMA disable_gpu_graph")
+        out = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        return out
+
+    def pins():
+        return int(d.execute("SELECT * FROM gg_graph_pins()")[0, 0])
+
+    pin = "SELECT * FROM gg_graph_pin('', '', 'pw', 'a', 'b')"
+    d.execute("PRAGMA enable_gpu_graph")
+    d.execute("SELECT * FROM gg_graph_unpin()")
+    try:
+        # 1. not opted in: the pin exists but the statement reads the table — an UPDATE shows at once
+        d.execute(pin)
+        assert pins() == 1
+        before = cpu()
+        assert np.array_equal(d.execute(sql), before)
+        d.execute("UPDATE pw SET b = %d WHERE a = %d" % (int(vid[7]), int(vid[9])))
+        assert pins() == 0  # ... and the write dropped the pin anyway
+        after = cpu()
+        assert not np.array_equal(after, before) and np.array_equal(d.execute(sql), after)
+        # 2. opted in: UPDATE, DELETE and INSERT each drop the pin, the next statement sees the change
+        d.execute("PRAGMA gg_use_pinned_graphs")
+        for change in ("UPDATE pw SET b = %d WHERE a = %d" % (int(vid[11]), int(vid[12])),
+                       "DELETE FROM pw WHERE a = %d" % int(vid[13]),
+                       "INSERT INTO pw VALUES (%d, %d)" % (int(vid[14]), int(vid[15]))):
+            d.execute(pin)
+            assert pins() == 1 and np.array_equal(d.execute(sql), cpu()) and pins() == 1
+            d.execute(change)
+            assert pins() == 0
+            assert np.array_equal(d.execute(sql), cpu())
+        # 3. a write that is rolled back still cost the pin; the result is the table's again
+        d.execute(pin)
+        keep = cpu()
+        d.execute("BEGIN TRANSACTION")
+        d.execute("DELETE FROM pw WHERE a = %d" % int(vid[20]))
+        assert pins() == 0
+        assert np.array_equal(d.execute(sql), cpu())  # inside the transaction: its own deletes are seen
+        d.execute("ROLLBACK")
+        assert np.array_equal(d.execute(sql), keep) and np.array_equal(cpu(), keep)
+        # 4. a transaction with changes of its own does not pin ...
+        d.execute("CREATE TABLE other (x BIGINT)")
+        d.execute("BEGIN TRANSACTION")
+        d.execute("INSERT INTO other VALUES (1)")
+        with pytest.raises(Exception, match="uncommitted changes"):
+            d.execute(pin)
+        d.execute("ROLLBACK")
+        # ... and does not use a pin made before it started
+        d.execute(pin)
+        d.execute("BEGIN TRANSACTION")
+        d.execute("INSERT INTO other VALUES (2)")
+        assert pins() == 1 and np.array_equal(d.execute(sql), keep)
+        d.execute("ROLLBACK")
+        # 5. another connection has its own switches: no pragma, no substituted plan
+        c = d.connect()
+        assert "GG_" not in c.explain(sql)
+        c.execute("PRAGMA enable_gpu_graph")
+        assert "GG_" in c.explain(sql) and "GG_" in d.explain(sql)
+        c.execute("PRAGMA disable_gpu_graph")
+        assert "GG_" not in c.explain(sql) and "GG_" in d.explain(sql)
+        c.close()
+    finally:
+        d.execute("SELECT * FROM gg_graph_unpin()")
+        d.execute("PRAGMA gg_ignore_pinned_graphs")
+        d.execute("PRAGMA disable_gpu_graph")

@@ -175,18 +175,7 @@ def test_other_recursive_ctes_are_left_alone(db, sql):
 
 
 # ---- walks whose vertices share a neighbour in a second edge table (Train Benchmark ConnectedSegments) ----
-def connectedsegments_sql(hops=5, segment="INNER JOIN", extra=""):
-    """benchmark/trainbenchmark/queries/connectedsegments.sql:1-25, generalised over the walk length."""
-    cols = ", ".join(f"ct{i}.TrackElement1_id AS segment{i}" for i in range(1, hops + 1))
-    sql = f"SELECT mb1.Sensor_id AS sensor, {cols}, ct{hops}.TrackElement2_id AS segment{hops + 1}\nFROM Segment\n"
-    sql += f"{segment} connectsTo as ct1 ON Segment.id = ct1.TrackElement1_id\n"
-    for i in range(2, hops + 1):
-        sql += f"INNER JOIN connectsTo as ct{i} ON ct{i-1}.TrackElement2_id = ct{i}.TrackElement1_id\n"
-    for i in range(1, hops + 1):
-        sql += f"INNER JOIN monitoredBy as mb{i} ON mb{i}.TrackElement_id = ct{i}.TrackElement1_id\n"
-    sql += f"INNER JOIN monitoredBy as mb{hops + 1} ON mb{hops + 1}.TrackElement_id = ct{hops}.TrackElement2_id\n"
-    sql += "WHERE " + " AND ".join(f"mb1.Sensor_id = mb{i}.Sensor_id" for i in range(2, hops + 2)) + extra
-    return sql
+from tests.trainbenchmark import connectedsegments_sql  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -300,3 +289,20 @@ def test_the_references_ldbc_queries_get_gpu_operators():
     d.close()
     for name, op in expect.items():
         assert op in seen.get(name, []), (name, seen.get(name))
+
+
+def test_the_rule_switch_belongs_to_one_connection(db):
+    """PRAGMA enable_gpu_graph acts on the connection that issues it (the reference's pragmas are ClientContext
+    state, client_context.hpp:61-95): a second connection keeps the reference's plan until it says so itself."""
+    sql = "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id"
+    other = db.connect()
+    try:
+        db.execute("PRAGMA enable_gpu_graph")
+        assert "GG_" in db.explain(sql) and "GG_" not in other.explain(sql)
+        other.execute("PRAGMA enable_gpu_graph")
+        db.execute("PRAGMA disable_gpu_graph")
+        assert "GG_" not in db.explain(sql) and "GG_" in other.explain(sql)
+    finally:
+        other.execute("PRAGMA disable_gpu_graph")
+        other.close()
+        db.execute("PRAGMA disable_gpu_graph")

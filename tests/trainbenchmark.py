@@ -44,3 +44,17 @@ def connectedsegments_via_joins(orc, t):
         keep = mb[m[:, 1], 1] == rows[m[:, 0], 0]
         rows = rows[m[keep, 0]]
     return rows
+
+
+def connectedsegments_sql(hops=5, segment="INNER JOIN", extra=""):
+    """benchmark/trainbenchmark/queries/connectedsegments.sql:1-25, generalised over the walk length."""
+    cols = ", ".join(f"ct{i}.TrackElement1_id AS segment{i}" for i in range(1, hops + 1))
+    sql = f"SELECT mb1.Sensor_id AS sensor, {cols}, ct{hops}.TrackElement2_id AS segment{hops + 1}\nFROM Segment\n"
+    sql += f"{segment} connectsTo as ct1 ON Segment.id = ct1.TrackElement1_id\n"
+    for i in range(2, hops + 1):
+        sql += f"INNER JOIN connectsTo as ct{i} ON ct{i-1}.TrackElement2_id = ct{i}.TrackElement1_id\n"
+    for i in range(1, hops + 1):
+        sql += f"INNER JOIN monitoredBy as mb{i} ON mb{i}.TrackElement_id = ct{i}.TrackElement1_id\n"
+    sql += f"INNER JOIN monitoredBy as mb{hops + 1} ON mb{hops + 1}.TrackElement_id = ct{hops}.TrackElement2_id\n"
+    sql += "WHERE " + " AND ".join(f"mb1.Sensor_id = mb{i}.Sensor_id" for i in range(2, hops + 2)) + extra
+    return sql
