@@ -15,8 +15,12 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDUCKDB = os.path.join(HERE, "_ref", "libduckdb.so")
-LIBGGREF = os.path.join(HERE, "_ref", "libggref.so")
+# GG_REF_VARIANT=hoisted: the reference with oracle/hoisted_build.patch (hash tables of a recursive CTE's invariant
+# builds kept across iterations: the "best CPU" baseline).  One variant per process: both export the same symbols.
+VARIANT = os.environ.get("GG_REF_VARIANT", "")
+_DIR = "_ref_hoisted" if VARIANT == "hoisted" else "_ref"
+LIBDUCKDB = os.path.join(HERE, _DIR, "libduckdb.so")
+LIBGGREF = os.path.join(HERE, _DIR, "libggref.so")
 # interposition shim of the product's planner rules (duckdb_pgq_amd/host/gg_plan_hook.c): a pass-through
 # until the extension registers its rules, but it has to be in the global scope BEFORE libduckdb
 PLAN_HOOK = os.path.join(os.path.dirname(HERE), "duckdb_pgq_amd", "libgg_plan_hook.so")

@@ -61,3 +61,26 @@ def test_connectedsegments_sql_on_reference():
     sql = open(path).read() if os.path.exists(path) else tb.connectedsegments_sql()
     assert np.array_equal(sort_rows(db.execute(sql)), sort_rows(tb.CONNECTEDSEGMENTS_GOLDEN))
     db.close()
+
+
+def test_hoisted_build_variant_of_the_reference_returns_the_same_relation():
+    """oracle/hoisted_build.patch keeps the hash table over the edge table across the iterations of
+    the recursive CTE instead of rebuilding it per level (physical_recursive_cte.cpp:112-119).  It is only a faster
+    baseline: the shortest-path relation must be the stock reference's.  One variant per process (same symbols)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref_hoisted", "libduckdb.so")):
+        pytest.skip("oracle/_ref_hoisted not built (make -C oracle ref_hoisted)")
+    out = {}
+    for variant in ("", "hoisted"):
+        env = dict(os.environ, GG_REF_VARIANT=variant)
+        r = subprocess.run([sys.executable, os.path.join(root, "oracle", "ref_cte_bench.py"), "1500,40000,9", "24", "4", "2"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[variant or "stock"] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["stock"]["variant"] == "stock" and out["hoisted"]["variant"] == "hoisted"
+    assert out["stock"]["rows"] == out["hoisted"]["rows"] > 0
+    assert out["stock"]["checksum"] == out["hoisted"]["checksum"]
