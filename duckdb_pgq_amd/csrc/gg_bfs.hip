@@ -111,11 +111,54 @@ __global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ sr
   }
 }
 
+// ---- levels driven from the device (bfs_run) --------------------------------------------------------------------
+// The host does not read anything back between levels: every level's kernels are launched in advance and each
+// decides from the statistics of the frontier it starts from (steps[level - 1], written by the level before)
+// whether there is anything to do and in which direction: done (empty frontier), pull (heavy) or push (light).
+// Kernels of the direction not taken return at once.  steps[] also records which of the two word buffers holds the
+// frontier a level produced and whether the other one still has stale bits (after a pull level).
+struct BfsStep {
+  unsigned long long n_active, te, reached;  // BfsLevel of the frontier this level produced
+  unsigned long long cur;                    // buffer (0/1) that holds it
+  unsigned long long dirty;                  // the other buffer is not all-zero
+};
+enum BfsMode : int { BFS_DONE = 0, BFS_PUSH = 1, BFS_PULL = 2 };
+__device__ __forceinline__ int bfs_mode(const BfsStep &prev, uint64_t E) {
+  if (prev.n_active == 0) return BFS_DONE;
+  return prev.te * 16 > E ? BFS_PULL : BFS_PUSH;  // heavy frontier: gather instead of scatter
+}
+
+__device__ __forceinline__ void compact_body(const uint64_t *__restrict__ frontier, uint64_t V,
+                                             uint32_t *__restrict__ active, unsigned long long *__restrict__ cursor,
+                                             uint32_t *s_cnt, uint32_t *s_base);
+
 __global__ __launch_bounds__(256) void k_bfs_compact(const uint64_t *__restrict__ frontier, uint64_t V,
                                                      uint32_t *__restrict__ active,
                                                      unsigned long long *__restrict__ cursor) {
   __shared__ uint32_t s_cnt[4];
   __shared__ uint32_t s_base;
+  compact_body(frontier, V, active, cursor, s_cnt, &s_base);
+}
+
+// push level, first kernel: clear what a pull level left in the spare buffer, then list the active vertices
+__global__ __launch_bounds__(256) void k_bfs_compact_dev(const BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
+                                                         uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
+                                                         uint64_t V, uint32_t *__restrict__ active,
+                                                         unsigned long long *__restrict__ cursors) {
+  __shared__ uint32_t s_cnt[4];
+  __shared__ uint32_t s_base;
+  const BfsStep prev = steps[level - 1];
+  if (bfs_mode(prev, E) != BFS_PUSH) return;
+  uint64_t *front = prev.cur ? f1 : f0, *other = prev.cur ? f0 : f1;
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (prev.dirty && v < V) other[v] = 0;
+  compact_body(front, V, active, cursors + level, s_cnt, &s_base);
+}
+
+__device__ __forceinline__ void compact_body(const uint64_t *__restrict__ frontier, uint64_t V,
+                                             uint32_t *__restrict__ active, unsigned long long *__restrict__ cursor,
+                                             uint32_t *s_cnt, uint32_t *s_base_p) {
+#define s_base (*s_base_p)
   const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = v < V && frontier[v] != 0;
   const uint64_t m = __ballot(on);
@@ -130,13 +173,37 @@ __global__ __launch_bounds__(256) void k_bfs_compact(const uint64_t *__restrict_
   uint32_t wbase = s_base;
   for (int w = 0; w < wave; w++) wbase += s_cnt[w];
   if (on) active[wbase + __popcll(m & ((1ULL << lane) - 1ULL))] = (uint32_t)v;
+#undef s_base
 }
 
 // push: a wavefront per active vertex (grid-strided)
+__device__ __forceinline__ void push_body(const uint32_t *__restrict__ active, uint64_t n_active,
+                                          const uint64_t *__restrict__ frontier, const uint64_t *__restrict__ seen,
+                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                          uint64_t *__restrict__ next);
+
 __global__ __launch_bounds__(256) void k_bfs_push(const uint32_t *__restrict__ active, uint64_t n_active,
                                                   const uint64_t *__restrict__ frontier,
                                                   const uint64_t *__restrict__ seen, const uint32_t *__restrict__ off,
                                                   const uint32_t *__restrict__ nbr, uint64_t *__restrict__ next) {
+  push_body(active, n_active, frontier, seen, off, nbr, next);
+}
+
+__global__ __launch_bounds__(256) void k_bfs_push_dev(const BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
+                                                      uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
+                                                      const uint32_t *__restrict__ active,
+                                                      const uint64_t *__restrict__ seen,
+                                                      const uint32_t *__restrict__ off,
+                                                      const uint32_t *__restrict__ nbr) {
+  const BfsStep prev = steps[level - 1];
+  if (bfs_mode(prev, E) != BFS_PUSH) return;
+  push_body(active, prev.n_active, prev.cur ? f1 : f0, seen, off, nbr, prev.cur ? f0 : f1);
+}
+
+__device__ __forceinline__ void push_body(const uint32_t *__restrict__ active, uint64_t n_active,
+                                          const uint64_t *__restrict__ frontier, const uint64_t *__restrict__ seen,
+                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                          uint64_t *__restrict__ next) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -154,11 +221,42 @@ __global__ __launch_bounds__(256) void k_bfs_push(const uint32_t *__restrict__ a
 
 // after a push: fold `next` into the new frontier
 template <typename DistT>
+__device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
+                                            uint64_t *__restrict__ next, uint64_t V, uint32_t level,
+                                            const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
+                                            BfsLevel *__restrict__ lv, uint64_t *s_red);
+
+template <typename DistT>
 __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
                                                     uint64_t *__restrict__ next, uint64_t V, uint32_t level,
                                                     const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
                                                     BfsLevel *__restrict__ lv) {
   __shared__ uint64_t s_red[12];
+  update_body<DistT>(frontier, seen, next, V, level, off, dist8, lv, s_red);
+}
+
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_update_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
+                                                        uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
+                                                        uint64_t *__restrict__ seen, uint64_t V,
+                                                        const uint32_t *__restrict__ off,
+                                                        uint64_t *__restrict__ dist8) {
+  __shared__ uint64_t s_red[12];
+  const BfsStep prev = steps[level - 1];
+  if (bfs_mode(prev, E) != BFS_PUSH) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the new frontier stays in the same buffer, the spare one is zero again
+    steps[level].cur = prev.cur;
+    steps[level].dirty = 0;
+  }
+  update_body<DistT>(prev.cur ? f1 : f0, seen, prev.cur ? f0 : f1, V, level, off, dist8,
+                     reinterpret_cast<BfsLevel *>(&steps[level]), s_red);
+}
+
+template <typename DistT>
+__device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
+                                            uint64_t *__restrict__ next, uint64_t V, uint32_t level,
+                                            const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
+                                            BfsLevel *__restrict__ lv, uint64_t *s_red) {
   const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t nw = 0, te = 0;
   if (v < V) {
@@ -186,12 +284,47 @@ __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ front
 constexpr uint32_t PULL_HEAVY = GG_PULL_HEAVY;
 
 template <typename DistT>
+__device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
+                                          uint64_t *__restrict__ seen, uint64_t V, uint32_t level,
+                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
+                                          const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
+                                          BfsLevel *__restrict__ lv, uint64_t *s_red);
+
+template <typename DistT>
 __global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
                                                   uint64_t *__restrict__ seen, uint64_t V, uint32_t level,
                                                   const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
                                                   const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
                                                   BfsLevel *__restrict__ lv) {
   __shared__ uint64_t s_red[12];
+  pull_body<DistT>(fin, fout, seen, V, level, off, roff, rnbr, dist8, lv, s_red);
+}
+
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_bfs_pull_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
+                                                      uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
+                                                      uint64_t *__restrict__ seen, uint64_t V,
+                                                      const uint32_t *__restrict__ off,
+                                                      const uint32_t *__restrict__ roff,
+                                                      const uint32_t *__restrict__ rnbr,
+                                                      uint64_t *__restrict__ dist8) {
+  __shared__ uint64_t s_red[12];
+  const BfsStep prev = steps[level - 1];
+  if (bfs_mode(prev, E) != BFS_PULL) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // every word of the other buffer is written: it is the frontier now
+    steps[level].cur = prev.cur ^ 1ULL;
+    steps[level].dirty = 1;
+  }
+  pull_body<DistT>(prev.cur ? f1 : f0, prev.cur ? f0 : f1, seen, V, level, off, roff, rnbr, dist8,
+                   reinterpret_cast<BfsLevel *>(&steps[level]), s_red);
+}
+
+template <typename DistT>
+__device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
+                                          uint64_t *__restrict__ seen, uint64_t V, uint32_t level,
+                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
+                                          const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
+                                          BfsLevel *__restrict__ lv, uint64_t *s_red) {
   const int lane = threadIdx.x & 63, group = lane >> 4, gl = lane & 15;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -207,8 +340,27 @@ __global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ f
     }
     const bool heavy = e - b >= PULL_HEAVY;
     uint64_t acc = 0;
-    if (!heavy)
-      for (uint32_t i = b + gl; i < e; i += 16) acc |= fin[rnbr[i]];
+    {
+      // a 16-lane group walks its list 16 entries per trip and stops as soon as the lanes w still misses are all
+      // found (checked every second trip): in the levels where the frontier is most of the graph a vertex is
+      // complete after one or two trips instead of the 5.5 an average list takes
+      bool walking = !heavy && b < e;
+      uint32_t i0 = b;
+      for (int trip = 1; __any(walking); trip++) {
+        if (walking) {
+          const uint32_t i = i0 + gl;
+          if (i < e) acc |= fin[rnbr[i]];
+          i0 += 16;
+          if (i0 >= e) walking = false;
+        }
+        if ((trip & 1) == 0) {
+          uint64_t g = acc;
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) g |= __shfl_xor(g, o, 64);
+          if ((g | s) == ~0ULL) walking = false;
+        }
+      }
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);  // stays inside the 16-lane group
     uint64_t hm = __ballot(heavy && gl == 0);  // bit 16*g: group g's vertex wants the whole wave
@@ -332,8 +484,9 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   int64_t *ids_dev = nullptr;
   uint32_t *src_dense = nullptr, *active = nullptr;
   uint64_t *fa = nullptr, *fb = nullptr, *seen = nullptr, *dist8 = nullptr;
-  BfsLevel *lv = nullptr;
-  unsigned long long *cursor = nullptr;
+  BfsStep *steps = nullptr;            // steps[L]: the frontier level L produced (L = 0: the seed)
+  unsigned long long *cursors = nullptr;  // one compaction cursor per level
+  constexpr size_t STEP_SLOTS = (size_t)MAX_LEVEL + 2;
   GG_TRY(ctx->dev_alloc((void **)&ids_dev, GG_BFS_LANES * sizeof(int64_t)));
   GG_TRY(ctx->dev_alloc((void **)&src_dense, GG_BFS_LANES * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&active, V * sizeof(uint32_t)));
@@ -341,60 +494,72 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   GG_TRY(ctx->dev_alloc((void **)&fb, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&seen, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&dist8, V * 64 * sizeof(DistT)));
-  GG_TRY(ctx->dev_alloc((void **)&lv, sizeof(BfsLevel)));
-  GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
+  GG_TRY(ctx->dev_alloc((void **)&steps, STEP_SLOTS * sizeof(BfsStep)));
+  GG_TRY(ctx->dev_alloc((void **)&cursors, STEP_SLOTS * sizeof(unsigned long long)));
 
+  // (pageable source: the runtime stages it before the call returns; no synchronisation needed here)
   GG_HIP(hipMemcpyAsync(ids_dev, src_ids, (size_t)n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
-  GG_HIP(hipStreamSynchronize(s));
   GG_TRY(lookup_ids(ctx, csr, ids_dev, (uint64_t)n_src, src_dense));
+  GG_HIP(hipMemsetAsync(steps, 0, STEP_SLOTS * sizeof(BfsStep), s));
+  GG_HIP(hipMemsetAsync(cursors, 0, STEP_SLOTS * sizeof(unsigned long long), s));
   GG_HIP(hipMemsetAsync(fa, 0, V * sizeof(uint64_t), s));
   GG_HIP(hipMemsetAsync(fb, 0, V * sizeof(uint64_t), s));  // doubles as the push direction's `next`
   GG_HIP(hipMemsetAsync(seen, 0, V * sizeof(uint64_t), s));
   GG_HIP(hipMemsetAsync(dist8, 0xFF, V * 64 * sizeof(DistT), s));
-  GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<DistT>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, fa, seen, dist8, lv);
+  GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<DistT>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, fa, seen, dist8,
+            reinterpret_cast<BfsLevel *>(steps));  // steps[0]: cur = 0 (fa), dirty = 0 from the memset
 
   const unsigned vgrid = (unsigned)((V + 255) / 256);
   const uint64_t max_waves = (uint64_t)ctx->num_cus * 32;  // one resident set; grid-stride the rest
-  uint64_t *front = fa, *other = fb;  // `other` is all-zero whenever a level starts
-  int level = 0;
+  // Levels are launched ahead, BFS_CHUNK at a time, and decide on the device what they do (BfsStep); the host
+  // reads the steps back once per chunk — once per batch for the usual five or six levels — instead of once
+  // per level (0.83 ms wall for 0.60 ms of kernels at SF100 when every level waited for a D2H copy).
+#ifndef GG_BFS_CHUNK
+#define GG_BFS_CHUNK 6
+#endif
+  constexpr int BFS_CHUNK = GG_BFS_CHUNK;
+  const int level_cap = max_hops >= 0 && max_hops < MAX_LEVEL ? max_hops : MAX_LEVEL;
+  const unsigned push_grid = (unsigned)(((V < max_waves ? V : max_waves) * 64 + 255) / 256);
+  const uint64_t quads = (V + 3) / 4;  // pull: four vertices per wavefront
+  const unsigned pull_grid = (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + 255) / 256);
+  std::vector<BfsStep> host_steps((size_t)level_cap + 2);
+  int launched = 0;  // levels 1..launched are enqueued
   uint64_t reached = 0;
+  bool pull_ready = csr->roff != nullptr;
   while (true) {
-    // stats of the current frontier (written by the seed / previous level); one small read per level
-    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, lv, sizeof(BfsLevel), hipMemcpyDeviceToHost, s));
-    GG_HIP(hipStreamSynchronize(s));
-    BfsLevel h;
-    memcpy(&h, ctx->pin_scratch, sizeof(h));
-    reached = h.reached;
-    if (h.n_active == 0 || (max_hops >= 0 && level >= max_hops)) break;
-    if (level >= MAX_LEVEL) {  // cannot record a deeper level in DistT
-      *overflow = true;
-      break;
+    const int upto = launched + BFS_CHUNK < level_cap ? launched + BFS_CHUNK : level_cap;
+    for (int level = launched + 1; level <= upto; level++) {
+      if (!pull_ready) {  // (whole builds make the reverse CSR eagerly; legacy builds on first use)
+        GG_TRY(ensure_reverse(ctx, csr));
+        pull_ready = true;
+      }
+      GG_LAUNCH(ctx, "bfs_compact", k_bfs_compact_dev, dim3(vgrid), dim3(256), 0, (const BfsStep *)steps, (uint32_t)level,
+                csr->E, fa, fb, V, active, cursors);
+      GG_LAUNCH(ctx, "bfs_push", k_bfs_push_dev, dim3(push_grid), dim3(256), 0, (const BfsStep *)steps, (uint32_t)level,
+                csr->E, fa, fb, (const uint32_t *)active, (const uint64_t *)seen, csr->off, csr->nbr);
+      GG_LAUNCH(ctx, "bfs_update", (k_bfs_update_dev<DistT>), dim3(vgrid), dim3(256), 0, steps, (uint32_t)level, csr->E, fa,
+                fb, seen, V, csr->off, dist8);
+      GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull_dev<DistT>), dim3(pull_grid), dim3(256), 0, steps, (uint32_t)level, csr->E, fa,
+                fb, seen, V, csr->off, csr->roff, csr->rnbr, dist8);
     }
-    st.levels++;
-    st.active_vertices += h.n_active;
-    st.traversed_edges += h.te;
-    GG_HIP(hipMemsetAsync(lv, 0, 2 * sizeof(unsigned long long), s));  // reached keeps accumulating
-    level++;
-    const bool pull = h.te * 16 > csr->E;  // heavy frontier: gather instead of scatter
-    if (pull) {
-      GG_TRY(ensure_reverse(ctx, csr));
-      const uint64_t quads = (V + 3) / 4;  // four vertices per wavefront
-      uint64_t waves = quads < max_waves ? quads : max_waves;
-      GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull<DistT>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, front, other,
-                seen, V, (uint32_t)level, csr->off, csr->roff, csr->rnbr, dist8, lv);
-      // the old frontier becomes the spare buffer and must be zero again for a later push level
-      GG_HIP(hipMemsetAsync(front, 0, V * sizeof(uint64_t), s));
-      uint64_t *t = front;
-      front = other;
-      other = t;
-    } else {
-      GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s));
-      GG_LAUNCH(ctx, "bfs_compact", k_bfs_compact, dim3(vgrid), dim3(256), 0, front, V, active, cursor);
-      uint64_t waves = h.n_active < max_waves ? h.n_active : max_waves;
-      GG_LAUNCH(ctx, "bfs_push", k_bfs_push, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, active,
-                (uint64_t)h.n_active, front, seen, csr->off, csr->nbr, other);
-      GG_LAUNCH(ctx, "bfs_update", (k_bfs_update<DistT>), dim3(vgrid), dim3(256), 0, front, seen, other, V, (uint32_t)level,
-                csr->off, dist8, lv);
+    launched = upto;
+    GG_HIP(hipMemcpyAsync(host_steps.data(), steps, (size_t)(launched + 1) * sizeof(BfsStep), hipMemcpyDeviceToHost, s));
+    GG_HIP(hipStreamSynchronize(s));
+    // level L ran iff the frontier it started from (steps[L - 1]) was not empty
+    int ran = 0;
+    while (ran < launched && host_steps[ran].n_active != 0) ran++;
+    const bool frontier_left = ran == launched && host_steps[launched].n_active != 0;
+    if (!frontier_left || launched == level_cap) {
+      st.levels = (uint32_t)ran;
+      reached = 0;
+      for (int l = 0; l <= ran; l++) reached += host_steps[l].reached;
+      for (int l = 0; l < ran; l++) {
+        st.active_vertices += host_steps[l].n_active;
+        st.traversed_edges += host_steps[l].te;
+      }
+      // the deepest recordable level is reached with work left and the caller did not bound the search there
+      if (frontier_left && launched == MAX_LEVEL && (max_hops < 0 || max_hops > MAX_LEVEL)) *overflow = true;
+      break;
     }
   }
   st.reached_pairs = reached;
@@ -471,8 +636,8 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   ctx->dev_free(fb);
   ctx->dev_free(seen);
   ctx->dev_free(dist8);
-  ctx->dev_free(lv);
-  ctx->dev_free(cursor);
+  ctx->dev_free(steps);
+  ctx->dev_free(cursors);
   if (stats) *stats = st;
   return rc;
 }
