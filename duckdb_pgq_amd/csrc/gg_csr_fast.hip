@@ -98,7 +98,7 @@ struct FastGeom {
 };
 
 // ---- D: densify + per-tile bucket histograms of both directions ---------------------------------------------
-// counts[(dir * nbuckets + bucket) * nblocks + tile]
+// counts[tile * 2 nb + dir * nb + bucket]: tile-major, one contiguous 2 nb row per tile
 template <int MODE>
 __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                              uint64_t E, uint64_t base, const HtSlot *__restrict__ ht, uint64_t cap,
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_densify_pairs(
     densify_tile<DICT_WIDE16>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < 2 * nb; i += FB_THREADS)
-    counts[(uint64_t)i * nblocks + blockIdx.x] = hist[i];  // i = dir * nb + bucket
+    counts[(uint64_t)blockIdx.x * 2 * nb + i] = hist[i];  // i = dir * nb + bucket
 }
 
 // ---- A: two stable bucket partitions from one read of the pairs ---------------------------------------------
@@ -218,9 +218,8 @@ template <bool PACK, bool ROWID, int STOP = 0>  // STOP > 0: timing probes that 
 __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
     const u32x2 *__restrict__ pairs, uint64_t E, FastGeom g, uint64_t nblocks, const uint32_t *__restrict__ bases,
     const BuildStatus *__restrict__ st, uint32_t *__restrict__ out_f, uint32_t *__restrict__ out_r,
-    uint32_t *__restrict__ epos_f, const unsigned long long *__restrict__ err) {
+    uint32_t *__restrict__ epos_f) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  if (*err) return;  // scan error: see k_bucket_starts
   const uint32_t nb = 1u << g.hb;
   uint32_t *xw = lds;                                   // staged words (PACK) or low keys
   uint32_t *xp = xw + FB_TILE;                          // staged payloads (!PACK)
@@ -248,7 +247,6 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 #endif
   const uint64_t tile_base = tile * FB_TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t kept = (uint32_t)st->kept;
   const uint32_t low_mask = (1u << g.low) - 1u;
 
   uint32_t u[FB_ITEMS], v[FB_ITEMS];
@@ -283,7 +281,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
       if (u[it] != INVALID_U32) atomicAdd(&myh[key >> g.low], 1u);
     }
     __syncthreads();
-    // per bucket: wave counts -> exclusive offsets across waves; bucket totals -> exclusive scan = dbase
+    // per bucket: wave counts -> staged-slot cursors (first staged slot of the bucket + the waves before); the
+    // tile's global positions come from the column kernels' bases (tile-major: one coalesced row per direction)
     {
       const uint32_t dpt = (nb + FB_THREADS - 1) / FB_THREADS;  // buckets per thread (1 or 2)
       uint32_t tot[2] = {0, 0};
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
         if (d < nb) {
           uint32_t t = 0;
 #pragma unroll
-          for (int w = 0; w < FB_WAVES; w++) {
+          for (int w = 0; w < FB_WAVES; w++) {  // counts -> exclusive offsets across the waves
             const uint32_t c = hw[w * nb + d];
             hw[w * nb + d] = t;
             t += c;
@@ -320,8 +319,9 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
       for (uint32_t q = 0; q < dpt; q++) {
         const uint32_t d = threadIdx.x * dpt + q;
         if (d < nb) {
-          dbase[d] = ex;
-          gb[d] = bases[(uint64_t)(dir * nb + d) * nblocks + tile] - (dir ? kept : 0u) - ex;
+          gb[d] = bases[tile * 2 * nb + (uint64_t)dir * nb + d] - ex;
+#pragma unroll
+          for (int w = 0; w < FB_WAVES; w++) hw[w * nb + d] += ex;  // ... + the bucket's first staged slot
           ex += tot[q];
         }
       }
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
       }
 #endif
       if (valid) {
-        const uint32_t pos = dbase[d] + cur[d] + __popcll(m & lane_lt);
+        const uint32_t pos = cur[d] + __popcll(m & lane_lt);
         if (PACK) {
           xw[pos] = ((key & low_mask) << g.key_bits) | pay;
         } else {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
         xd[pos] = (uint16_t)d;
       }
       __builtin_amdgcn_wave_barrier();
-      if (valid && (m & lane_lt) == 0) cur[d] += __popcll(m);  // lowest lane of each bucket group
+      if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));  // lowest lane of each group
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -401,31 +401,91 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 constexpr int LEAF_WAVES = 4;    // waves (= leaves) per workgroup of k_leaf_rows
 constexpr int LEAF_MAXS = 24;    // 64-entry steps a wave keeps in registers
 
-// bucket boundaries of both directions from the scanned counters, the chunk table, kept-edge count.
+// ---- column kernels: counters -> global positions ----------------------------------------------------------------
+// counts[tile][2 nb] (tile-major) must become bases[tile][c] = start of column c (its direction's bucket start)
+// + the counts of the earlier tiles in column c.  Three small kernels over groups of `gsz` tiles:
+//   k_col_partial  partial[g][c] = sum of the group's counts in column c
+//   k_col_scan     (one workgroup) partial[g][c] <- bucket start + sums of the earlier groups; bucket starts, chunk
+//                  table and kept-edge count on the way (every figure the kernels below need)
+//   k_col_apply    counts[tile][c] <- partial[g][c] + counts of the group's earlier tiles, in place
+// Every access is a coalesced row.  (The first version kept the counters bucket-major for a chained scan: D wrote
+// and A read 1024 separate lines per tile, as many bytes again as A's payload.)
 //   bstart[dir * (nb + 1) + j]   first position of bucket j in that direction's partitioned array
 //   cstart[i], i = dir * nb + j  first chunk of bucket i (cstart[2 nb] = number of chunks)
 //   part_of[p]                   bucket i of chunk p
-__global__ __launch_bounds__(256) void k_bucket_starts(const uint32_t *__restrict__ bases, uint64_t nblocks,
-                                                       uint32_t nb, const uint64_t *__restrict__ total,
-                                                       uint32_t *__restrict__ bstart, uint32_t *__restrict__ cstart,
-                                                       uint32_t *__restrict__ part_of, BuildStatus *__restrict__ st,
-                                                       const unsigned long long *__restrict__ err) {
-  __shared__ uint32_t s_b[2 * ((1 << FB_MAX_HB) + 1)];
-  if (*err) {  // the scan gave up: its prefixes are too small, positions derived from them could leave the arrays
-    for (uint32_t i = threadIdx.x; i <= 2 * nb; i += 256) cstart[i] = 0;  // no chunks: the kernels below do nothing
-    return;
+__global__ __launch_bounds__(1024) void k_col_partial(const uint32_t *__restrict__ counts, uint64_t nblocks,
+                                                     uint32_t ncol, uint32_t gsz, uint32_t *__restrict__ partial,
+                                                     uint32_t *__restrict__ coltot /* [ncol], zeroed */) {
+  const uint64_t t0 = (uint64_t)blockIdx.x * gsz, t1 = t0 + gsz < nblocks ? t0 + gsz : nblocks;
+  for (uint32_t c = threadIdx.x; c < ncol; c += 1024) {
+    uint32_t sum = 0;
+    for (uint64_t tb = t0; tb < t1; tb += 16) {
+      uint32_t v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = tb + q < t1 ? counts[(tb + q) * ncol + c] : 0u;
+#pragma unroll
+      for (int q = 0; q < 16; q++) sum += v[q];
+    }
+    partial[(uint64_t)blockIdx.x * ncol + c] = sum;
+    if (sum) atomicAdd(&coltot[c], sum);  // integer adds: the total does not depend on their order
   }
-  __shared__ uint32_t s_w[4];
-  const uint32_t kept = (uint32_t)(*total / 2);  // both directions count the same rows
-  for (uint32_t i = threadIdx.x; i < 2 * (nb + 1); i += 256) {
-    const uint32_t dir = i / (nb + 1), j = i % (nb + 1);
-    const uint32_t pos = j < nb ? bases[(uint64_t)(dir * nb + j) * nblocks] : (dir ? 2 * kept : kept);
-    s_b[i] = pos - (dir ? kept : 0u);
-    bstart[i] = s_b[i];
+}
+
+// one workgroup: bucket starts of both directions (scan of the column totals), chunk table, kept-edge count
+__global__ __launch_bounds__(1024) void k_col_scan(uint32_t *__restrict__ coltot /* in: totals, out: starts */,
+                                                   uint32_t nb, uint32_t *__restrict__ bstart,
+                                                   uint32_t *__restrict__ cstart, uint32_t *__restrict__ part_of,
+                                                   BuildStatus *__restrict__ st) {
+  __shared__ uint32_t s_b[2 * ((1 << FB_MAX_HB) + 1)];  // bucket starts, both directions
+  __shared__ uint32_t s_w[2][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // thread j owns bucket j of BOTH directions (nb <= 1024)
+  uint32_t tot[2] = {0, 0};
+  if (threadIdx.x < nb) {
+    tot[0] = coltot[threadIdx.x];
+    tot[1] = coltot[nb + threadIdx.x];
+  }
+  uint32_t incl[2] = {tot[0], tot[1]};
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t a = __shfl_up(incl[0], o, 64), b = __shfl_up(incl[1], o, 64);
+    if (lane >= o) {
+      incl[0] += a;
+      incl[1] += b;
+    }
+  }
+  if (lane == 63) {
+    s_w[0][wave] = incl[0];
+    s_w[1][wave] = incl[1];
   }
   __syncthreads();
-  // chunks per bucket, exclusive scan over the 2 nb buckets (8 consecutive buckets per thread)
-  const uint32_t per = (2 * nb + 255) / 256;
+  uint32_t ex[2] = {incl[0] - tot[0], incl[1] - tot[1]}, all[2] = {0, 0};
+  for (int w = 0; w < 16; w++) {
+    if (w < wave) {
+      ex[0] += s_w[0][w];
+      ex[1] += s_w[1][w];
+    }
+    all[0] += s_w[0][w];
+    all[1] += s_w[1][w];
+  }
+  if (threadIdx.x < nb) {
+    for (int dir = 0; dir < 2; dir++) {
+      s_b[dir * (nb + 1) + threadIdx.x] = ex[dir];
+      bstart[dir * (nb + 1) + threadIdx.x] = ex[dir];
+      coltot[dir * nb + threadIdx.x] = ex[dir];  // k_col_apply starts every column from its bucket start
+    }
+  }
+  if (threadIdx.x == 0) {
+    for (int dir = 0; dir < 2; dir++) {
+      s_b[dir * (nb + 1) + nb] = all[dir];
+      bstart[dir * (nb + 1) + nb] = all[dir];
+    }
+    st->kept = all[0];  // both directions count the same rows
+    st->kept_rev = all[1];
+  }
+  __syncthreads();
+  // chunks per bucket, exclusive scan over the 2 nb buckets (consecutive buckets per thread), chunk -> bucket table
+  const uint32_t per = (2 * nb + 1023) / 1024;
   uint32_t mine = 0;
   for (uint32_t q = 0; q < per; q++) {
     const uint32_t i = threadIdx.x * per + q;
@@ -435,32 +495,58 @@ __global__ __launch_bounds__(256) void k_bucket_starts(const uint32_t *__restric
       mine += (len + FB_TILE - 1) / FB_TILE;
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = mine;
+  uint32_t cincl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
+    const uint32_t t = __shfl_up(cincl, o, 64);
+    if (lane >= o) cincl += t;
   }
-  if (lane == 63) s_w[wave] = incl;
   __syncthreads();
-  uint32_t ex = incl - mine;
-  for (int w = 0; w < wave; w++) ex += s_w[w];
+  if (lane == 63) s_w[0][wave] = cincl;
+  __syncthreads();
+  uint32_t cex = cincl - mine;
+  for (int w = 0; w < wave; w++) cex += s_w[0][w];
   for (uint32_t q = 0; q < per; q++) {
     const uint32_t i = threadIdx.x * per + q;
     if (i < 2 * nb) {
       const uint32_t dir = i / nb, j = i % nb;
       const uint32_t len = s_b[dir * (nb + 1) + j + 1] - s_b[dir * (nb + 1) + j];
       const uint32_t n = (len + FB_TILE - 1) / FB_TILE;
-      cstart[i] = ex;
-      for (uint32_t c = 0; c < n; c++) part_of[ex + c] = i;  // stores are not waited for: cheap even for one huge bucket
-      ex += n;
+      cstart[i] = cex;
+      for (uint32_t c = 0; c < n; c++) part_of[cex + c] = i;  // stores are not waited for: cheap even for one huge bucket
+      cex += n;
     }
   }
-  if (threadIdx.x == 255) cstart[2 * nb] = ex;
-  if (threadIdx.x == 0) {
-    st->kept = kept;
-    st->kept_rev = kept;
+  if (threadIdx.x == 1023) cstart[2 * nb] = cex;
+}
+
+// bases in place: counts[tile][c] <- bucket start + counts of every earlier tile in column c.  A group adds up the
+// partial rows of the groups before it (L2-resident: the whole matrix is ~1 MB) instead of waiting for a scan.
+__global__ __launch_bounds__(1024) void k_col_apply(uint32_t *__restrict__ counts, uint64_t nblocks, uint32_t ncol,
+                                                    uint32_t gsz, const uint32_t *__restrict__ partial,
+                                                    const uint32_t *__restrict__ colstart) {
+  const uint64_t t0 = (uint64_t)blockIdx.x * gsz, t1 = t0 + gsz < nblocks ? t0 + gsz : nblocks;
+  for (uint32_t c = threadIdx.x; c < ncol; c += 1024) {
+    uint32_t run = colstart[c];
+    uint32_t g = 0;
+    for (; g + 8 <= blockIdx.x; g += 8) {  // eight independent row reads in flight
+      uint32_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = partial[(uint64_t)(g + q) * ncol + c];
+#pragma unroll
+      for (int q = 0; q < 8; q++) run += v[q];
+    }
+    for (; g < blockIdx.x; g++) run += partial[(uint64_t)g * ncol + c];
+    uint32_t v[16];
+    for (uint64_t tb = t0; tb < t1; tb += 16) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = tb + q < t1 ? counts[(tb + q) * ncol + c] : 0u;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if (tb + q < t1) counts[(tb + q) * ncol + c] = run;
+        run += v[q];
+      }
+    }
   }
 }
 
@@ -592,9 +678,7 @@ __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ bstart,
                                                    const uint32_t *__restrict__ cstart, FastGeom g, uint64_t V,
                                                    uint32_t *__restrict__ substart, uint32_t *__restrict__ off,
-                                                   uint32_t *__restrict__ roff,
-                                                   const unsigned long long *__restrict__ err) {
-  if (*err) return;  // scan error: see k_bucket_starts
+                                                   uint32_t *__restrict__ roff) {
   const uint32_t nb = 1u << g.hb, i = blockIdx.x, dir = i / nb, j = i % nb;
   const int lane = threadIdx.x;
   const uint32_t p0 = cstart[i], p1 = cstart[i + 1];
@@ -619,9 +703,8 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
     const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ offs,
     const uint32_t *__restrict__ substart, FastGeom g, uint64_t V, uint32_t *__restrict__ off,
     uint32_t *__restrict__ nbr, uint32_t *__restrict__ epos, uint32_t *__restrict__ roff,
-    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow, const unsigned long long *__restrict__ err) {
+    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  if (*err) return;  // scan error: see k_bucket_starts
   const uint32_t nb = 1u << g.hb, nsub = 1u << g.sub, leafW = 1u << g.leaf;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t unit = blockIdx.x * LEAF_WAVES + wave;  // (bucket i, sub s): waves are independent from here on
@@ -778,7 +861,7 @@ static int bits_of(uint64_t v) {  // bits needed for values 0..v
 int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   *taken = 0;
   const uint64_t V = csr->V, E = csr->E_cap;
-  if (E == 0 || V == 0 || E >= (1ull << 31)) return GG_OK;  // positions of both directions share one u32 scan
+  if (E == 0 || V == 0 || E >= 0xFFFFFFFFull) return GG_OK;  // positions are u32
   FastGeom g;
   int kb = bits_of(V - 1);
   if (kb < 1) kb = 1;
@@ -840,15 +923,24 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev, ctx->c_dst.dev, E,
             csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab, (const DirectMap *)dm,
             pairs, g, nblocks64, counts);
-  GG_TRY(scan_exclusive_u32(ctx, counts, counts, ncount, total));
   const uint64_t pmax = 2 * (nblocks64 + nb);  // chunks: every bucket may end in a partial one
-  uint32_t *cstart = nullptr, *part_of = nullptr, *offs = nullptr, *substart = nullptr;
+  uint32_t *cstart = nullptr, *part_of = nullptr, *offs = nullptr, *substart = nullptr, *partial = nullptr;
+  const uint32_t ncol = 2 * nb;
+  uint32_t gsz = 16;  // tiles per group of the column kernels; at most 512 groups for the single-workgroup step
+  while ((nblocks64 + gsz - 1) / gsz > 512) gsz *= 2;
+  const uint32_t ngroups = (uint32_t)((nblocks64 + gsz - 1) / gsz);
   GG_TRY(ctx->dev_alloc((void **)&cstart, (2 * nb + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&offs, pmax * 65 * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * 65 * sizeof(uint32_t)));
-  GG_LAUNCH(ctx, "bucket_starts", k_bucket_starts, dim3(1), dim3(256), 0, (const uint32_t *)counts, nblocks64, nb,
-            (const uint64_t *)total, bstart, cstart, part_of, st, (const unsigned long long *)ctx->dev_err);
+  GG_TRY(ctx->dev_alloc((void **)&partial, ((uint64_t)ngroups + 1) * ncol * sizeof(uint32_t)));
+  uint32_t *coltot = partial + (uint64_t)ngroups * ncol;  // column totals, then column (= bucket) starts
+  GG_HIP(hipMemsetAsync(coltot, 0, ncol * sizeof(uint32_t), s));
+  GG_LAUNCH(ctx, "col_partial", k_col_partial, dim3(ngroups), dim3(1024), 0, (const uint32_t *)counts, nblocks64, ncol, gsz,
+            partial, coltot);
+  GG_LAUNCH(ctx, "col_scan", k_col_scan, dim3(1), dim3(1024), 0, coltot, nb, bstart, cstart, part_of, st);
+  GG_LAUNCH(ctx, "col_apply", k_col_apply, dim3(ngroups), dim3(1024), 0, counts, nblocks64, ncol, gsz,
+            (const uint32_t *)partial, (const uint32_t *)coltot);
 
   // ---- A ----------------------------------------------------------------------------------------------------
   const size_t words = g.pack ? 1 : 2;
@@ -872,7 +964,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));                                \
   GG_LAUNCH(ctx, "partition_dual", (k_partition_dual<P, R>), dim3(grid_a), dim3(FB_THREADS), lds_a,                  \
             (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r, \
-            epos_f, (const unsigned long long *)ctx->dev_err)
+            epos_f)
 #ifdef GG_FB_PROBES
   if (g.pack && !rowid) {
     GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 1>),
@@ -883,13 +975,13 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     GG_LAUNCH(ctx, "probe_A_loads", (k_partition_dual<true, false, 1>), dim3(grid_a), dim3(FB_THREADS), lds_a,
               (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f, (const unsigned long long *)ctx->dev_err);
+              epos_f);
     GG_LAUNCH(ctx, "probe_A_counts", (k_partition_dual<true, false, 2>), dim3(grid_a), dim3(FB_THREADS), lds_a,
               (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f, (const unsigned long long *)ctx->dev_err);
+              epos_f);
     GG_LAUNCH(ctx, "probe_A_rank", (k_partition_dual<true, false, 3>), dim3(grid_a), dim3(FB_THREADS), lds_a,
               (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f, (const unsigned long long *)ctx->dev_err);
+              epos_f);
   }
 #endif
   if (g.pack && rowid) {
@@ -913,12 +1005,11 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_LAUNCH(ctx, "sub_sort", (k_sub_sort<P, R>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, epos_f, \
             (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint32_t *)part_of, g, offs);                    \
   GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,                         \
-            (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff,                    \
-            (const unsigned long long *)ctx->dev_err);                                                                  \
+            (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);                   \
   GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<P, R>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,                          \
             (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,     \
             (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,     \
-            csr->epos, csr->roff, csr->rnbr, csr->rrow, (const unsigned long long *)ctx->dev_err)
+            csr->epos, csr->roff, csr->rnbr, csr->rrow)
   if (g.pack && rowid) {
     GG_FB_LAUNCH_B(true, true);
   } else if (g.pack) {
@@ -932,7 +1023,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
 
   for (void *p : {(void *)dm, (void *)dir, (void *)tab, (void *)pairs, (void *)counts, (void *)bstart, (void *)total,
                   (void *)part_f, (void *)part_r, (void *)epos_f, (void *)cstart, (void *)part_of, (void *)offs,
-                  (void *)substart})
+                  (void *)substart, (void *)partial})
     ctx->dev_free(p);
   return GG_OK;
 }

@@ -820,7 +820,7 @@ def test_profile_select_times_only_the_named_kernels(gg, orc):
     c = gg.build_csr()
     c.close()
     gg.profile(False)
-    assert {"ht_insert", "densify_pairs", "partition_dual", "scan_chained", "sub_sort", "leaf_rows"} <= set(gg.profile_get())
+    assert {"ht_insert", "densify_pairs", "col_scan", "partition_dual", "sub_sort", "leaf_rows"} <= set(gg.profile_get())
     gg.force_legacy_build(True)
     try:
         gg.profile_reset()
@@ -918,30 +918,37 @@ def test_bucketed_build_and_multipass_build_both_equal_the_oracle(gg, orc, kind,
         gg.set_edge_rowid(True)
 
 
-@pytest.mark.parametrize("legacy", [False, True])
-def test_a_scan_tile_that_never_publishes_is_an_error_not_a_wrong_csr(gg, orc, legacy):
-    """The chained prefix scan bounds its look-back spin.  If a predecessor tile never publishes (injected here),
-    the tiles behind it give up — and the build must fail with GG_ERR_HIP instead of returning offsets computed
-    from a wrong prefix.  Afterwards the context works again."""
+def test_a_scan_tile_that_never_publishes_is_an_error_not_a_wrong_csr(gg, orc):
+    """The chained prefix scan (multi-pass build, frontier offsets, BFS row compaction) bounds its look-back spin.
+    If a predecessor tile never publishes (injected here), the tiles behind it give up — and the call must fail
+    with GG_ERR_HIP instead of returning offsets computed from a wrong prefix; kernels after the scan do nothing.
+    Afterwards the context works again.  (The bucketed build has no chained scan: it is not affected.)"""
     from duckdb_pgq_amd import GGError
 
     vid, src, dst = datagen.ldbc_knows(20_000, 1_500_000, 5)
-    gg.force_legacy_build(legacy)
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
     try:
         gg.staging_clear()
         gg.append_vertices(vid)
         gg.append_edges(src, dst)
         gg.scan_fault(spin_limit=64, mute_tile=1)
+        csr = gg.build_csr()  # bucketed build: column sums instead of a chained scan
+        assert_csr_equal(csr, g)
+        with pytest.raises(GGError) as e:  # k >= 3 from a source list: frontier offsets come from the chained scan
+            gg.expand_khop(csr, 1, 3, sources=vid[:5000])
+        assert e.value.code == -2 and "scan" in str(e.value)
+        csr.close()
+        gg.force_legacy_build(True)
         with pytest.raises(GGError) as e:
             gg.build_csr()
         assert e.value.code == -2 and "scan" in str(e.value)
         gg.scan_fault()
         csr = gg.build_csr()
-        rc, g = orc.csr_build(vid, src, dst)
-        assert rc == 0
         assert_csr_equal(csr, g)
+        assert gg.expand_khop(csr, 1, 3, sources=vid[:5000]) == g.khop(1, 3, sources_dense=g.lookup(vid[:5000]).astype(np.uint32))
         csr.close()
-        g.close()
     finally:
         gg.scan_fault()
         gg.force_legacy_build(False)
+        g.close()
