@@ -687,14 +687,14 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
 
   // whole graphs of up to 2^22 vertices: forward and reverse CSR by the bucketed build (gg_csr_fast.hip)
   int fast = 0;
-  if (!shard && !ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));
+  if (!ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));
   if (!fast) GG_TRY(ctx->dev_alloc((void **)&csr->row, (E ? E : 1) * sizeof(uint32_t)));
 
   unsigned long long *kept_dev = nullptr, *kept_rev_dev = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
   GG_HIP(hipMemsetAsync(kept_dev, 0, sizeof(unsigned long long), s));
   uint32_t *rkey_sorted = nullptr;
-  if (shard) {
+  if (shard && !fast) {
     GG_TRY(ctx->dev_alloc((void **)&kept_rev_dev, sizeof(unsigned long long)));
     GG_HIP(hipMemsetAsync(kept_rev_dev, 0, sizeof(unsigned long long), s));
     GG_TRY(ctx->dev_alloc((void **)&csr->roff, (V + 1) * sizeof(uint32_t)));
@@ -765,7 +765,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
     ctx->dev_free(rk);
     ctx->dev_free(rv);
   }
-  if (shard) {
+  if (shard && !fast) {
     GG_LAUNCH(ctx, "row_offsets", k_row_offsets, dim3((unsigned)(((E ? E : 1) + 1023) / 1024)), dim3(256), 0,
               rkey_sorted, (uint64_t)0, (const unsigned long long *)kept_rev_dev, V, csr->roff, (const unsigned long long *)ctx->dev_err);
   }

@@ -95,7 +95,12 @@ struct FastGeom {
   uint32_t pack;      // 1: B's input is one u32 word low(key) << key_bits | payload
   uint32_t sub;       // low = (sub, leaf): sub-bucket bits (<= 6) ...
   uint32_t leaf;      // ... and vertex-in-leaf bits (<= 6)
+  uint32_t part;      // shard builds (gg_csr_build_shard): forward rows of owned sources, reverse rows of owned
+  uint32_t n_parts;   // destinations only; 1: whole graph
 };
+// Shard builds mark, in the dense pair, the direction a row does not take part in: bit 31 of u = "source not
+// owned: no forward entry", bit 31 of v = "destination not owned: no reverse entry" (dense indices stay below 2^22).
+constexpr uint32_t FB_SKIP = 0x80000000u;
 
 // ---- D: densify + per-tile bucket histograms of both directions ---------------------------------------------
 // counts[tile * 2 nb + dir * nb + bucket]: tile-major, one contiguous 2 nb row per tile
@@ -105,7 +110,8 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
                                              int64_t min_idx, const uint32_t *__restrict__ dir,
                                              const unsigned long long *__restrict__ tab,
                                              const DirectMap *__restrict__ dm, u32x2 *__restrict__ pairs,
-                                             uint32_t low, uint32_t *hist_f, uint32_t *hist_r) {
+                                             uint32_t low, uint32_t part, uint32_t n_parts, uint32_t *hist_f,
+                                             uint32_t *hist_r) {
 #ifndef GG_FB_DB
 #define GG_FB_DB 4
 #endif
@@ -175,8 +181,16 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
         u = INVALID_U32;  // dropped: an endpoint is not a vertex (inner-join semantics)
         v = INVALID_U32;
       } else {
-        atomicAdd(&hist_f[u >> low], 1u);
-        atomicAdd(&hist_r[v >> low], 1u);
+        const bool fwd = owns(ks[j], part, n_parts), rev = owns(kd[j], part, n_parts);
+        if (fwd) atomicAdd(&hist_f[u >> low], 1u);
+        if (rev) atomicAdd(&hist_r[v >> low], 1u);
+        if (!fwd && !rev) {
+          u = INVALID_U32;  // a row of other shards only
+          v = INVALID_U32;
+        } else {
+          u |= fwd ? 0u : FB_SKIP;
+          v |= rev ? 0u : FB_SKIP;
+        }
       }
       u32x2 pr;
       pr.x = u;
@@ -199,13 +213,17 @@ __global__ __launch_bounds__(FB_THREADS) void k_densify_pairs(
   const uint64_t base = (uint64_t)blockIdx.x * FB_TILE;
   const unsigned long long mode = PROBE ? 99ULL : dm->mode;  // uniform over the grid
   if (PROBE)
-    densify_tile<99>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+    densify_tile<99>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part, g.n_parts, hist,
+                          hist + nb);
   else if (mode == DICT_DIRECT)
-    densify_tile<DICT_DIRECT>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+    densify_tile<DICT_DIRECT>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part, g.n_parts, hist,
+                          hist + nb);
   else if (mode == DICT_PACKED8)
-    densify_tile<DICT_PACKED8>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+    densify_tile<DICT_PACKED8>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part, g.n_parts, hist,
+                          hist + nb);
   else
-    densify_tile<DICT_WIDE16>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, hist, hist + nb);
+    densify_tile<DICT_WIDE16>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part, g.n_parts, hist,
+                          hist + nb);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < 2 * nb; i += FB_THREADS)
     counts[(uint64_t)blockIdx.x * 2 * nb + i] = hist[i];  // i = dir * nb + bucket
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 #pragma unroll
     for (int it = 0; it < FB_ITEMS; it++) {
       const uint32_t key = dir ? v[it] : u[it];
-      if (u[it] != INVALID_U32) atomicAdd(&myh[key >> g.low], 1u);
+      if (u[it] != INVALID_U32 && !(key & FB_SKIP)) atomicAdd(&myh[key >> g.low], 1u);
     }
     __syncthreads();
     // per bucket: wave counts -> staged-slot cursors (first staged slot of the bucket + the waves before); the
@@ -334,8 +352,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
     volatile uint32_t *cur = myh;
 #pragma unroll
     for (int it = 0; it < FB_ITEMS; it++) {
-      const bool valid = u[it] != INVALID_U32;
-      const uint32_t key = dir ? v[it] : u[it], pay = dir ? u[it] : v[it];
+      const uint32_t key = dir ? v[it] : u[it], pay = (dir ? u[it] : v[it]) & ~FB_SKIP;
+      const bool valid = u[it] != INVALID_U32 && !(key & FB_SKIP);  // (shards: this direction's endpoint is owned)
       const uint32_t d = valid ? key >> g.low : 0u;
 #if GG_FB_MATCH_OR
       const uint64_t m = match_or(mm, d, valid, lane);
@@ -865,20 +883,29 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   FastGeom g;
   int kb = bits_of(V - 1);
   if (kb < 1) kb = 1;
-  int low = kb - 9;
-  if (low < 6) low = kb < 6 ? kb : 6;
-  if (low > FB_MAX_LOW) low = FB_MAX_LOW;
-  const int hb = kb - low;
-  if (hb > FB_MAX_HB) return GG_OK;  // more than 2^22 vertices: the multi-pass build
+  // Geometry: key = (bucket: hb bits)(sub-bucket: sub bits)(leaf vertex: leaf bits).  A leaf is finished by one
+  // wave, so it should hold about a thousand entries: 2^(hb + sub) ~ entries / 1024..2048, where a shard expects about
+  // half of its local rows per direction.  leaf <= 6 bits (one lane per vertex), sub <= 6, hb <= FB_MAX_HB.
+  const uint64_t expect = csr->n_parts > 1 ? E / 2 : E;
+  int lb = bits_of(expect / 2048);               // log2 of the number of leaves wanted (600-1200 entries each)
+  if (lb < kb - 6) lb = kb - 6;                  // leaf <= 6 bits
+  if (lb > kb) lb = kb;                          // at most one leaf per vertex
+  if (lb < 0) lb = 0;
+  int sub = lb < 6 ? lb : 6;
+  int hb = lb - sub;
+  if (hb > FB_MAX_HB) return GG_OK;              // more than 2^22 vertices: the multi-pass build
+  const int low = kb - hb;
   g.key_bits = (uint32_t)kb;
   g.low = (uint32_t)low;
   g.hb = (uint32_t)hb;
   g.pack = (low + kb <= 32) ? 1u : 0u;
-  g.sub = (uint32_t)(low < 6 ? low : 6);
-  g.leaf = (uint32_t)low - g.sub;
+  g.sub = (uint32_t)sub;
+  g.leaf = (uint32_t)(low - sub);
+  g.part = (uint32_t)csr->part;
+  g.n_parts = (uint32_t)csr->n_parts;
   *taken = 1;
   const uint32_t nb = 1u << hb;
-  const bool rowid = ctx->keep_edge_rowid;
+  const bool rowid = ctx->keep_edge_rowid && csr->n_parts <= 1;  // a shard only serves 2-hop counting and BFS: no rowids
   hipStream_t s = ctx->stream;
   const uint64_t nblocks64 = (E + FB_TILE - 1) / FB_TILE;
   const unsigned nblocks = (unsigned)nblocks64;

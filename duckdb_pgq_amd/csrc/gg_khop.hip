@@ -248,6 +248,9 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced) and every
 // staged state of the run is folded against it (LDS broadcast read + 4 VALU ops per walk).  The kernel
 // is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
+#ifndef GG_MID_PIPE
+#define GG_MID_PIPE 1
+#endif
 constexpr int MID_R = 8;  // out-row values per lane per J-block: a J-block covers 64*MID_R = 512 leaves
 
 #define GG_XAD(acc, q, t) asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(q), "v"(t))
@@ -263,6 +266,31 @@ __device__ __forceinline__ void mid_fold(uint32_t q, const uint32_t (&t)[MID_R],
 template <int NREG>
 __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int ib, const uint32_t (&t)[MID_R],
                                                uint32_t (&acc)[MID_R]) {
+#if GG_MID_PIPE
+  // the slice bounds are the same in every lane: scalar loop control; states are read four at a time with one
+  // 16-byte LDS broadcast read, the next four already in flight while the current ones are folded
+  ia = __builtin_amdgcn_readfirstlane(ia);
+  ib = __builtin_amdgcn_readfirstlane(ib);
+  int i = ia;
+  for (; i < ib && (i & 3); i++) mid_fold<NREG>(s_q[i], t, acc);
+  if (i + 4 <= ib) {
+    uint4 cur = *reinterpret_cast<const uint4 *>(s_q + i);
+    for (; i + 8 <= ib; i += 4) {
+      const uint4 nxt = *reinterpret_cast<const uint4 *>(s_q + i + 4);
+      mid_fold<NREG>(cur.x, t, acc);
+      mid_fold<NREG>(cur.y, t, acc);
+      mid_fold<NREG>(cur.z, t, acc);
+      mid_fold<NREG>(cur.w, t, acc);
+      cur = nxt;
+    }
+    mid_fold<NREG>(cur.x, t, acc);
+    mid_fold<NREG>(cur.y, t, acc);
+    mid_fold<NREG>(cur.z, t, acc);
+    mid_fold<NREG>(cur.w, t, acc);
+    i += 4;
+  }
+  for (; i < ib; i++) mid_fold<NREG>(s_q[i], t, acc);
+#else
   int i = ia;
   for (; i + 4 <= ib; i += 4) {  // 4 states per trip: their LDS broadcast reads issue back to back
     const uint32_t q0 = s_q[i], q1 = s_q[i + 1], q2 = s_q[i + 2], q3 = s_q[i + 3];
@@ -272,6 +300,7 @@ __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int 
     mid_fold<NREG>(q3, t, acc);
   }
   for (; i < ib; i++) mid_fold<NREG>(s_q[i], t, acc);
+#endif
 }
 
 #ifndef GG_MID_EPT
@@ -281,7 +310,7 @@ constexpr int MID_EPT = GG_MID_EPT;    // reverse-CSR entries per thread
 constexpr int MT = XT * MID_EPT;       // entries per tile (workgroup): 512
 constexpr int MID_SEG = MID_EPT * (XT / 64);  // (entry slot, wave) segments of a tile, in position order
 
-struct MidShared {  // LDS image of one tile
+struct alignas(16) MidShared {  // LDS image of one tile
   uint32_t q[MT];          // low half of the hash state q_1 of each 1-hop row of the tile
   uint32_t pq[MT + 1];     // prefix sums (mod 2^32) of q: pq[i] = sum of q[0..i)
   uint32_t x[MT];          // middle vertex of each row
