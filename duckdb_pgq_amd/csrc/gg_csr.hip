@@ -675,19 +675,22 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   GG_TRY(ctx->dev_alloc((void **)&csr->epos, (E ? E : 1) * sizeof(uint32_t)));
   BuildStatus *st = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&st, sizeof(BuildStatus)));
-  BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL, 0ULL};
+  BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
   memcpy(ctx->pin_scratch, &init, sizeof(init));
   GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch, sizeof(init), hipMemcpyHostToDevice, s));
   if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-  GG_LAUNCH(ctx, "ht_init", k_ht_init, dim3((unsigned)((csr->ht_cap + 255) / 256)), dim3(256), 0, csr->ht,
-            csr->ht_cap);
-  if (V)
-    GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts);
-
-  // whole graphs of up to 2^22 vertices: forward and reverse CSR by the bucketed build (gg_csr_fast.hip)
+  // whole graphs and shards of up to 2^22 vertices: forward and reverse CSR by the bucketed build
+  // (gg_csr_fast.hip), which also picks and fills the id dictionary; the 16-byte table is then filled only if the
+  // densification needs it (ensure_ht does it later for gg_csr_lookup, source lists, the neighbour filter)
   int fast = 0;
   if (!ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));
+  if (!fast) {
+    GG_LAUNCH(ctx, "ht_init", k_ht_init, dim3((unsigned)((csr->ht_cap + 255) / 256)), dim3(256), 0, csr->ht,
+              csr->ht_cap);
+    if (V)
+      GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
+                csr->ht_cap, st, (uint32_t)part, (uint32_t)n_parts);
+  }
   if (!fast) GG_TRY(ctx->dev_alloc((void **)&csr->row, (E ? E : 1) * sizeof(uint32_t)));
 
   unsigned long long *kept_dev = nullptr, *kept_rev_dev = nullptr;
@@ -811,6 +814,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
     return GG_ERR_DUPLICATE_VERTEX;
   }
   csr->ht_min_idx = hs.min_idx;
+  csr->ht_built = !fast || hs.dict_mode == DICT_WIDE16;
   csr->E = hs.kept;
   csr->E_rev = hs.kept_rev;
   csr->owned_vertices = shard ? hs.owned : V;
@@ -830,6 +834,30 @@ extern "C" int gg_csr_build_shard(gg_ctx *ctx, int part, int n_parts, gg_csr **o
 }
 
 namespace gg {
+
+// The 16-byte id table of a CSR whose build did not need it (direct or packed dictionary): filled from csr->vid on
+// first use.  Duplicate ids cannot occur any more (the build checked); the sentinel id's index is read back.
+int ensure_ht(gg_ctx *ctx, gg_csr *csr) {
+  if (csr->ht_built) return GG_OK;
+  GG_HIP(hipSetDevice(ctx->device));
+  BuildStatus *st = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&st, sizeof(BuildStatus)));
+  BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+  memcpy(ctx->pin_scratch + 16, &init, sizeof(init));
+  GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch + 16, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  GG_LAUNCH(ctx, "ht_init", k_ht_init, dim3((unsigned)((csr->ht_cap + 255) / 256)), dim3(256), 0, csr->ht, csr->ht_cap);
+  if (csr->V)
+    GG_LAUNCH(ctx, "ht_insert", k_ht_insert, dim3((unsigned)((csr->V + 255) / 256)), dim3(256), 0,
+              (const int64_t *)csr->vid, csr->V, csr->ht, csr->ht_cap, st, 0u, 1u);
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch + 16, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  BuildStatus hs;
+  memcpy(&hs, ctx->pin_scratch + 16, sizeof(hs));
+  ctx->dev_free(st);
+  csr->ht_min_idx = hs.min_idx;
+  csr->ht_built = true;
+  return GG_OK;
+}
 
 // Reverse CSR from the forward COO view (row, nbr), which is sorted by (source, rowid): a stable sort
 // by destination leaves every in-neighbour list in ascending (source, rowid) order.

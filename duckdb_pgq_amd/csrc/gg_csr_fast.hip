@@ -40,7 +40,6 @@ constexpr int FB_ITEMS = GG_FB_ITEMS;            // edge rows per lane and tile
 constexpr int FB_TILE = FB_THREADS * FB_ITEMS;   // 8192 rows per workgroup (D and A share the tiling)
 constexpr int FB_WTILE = FB_TILE / FB_WAVES;     // contiguous rows per wave in A
 constexpr int FB_MAX_HB = 10;                    // bucket bits
-constexpr int FB_MAX_LOW = 12;                   // vertex-in-bucket bits (8 x 4096 x 4 B of LDS histograms in B)
 #ifndef GG_FB_LOAD_PCT
 #define GG_FB_LOAD_PCT 50                        // load factor of the packed dictionary, percent
 #endif
@@ -921,17 +920,20 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_TRY(ctx->dev_alloc((void **)&dm, sizeof(DirectMap)));
   GG_TRY(ctx->dev_alloc((void **)&dir, DIRECT_MAX_RANGE * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&tab, 2 * npairs * sizeof(unsigned long long)));
-  const DirectMap dm_init{INT64_MAX, INT64_MIN, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+  const DirectMap dm_init{INT64_MAX, INT64_MIN, 0ULL, (unsigned long long)DICT_PACKED8, 0ULL, 0ULL, 0ULL, 0ULL};
   memcpy(ctx->pin_scratch + 8, &dm_init, sizeof(dm_init));  // (the first words carry the BuildStatus seed)
   GG_HIP(hipMemcpyAsync(dm, ctx->pin_scratch + 8, sizeof(dm_init), hipMemcpyHostToDevice, s));
-  const unsigned mm_blocks = (V + 255) / 256 < 64 ? (unsigned)((V + 255) / 256) : 64u;
-  GG_LAUNCH(ctx, "id_minmax", k_id_minmax, dim3(mm_blocks), dim3(256), 0, csr->vid, V, dm);
-  GG_LAUNCH(ctx, "dict_decide", k_dict_decide, dim3(1), dim3(64), 0, dm, V, idx_bits, q);
-  GG_LAUNCH(ctx, "direct_init", k_direct_init, dim3((unsigned)(DIRECT_MAX_RANGE / 256)), dim3(256), 0, dir, dm);
-  GG_LAUNCH(ctx, "direct_fill", k_direct_fill, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, dir, dm);
-  GG_LAUNCH(ctx, "packed_init", k_packed_init, dim3((unsigned)((2 * npairs + 255) / 256)), dim3(256), 0, tab, dm);
-  GG_LAUNCH(ctx, "packed_insert", k_packed_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, tab,
-            dm);
+  {
+    uint64_t span = csr->ht_cap > 2 * npairs ? csr->ht_cap : 2 * npairs;
+    if (span < DIRECT_MAX_RANGE) span = DIRECT_MAX_RANGE;
+    if (span < V) span = V;
+    GG_LAUNCH(ctx, "dict_init", k_dict_init, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
+              csr->ht_cap, tab, 2 * npairs, dir, dm);
+    GG_LAUNCH(ctx, "dict_insert", k_dict_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
+              csr->ht_cap, tab, dir, dm, idx_bits, q, st, (uint32_t)csr->part, (uint32_t)csr->n_parts);
+    GG_LAUNCH(ctx, "dict_wide", k_dict_wide, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
+              csr->ht_cap, (const DirectMap *)dm, st);
+  }
 
   // ---- D ----------------------------------------------------------------------------------------------------
   u32x2 *pairs = nullptr;

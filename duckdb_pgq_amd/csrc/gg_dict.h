@@ -191,4 +191,164 @@ __device__ __forceinline__ uint32_t packed_resolve(const unsigned long long *__r
   }
 }
 
+// ---- the bucketed build's dictionary in two launches (+ one that normally does nothing) -------------------------
+// k_dict_init    clears all three candidate tables and takes the ids' min / max in the same pass
+// k_dict_insert  every thread derives the mode from min / max (thread 0 publishes it), inserts its vertex into the
+//                table of that mode, reports duplicate ids, counts owned vertices (shards)
+// k_dict_wide    only if a packed insert had to give up (mode flipped to DICT_WIDE16): fills the 16-byte table
+__device__ __forceinline__ unsigned long long dict_mode_of(long long min_id, long long max_id, uint64_t V,
+                                                           uint32_t idx_bits, uint32_t q, uint32_t *span_bits_out) {
+  const uint64_t span = (uint64_t)max_id - (uint64_t)min_id;
+  const bool any = V > 0 && max_id >= min_id;
+  const uint32_t span_bits = span ? 64u - (uint32_t)__clzll((long long)span) : 0u;
+  *span_bits_out = span_bits;
+  if (any && span < DIRECT_MAX_RANGE) return DICT_DIRECT;
+  if (any && q && span_bits >= q && span_bits <= 57u && span_bits - q + PK_DISP_BITS + idx_bits <= 63u) return DICT_PACKED8;
+  return DICT_WIDE16;
+}
+
+static __global__ __launch_bounds__(256) void k_dict_init(const int64_t *__restrict__ vid, uint64_t V,
+                                                          HtSlot *__restrict__ ht, uint64_t cap,
+                                                          unsigned long long *__restrict__ tab, uint64_t nslots,
+                                                          uint32_t *__restrict__ dir, DirectMap *__restrict__ dm) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) {
+    uint4 e;
+    e.x = 0u;
+    e.y = 0x80000000u;  // key = INT64_MIN
+    e.z = INVALID_U32;
+    e.w = 0u;
+    *reinterpret_cast<uint4 *>(&ht[i]) = e;
+  }
+  if (i < nslots) tab[i] = PK_EMPTY;
+  if (i < DIRECT_MAX_RANGE) dir[i] = INVALID_U32;
+  if (blockIdx.x < 64) {  // min / max: 64 workgroups stride over the ids (two same-address atomics each, not two per block)
+    long long lo = INT64_MAX, hi = INT64_MIN;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += 64ull * blockDim.x) {
+      const long long x = vid[v];
+      lo = x < lo ? x : lo;
+      hi = x > hi ? x : hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    __shared__ long long s_lo[4], s_hi[4];
+    if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6] = lo;
+      s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; w++) {
+        lo = s_lo[w] < lo ? s_lo[w] : lo;
+        hi = s_hi[w] > hi ? s_hi[w] : hi;
+      }
+      if (lo <= hi) {
+        atomicMin(&dm->min_id, lo);
+        atomicMax(&dm->max_id, hi);
+      }
+    }
+  }
+}
+
+// 16-byte-table insert of vertex i (shared by k_dict_insert, k_dict_wide and the legacy k_ht_insert)
+__device__ __forceinline__ void ht_insert_one(const int64_t *__restrict__ vid, uint64_t i, HtSlot *__restrict__ ht,
+                                              uint64_t cap, BuildStatus *__restrict__ st) {
+  const int64_t key = vid[i];
+  if (key == HT_EMPTY) {  // the sentinel value itself is a legal id: keep it outside the table
+    const long long prev = (long long)atomicCAS((unsigned long long *)&st->min_idx, (unsigned long long)-1LL,
+                                                (unsigned long long)i);
+    if (prev != -1LL) atomicOr(&st->dup_vertex, 1ULL);
+    return;
+  }
+  uint64_t slot = ht_slot(key, cap);
+  while (true) {
+    const unsigned long long prev =
+        atomicCAS((unsigned long long *)&ht[slot].key, (unsigned long long)HT_EMPTY, (unsigned long long)key);
+    if (prev == (unsigned long long)HT_EMPTY) {
+      ht[slot].val = (uint32_t)i;
+      return;
+    }
+    if (prev == (unsigned long long)key) {
+      atomicOr(&st->dup_vertex, 1ULL);
+      return;
+    }
+    slot = ht_next(slot, cap);
+  }
+}
+
+static __global__ __launch_bounds__(256) void k_dict_insert(const int64_t *__restrict__ vid, uint64_t V,
+                                                            HtSlot *__restrict__ ht, uint64_t cap,
+                                                            unsigned long long *__restrict__ tab,
+                                                            uint32_t *__restrict__ dir, DirectMap *__restrict__ dm,
+                                                            uint32_t idx_bits, uint32_t q, BuildStatus *__restrict__ st,
+                                                            uint32_t part, uint32_t n_parts) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long min_id = dm->min_id, max_id = dm->max_id;  // complete: k_dict_init has finished
+  uint32_t span_bits;
+  const unsigned long long mode = dict_mode_of(min_id, max_id, V, idx_bits, q, &span_bits);
+  if (i == 0) {  // for the kernels after this one (nobody in this launch reads these fields)
+    dm->decided = mode;
+    dm->enabled = mode == DICT_DIRECT ? 1ULL : 0ULL;
+    dm->idx_bits = idx_bits;
+    dm->span_bits = span_bits;
+    dm->q = q;
+    if (mode != DICT_PACKED8) dm->mode = mode;  // packed: starts as DICT_PACKED8 (host), a failed insert flips it
+  }
+  if (n_parts > 1) {  // owned-vertex count (whole builds own everything: set on the host)
+    __shared__ uint32_t s_owned;
+    if (threadIdx.x == 0) s_owned = 0;
+    __syncthreads();
+    const bool mine = i < V && owns(vid[i < V ? i : 0], part, n_parts);
+    const uint64_t om = __ballot(mine);
+    if ((threadIdx.x & 63) == 0 && om) atomicAdd(&s_owned, (uint32_t)__popcll(om));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_owned) atomicAdd(&st->owned, (unsigned long long)s_owned);
+  }
+  if (i >= V) return;
+  if (mode == DICT_DIRECT) {
+    const uint32_t prev = atomicCAS(&dir[(uint64_t)vid[i] - (uint64_t)min_id], INVALID_U32, (uint32_t)i);
+    if (prev != INVALID_U32) atomicOr(&st->dup_vertex, 1ULL);
+  } else if (mode == DICT_PACKED8) {
+    PkGeom pk;
+    pk.min_id = (uint64_t)min_id;
+    pk.max_id = (uint64_t)max_id;
+    pk.S = span_bits;
+    pk.q = q;
+    pk.b = idx_bits;
+    uint64_t home, tag0;
+    pk.locate(vid[i], &home, &tag0);
+    const uint64_t pmask = (1ULL << q) - 1ULL;
+    for (uint64_t disp = 0; disp <= PK_MAX_DISP; disp++) {
+      const uint64_t g = (home + disp) & pmask;
+      const unsigned long long entry = ((tag0 | disp) << idx_bits) | i;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const unsigned long long prev = atomicCAS(&tab[2 * g + s], PK_EMPTY, entry);
+        if (prev == PK_EMPTY) return;
+        if ((prev >> idx_bits) == (tag0 | disp)) {
+          atomicOr(&st->dup_vertex, 1ULL);
+          return;
+        }
+      }
+    }
+    dm->mode = DICT_WIDE16;  // displaced too far: k_dict_wide fills the 16-byte table, the densification uses it
+  } else {
+    ht_insert_one(vid, i, ht, cap, st);
+  }
+}
+
+static __global__ __launch_bounds__(256) void k_dict_wide(const int64_t *__restrict__ vid, uint64_t V,
+                                                          HtSlot *__restrict__ ht, uint64_t cap,
+                                                          const DirectMap *__restrict__ dm,
+                                                          BuildStatus *__restrict__ st) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) st->dict_mode = dm->mode;  // final: k_dict_insert has finished
+  if (dm->mode != DICT_WIDE16 || dm->decided == DICT_WIDE16) return;  // normally: nothing to do
+  if (i < V) ht_insert_one(vid, i, ht, cap, st);
+}
+
 }  // namespace gg

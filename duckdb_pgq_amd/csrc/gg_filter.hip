@@ -93,6 +93,7 @@ extern "C" int gg_result_filter_common_neighbour(gg_ctx *ctx, const gg_result *r
   for (int c = 0; c < GG_MAX_HOPS + 2; c++) oc.c[c] = nullptr;
   uint64_t total = 0;
   if (n_rows) {
+    GG_TRY(ensure_ht(ctx, const_cast<gg_csr *>(filter)));
     uint64_t *counts = nullptr, *tot = nullptr;
     GG_TRY(ctx->dev_alloc((void **)&counts, (n_rows + 1) * sizeof(uint64_t)));
     GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(uint64_t)));

@@ -71,6 +71,7 @@ struct BuildStatus {  // device-side status block of a CSR build, copied back on
   unsigned long long kept_rev;     // edges kept in the reverse CSR (shard builds; destination owned)
   unsigned long long owned;        // vertices owned by this shard
   unsigned long long scan_error;   // !=0: a chained scan gave up waiting for a predecessor tile (gg_runtime.hip)
+  unsigned long long dict_mode;    // bucketed build: DictMode the edge densification used (DICT_WIDE16: csr->ht is built)
 };
 
 // id -> dense index dictionary used while densifying edge rows, chosen on the device from the vertex ids'
@@ -86,6 +87,7 @@ struct DirectMap {
   unsigned long long idx_bits;   // packed slots: bits of the dense index field
   unsigned long long span_bits;  // bits of max_id - min_id
   unsigned long long q;          // packed table: log2 of the number of 16-byte slot pairs
+  unsigned long long decided;    // the mode chosen from min/max (mode may fall back to DICT_WIDE16 afterwards)
 };
 
 }  // namespace gg
@@ -199,6 +201,7 @@ struct gg_csr {
   int64_t *eid = nullptr;      // E   explicit edge rowids (only if the Sink passed rowids), else null
   int64_t *vid = nullptr;      // V   vertex ids by dense index
   gg::HtSlot *ht = nullptr;    // id hash table (open addressing, 16-byte slots: one line per probe)
+  bool ht_built = false;       // filled at build time only if the densification needed it; else on first use (ensure_ht)
   uint64_t ht_cap = 0;         // slots; slot = mulhi(key * GOLD, ht_cap)
   int64_t ht_min_idx = -1;     // dense index of the vertex whose id == HT_EMPTY, if any
   // reverse CSR (in-neighbours), built lazily by ensure_reverse(): row x lists the sources u of
@@ -257,6 +260,8 @@ int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t 
 int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows);
 // build csr->roff / csr->rnbr if absent (gg_csr.hip)
 int ensure_reverse(gg_ctx *ctx, gg_csr *csr);
+// fill csr->ht from csr->vid if the build did not need it (gg_csr.hip); every ht_lookup user calls this first
+int ensure_ht(gg_ctx *ctx, gg_csr *csr);
 // bucketed two-level build of forward + reverse CSR (gg_csr_fast.hip); *taken = 0 if the graph is outside
 // its range (> 2^22 vertices) and nothing was launched
 int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken);

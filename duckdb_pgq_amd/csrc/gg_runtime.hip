@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256) void k_lookup_ids(const int64_t *__restrict__ 
 
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev) {
   if (n == 0) return GG_OK;
+  GG_TRY(ensure_ht(ctx, const_cast<gg_csr *>(csr)));
   GG_LAUNCH(ctx, "lookup_ids", k_lookup_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ids_dev, n,
             csr->ht, csr->ht_cap, csr->ht_min_idx, out_dev);
   return GG_OK;

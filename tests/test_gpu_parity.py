@@ -820,7 +820,7 @@ def test_profile_select_times_only_the_named_kernels(gg, orc):
     c = gg.build_csr()
     c.close()
     gg.profile(False)
-    assert {"ht_insert", "densify_pairs", "col_scan", "partition_dual", "sub_sort", "leaf_rows"} <= set(gg.profile_get())
+    assert {"dict_insert", "densify_pairs", "col_scan", "partition_dual", "sub_sort", "leaf_rows"} <= set(gg.profile_get())
     gg.force_legacy_build(True)
     try:
         gg.profile_reset()
