@@ -1,4 +1,4 @@
-// gg_csr_fast.hip — bucketed two-level CSR build: forward and reverse CSR in four kernels.
+// gg_csr_fast.hip — bucketed two-level CSR build: forward and reverse CSR in one pass over the edge table.
 //
 // Replaces the same reference work as gg_csr.hip (the hash-join build side, JoinHashTable::Build/Finalize/
 // InsertHashes, src/execution/join_hashtable.cpp:150-302) for graphs of up to 2^22 vertices.  The legacy
@@ -10,19 +10,20 @@
 //                         (gg_dict.h: direct array / packed 8-byte slots / 16-byte slots); writes the dense
 //                         pair (u, v) in rowid order; counts, per tile, the bucket of u (forward) and the
 //                         bucket of v (reverse) in LDS
-//      scan               one chained scan over both directions' (bucket x tile) counters
+//      k_col_*            three small kernels: the (tile x bucket) counters of both directions -> global positions
 //   A  k_partition_dual   one read of the pairs, TWO stable bucket partitions written from one LDS staging
 //                         area: forward (low(u), v[, edge position]) by bucket(u), reverse (low(v), u) by
-//                         bucket(v).  In-tile ranks come from __ballot match masks in element order, runs of
-//                         one bucket go out as contiguous stores (same scheme as k_radix_scatter)
-//   B  k_bucket_rows      one workgroup per (direction, bucket): a wave owns a contiguous eighth of the
-//                         bucket, counts its vertices' entries in a private LDS histogram, the workgroup turns
-//                         the histograms into row offsets (written to off[] / roff[]: no separate row-offset
-//                         pass) and per-wave cursors, then every wave places its entries in order.
+//                         bucket(v); runs of one bucket go out as contiguous stores
+//   B  k_sub_sort         a workgroup per 8192-entry chunk of a bucket: stable sort by sub-bucket, in place
+//      k_sub_totals       where each (bucket, sub-bucket) leaf starts
+//      k_leaf_rows        a wave per leaf (<= 64 vertices): gathers the leaf's run of every chunk, writes the row
+//                         offsets (no separate row-offset pass) and the rows
 //
 // Stable everywhere: inside a forward row neighbours keep ascending edge-rowid order (bit-identical to the
 // legacy build and to the oracle's counting sort); inside a reverse row in-neighbours are in rowid order too
-// (the order shard builds already produce).  No atomic decides a position.
+// (the order shard builds already produce).  Ranks inside a wave come from LDS cursors private to that wave:
+// either straight from ds_add_rtn, whose lane order is checked per context (k_lds_order_probe), or from
+// __ballot match masks; waves, tiles and chunks are ordered by prefix sums.
 // Algorithmic bytes: SURVEY.md §8d, 32E + 8V (densification) + 32E + 16V (CSR without rowid).
 #include "gg_dict.h"
 #include "gg_internal.h"
@@ -96,10 +97,64 @@ struct FastGeom {
   uint32_t leaf;      // ... and vertex-in-leaf bits (<= 6)
   uint32_t part;      // shard builds (gg_csr_build_shard): forward rows of owned sources, reverse rows of owned
   uint32_t n_parts;   // destinations only; 1: whole graph
+  uint32_t rank_atomic;  // 1: stable ranks straight from ds_add_rtn (lds_order_ok), 0: from match masks
 };
 // Shard builds mark, in the dense pair, the direction a row does not take part in: bit 31 of u = "source not
 // owned: no forward entry", bit 31 of v = "destination not owned: no reverse entry" (dense indices stay below 2^22).
 constexpr uint32_t FB_SKIP = 0x80000000u;
+
+// Stable ranking inside a wave.  Every ranking kernel below gives a wave its own row of LDS cursors, so the only
+// lanes that meet on a cursor belong to one instruction of one wave.  gfx950 serves the lanes of one ds_add_rtn_u32
+// that hit the same word in increasing lane order (scripts/ubench_ldsorder.hip: 1.3e11 lane-ops, none out of
+// order; 5x the rate of a 9-bit match-mask loop), which is exactly a stable rank: position = atomicAdd(cursor, 1).
+// That order is not an architectural promise, so k_lds_order_probe checks it once per context before the first
+// build relies on it; where it does not hold the kernels build match masks with ballots instead.
+__global__ __launch_bounds__(512) void k_lds_order_probe(uint32_t rounds, uint32_t *__restrict__ bad) {
+  __shared__ uint32_t rows[8 * 512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ULL << lane) - 1ULL;
+  const uint32_t K = blockIdx.x % 4 == 0 ? 1u : blockIdx.x % 4 == 1 ? 3u : blockIdx.x % 4 == 2 ? 16u : 512u;
+  uint32_t *row = rows + wave * 512;
+  for (uint32_t i = lane; i < 512; i += 64) row[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t nbad = 0;
+  for (uint32_t r = 0; r < rounds; r++) {
+    uint32_t h = (blockIdx.x * 8 + wave) * 0x9E3779B9u + r * 64 + lane;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    const uint32_t a = (h >> 8) % K;
+    const bool valid = (h & 7u) != 0;
+    volatile uint32_t *vr = row;
+    const uint32_t before = valid ? vr[a] : 0u;
+    uint64_t m = __ballot(valid);
+    for (uint32_t b = 0; b < 9; b++) {
+      const uint64_t bb = __ballot((a >> b) & 1u);
+      m &= ((a >> b) & 1u) ? bb : ~bb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t got = 0;
+    if (valid) got = atomicAdd(&row[a], 1u);
+    __builtin_amdgcn_wave_barrier();
+    if (valid && got != before + (uint32_t)__popcll(m & lane_lt)) nbad++;
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+// rank_mode: 0 decide by the probe (once), 1 ds_add_rtn ranks, 2 match masks
+static int lds_order_ok(gg_ctx *ctx, uint32_t *ok) {
+  if (ctx->rank_mode == 0) {
+    uint32_t *bad = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&bad, sizeof(uint32_t)));
+    GG_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_lds_order_probe, dim3(256), dim3(512), 0, ctx->stream, 256u, bad);
+    uint32_t h = 1;
+    GG_HIP(hipMemcpyAsync(&h, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->dev_free(bad);
+    ctx->rank_mode = h == 0 ? 1 : 2;
+  }
+  *ok = ctx->rank_mode == 1 ? 1u : 0u;
+  return GG_OK;
+}
 
 // ---- D: densify + per-tile bucket histograms of both directions ---------------------------------------------
 // counts[tile * 2 nb + dir * nb + bucket]: tile-major, one contiguous 2 nb row per tile
@@ -354,17 +409,28 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
       const uint32_t key = dir ? v[it] : u[it], pay = (dir ? u[it] : v[it]) & ~FB_SKIP;
       const bool valid = u[it] != INVALID_U32 && !(key & FB_SKIP);  // (shards: this direction's endpoint is owned)
       const uint32_t d = valid ? key >> g.low : 0u;
-#if GG_FB_MATCH_OR
-      const uint64_t m = match_or(mm, d, valid, lane);
-#else
       uint64_t m = __ballot(valid);
-      for (uint32_t bit = 0; bit < g.hb; bit++) {  // match mask: same bucket within the wave
-        const uint64_t bb = __ballot((d >> bit) & 1u);
-        m &= ((d >> bit) & 1u) ? bb : ~bb;
-      }
+      uint32_t pos = 0;
+      bool counted = false;  // the cursor already moved
+      if (g.rank_atomic) {
+        // one bucket for the whole wave (edge tables sorted by an endpoint): lanes in order, one add
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, m ? __ffsll((unsigned long long)m) - 1 : 0);
+        if (__ballot(valid && d != d0) != 0) {
+          if (valid) pos = atomicAdd((uint32_t *)&cur[d], 1u);
+          counted = true;
+        }
+      } else {
+#if GG_FB_MATCH_OR
+        m = match_or(mm, d, valid, lane);
+#else
+        for (uint32_t bit = 0; bit < g.hb; bit++) {  // match mask: same bucket within the wave
+          const uint64_t bb = __ballot((d >> bit) & 1u);
+          m &= ((d >> bit) & 1u) ? bb : ~bb;
+        }
 #endif
+      }
       if (valid) {
-        const uint32_t pos = cur[d] + __popcll(m & lane_lt);
+        if (!counted) pos = cur[d] + __popcll(m & lane_lt);
         if (PACK) {
           xw[pos] = ((key & low_mask) << g.key_bits) | pay;
         } else {
@@ -374,9 +440,11 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
         if (ROWID && dir == 0) xe[pos] = (uint32_t)(wbase + (uint64_t)it * 64 + lane);
         xd[pos] = (uint16_t)d;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));  // lowest lane of each group
-      __builtin_amdgcn_wave_barrier();
+      if (!counted) {  // uniform
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));  // lowest lane of each group
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     __syncthreads();
 
@@ -415,8 +483,14 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 #ifndef GG_FB_CAPW
 #define GG_FB_CAPW 1536  // entries of a wave's LDS stage in k_leaf_rows (halved when edge positions ride along)
 #endif
+#ifndef GG_FB_LEAF_TARGET
+#define GG_FB_LEAF_TARGET 2048  // entries per leaf aimed at: between half of this and this
+#endif
 constexpr int LEAF_WAVES = 4;    // waves (= leaves) per workgroup of k_leaf_rows
-constexpr int LEAF_MAXS = 24;    // 64-entry steps a wave keeps in registers
+#ifndef GG_FB_LEAF_MAXS
+#define GG_FB_LEAF_MAXS 24
+#endif
+constexpr int LEAF_MAXS = GG_FB_LEAF_MAXS;  // 64-entry steps a wave of k_leaf_rows keeps in registers (<= 32)
 
 // ---- column kernels: counters -> global positions ----------------------------------------------------------------
 // counts[tile][2 nb] (tile-major) must become bases[tile][c] = start of column c (its direction's bucket start)
@@ -656,12 +730,22 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     const bool valid = k[it] != INVALID_U32;
     const uint32_t sb = valid ? k[it] >> g.leaf : 0u;
     uint64_t m = __ballot(valid);
-    for (uint32_t bit = 0; bit < g.sub; bit++) {  // match mask: same sub-bucket within the wave
-      const uint64_t bb = __ballot((sb >> bit) & 1u);
-      m &= ((sb >> bit) & 1u) ? bb : ~bb;
+    uint32_t pos = 0;
+    bool counted = false;
+    if (g.rank_atomic) {  // (see k_partition_dual)
+      const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)sb, m ? __ffsll((unsigned long long)m) - 1 : 0);
+      if (__ballot(valid && sb != s0) != 0) {
+        if (valid) pos = atomicAdd((uint32_t *)&cur[sb], 1u);
+        counted = true;
+      }
+    } else {
+      for (uint32_t bit = 0; bit < g.sub; bit++) {  // match mask: same sub-bucket within the wave
+        const uint64_t bb = __ballot((sb >> bit) & 1u);
+        m &= ((sb >> bit) & 1u) ? bb : ~bb;
+      }
     }
     if (valid) {
-      const uint32_t pos = cur[sb] + __popcll(m & lane_lt);
+      if (!counted) pos = cur[sb] + __popcll(m & lane_lt);
       if (PACK) {
         xw[pos] = w[it];
       } else {
@@ -670,9 +754,11 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
       }
       if (with_pos) xe[pos] = ep[it];
     }
-    __builtin_amdgcn_wave_barrier();
-    if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[sb], (uint32_t)__popcll(m));
-    __builtin_amdgcn_wave_barrier();
+    if (!counted) {  // uniform
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[sb], (uint32_t)__popcll(m));
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   __syncthreads();
   const uint32_t n = s_n;
@@ -715,17 +801,15 @@ __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ 
 }
 
 template <bool PACK, bool ROWID>
-__global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
-    const uint32_t *__restrict__ buf_f, const uint32_t *__restrict__ buf_r, const uint32_t *__restrict__ epos_f,
-    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ offs,
-    const uint32_t *__restrict__ substart, FastGeom g, uint64_t V, uint32_t *__restrict__ off,
-    uint32_t *__restrict__ nbr, uint32_t *__restrict__ epos, uint32_t *__restrict__ roff,
-    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+__device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const uint32_t *__restrict__ buf_f,
+                              const uint32_t *__restrict__ buf_r, const uint32_t *__restrict__ epos_f,
+                              const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart,
+                              const uint32_t *__restrict__ offs, const uint32_t *__restrict__ substart, FastGeom g,
+                              uint64_t V, uint32_t *__restrict__ off, uint32_t *__restrict__ nbr,
+                              uint32_t *__restrict__ epos, uint32_t *__restrict__ roff, uint32_t *__restrict__ rnbr,
+                              uint32_t *__restrict__ rrow) {
   const uint32_t nb = 1u << g.hb, nsub = 1u << g.sub, leafW = 1u << g.leaf;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t unit = blockIdx.x * LEAF_WAVES + wave;  // (bucket i, sub s): waves are independent from here on
-  if (unit >= 2 * nb * nsub) return;
   const uint32_t i = unit / nsub, s = unit % nsub, dir = i / nb, j = i % nb;
   const uint32_t *__restrict__ buf = dir ? buf_r : buf_f;
   uint32_t *__restrict__ o_off = dir ? roff : off;
@@ -750,6 +834,7 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
   // whole leaf fits LEAF_MAXS steps the entries stay in registers between the two.
   uint32_t incl_keep = 0;  // lane d: end of vertex d's run (relative), set after pass 0
   uint32_t kw[LEAF_MAXS], pw[PACK ? 1 : LEAF_MAXS], ew[ROWID ? LEAF_MAXS : 1];
+  uint32_t have = 0;  // bit q: kw[q] holds an entry
   bool single = false;
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
@@ -773,10 +858,11 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
       if (pass == 0) single = nch <= 64 && T <= LEAF_MAXS;
       for (uint32_t r = 0; r < T; r += LEAF_MAXS) {
         if (pass == 0 || !single) {
+          have = 0;
 #pragma unroll
           for (int q = 0; q < LEAF_MAXS; q++) {  // all loads of the round issue back to back
             const uint32_t t = r + q;
-            kw[q] = INVALID_U32;
+            kw[q] = 0;
             if (!PACK) pw[PACK ? 0 : q] = 0;
             if (ROWID) ew[ROWID ? q : 0] = 0;
             if (t < T) {  // uniform
@@ -784,6 +870,7 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
               const uint32_t kidx = (t - (uint32_t)__shfl(sexcl, cc, 64)) * 64 + lane;
               const uint32_t e = (uint32_t)__shfl(src, cc, 64) + kidx;
               if (kidx < (uint32_t)__shfl(len, cc, 64)) {
+                have |= 1u << q;
                 if (PACK) {
                   kw[q] = buf[e];
                 } else {
@@ -799,22 +886,27 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
         if (pass == 0) {
 #pragma unroll
           for (int q = 0; q < LEAF_MAXS; q++)
-            if (kw[q] != INVALID_U32) atomicAdd(&lc[(PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask], 1u);
+            if ((have >> q) & 1u) atomicAdd(&lc[(PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask], 1u);
         } else {
           volatile uint32_t *cur = lc;
 #pragma unroll
           for (int q = 0; q < LEAF_MAXS; q++) {
             if (r + q >= T) continue;  // uniform
-            const bool valid = kw[q] != INVALID_U32;
+            const bool valid = (have >> q) & 1u;
             const uint32_t d = valid ? (PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask : 0u;
             const uint32_t pay = PACK ? kw[q] & pay_mask : pw[PACK ? 0 : q];
             uint64_t m = __ballot(valid);
-            for (uint32_t bit = 0; bit < g.leaf; bit++) {  // match mask: same vertex within the wave
-              const uint64_t bb = __ballot((d >> bit) & 1u);
-              m &= ((d >> bit) & 1u) ? bb : ~bb;
+            uint32_t rel = 0;
+            if (g.rank_atomic) {
+              if (valid) rel = atomicAdd((uint32_t *)&cur[d], 1u);
+            } else {
+              for (uint32_t bit = 0; bit < g.leaf; bit++) {  // match mask: same vertex within the wave
+                const uint64_t bb = __ballot((d >> bit) & 1u);
+                m &= ((d >> bit) & 1u) ? bb : ~bb;
+              }
+              if (valid) rel = cur[d] + __popcll(m & lane_lt);
             }
             if (valid) {
-              const uint32_t rel = cur[d] + __popcll(m & lane_lt);
               if (staged) {
                 stage[rel] = pay;
                 if (with_pos) stage_e[rel] = ew[ROWID ? q : 0];
@@ -824,9 +916,11 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
                 if (with_pos) epos[t0 + rel] = ew[ROWID ? q : 0];
               }
             }
-            __builtin_amdgcn_wave_barrier();
-            if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));
-            __builtin_amdgcn_wave_barrier();
+            if (!g.rank_atomic) {
+              __builtin_amdgcn_wave_barrier();
+              if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));
+              __builtin_amdgcn_wave_barrier();
+            }
           }
         }
       }
@@ -869,6 +963,21 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
   }
 }
 
+// One wave per leaf (bucket i, sub-bucket s); LEAF_WAVES leaves per workgroup.
+template <bool PACK, bool ROWID>
+__global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
+    const uint32_t *__restrict__ buf_f, const uint32_t *__restrict__ buf_r, const uint32_t *__restrict__ epos_f,
+    const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart, const uint32_t *__restrict__ offs,
+    const uint32_t *__restrict__ substart, FastGeom g, uint64_t V, uint32_t *__restrict__ off,
+    uint32_t *__restrict__ nbr, uint32_t *__restrict__ epos, uint32_t *__restrict__ roff,
+    uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t unit = blockIdx.x * LEAF_WAVES + (threadIdx.x >> 6);  // waves are independent from here on
+  if (unit >= (2u << (g.hb + g.sub))) return;
+  leaf_unit<PACK, ROWID>(unit, lds, buf_f, buf_r, epos_f, bstart, cstart, offs, substart, g, V, off, nbr, epos, roff,
+                         rnbr, rrow);
+}
+
 static int bits_of(uint64_t v) {  // bits needed for values 0..v
   int b = 0;
   while (b < 64 && (v >> b)) b++;
@@ -886,7 +995,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   // wave, so it should hold about a thousand entries: 2^(hb + sub) ~ entries / 1024..2048, where a shard expects about
   // half of its local rows per direction.  leaf <= 6 bits (one lane per vertex), sub <= 6, hb <= FB_MAX_HB.
   const uint64_t expect = csr->n_parts > 1 ? E / 2 : E;
-  int lb = bits_of(expect / 2048);               // log2 of the number of leaves wanted (600-1200 entries each)
+  int lb = bits_of(expect / GG_FB_LEAF_TARGET);               // log2 of the number of leaves wanted (600-1200 entries each)
   if (lb < kb - 6) lb = kb - 6;                  // leaf <= 6 bits
   if (lb > kb) lb = kb;                          // at most one leaf per vertex
   if (lb < 0) lb = 0;
@@ -902,6 +1011,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   g.leaf = (uint32_t)(low - sub);
   g.part = (uint32_t)csr->part;
   g.n_parts = (uint32_t)csr->n_parts;
+  GG_TRY(lds_order_ok(ctx, &g.rank_atomic));
   *taken = 1;
   const uint32_t nb = 1u << hb;
   const bool rowid = ctx->keep_edge_rowid && csr->n_parts <= 1;  // a shard only serves 2-hop counting and BFS: no rowids

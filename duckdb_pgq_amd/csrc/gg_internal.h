@@ -161,6 +161,7 @@ struct gg_ctx {
 
   // ---- profiling ----
   bool force_frontier = false;  // gg_debug_force_frontier
+  int rank_mode = 0;            // gg_debug_rank_mode: 0 probe the LDS atomic order once, 1 ds_add_rtn ranks, 2 match masks
   bool legacy_build = false;    // gg_debug_force_legacy_build: the multi-pass LSD build (also taken for > 2^22 vertices)
   bool keep_edge_rowid = true;  // gg_ctx_set_edge_rowid
   bool profiling = false;

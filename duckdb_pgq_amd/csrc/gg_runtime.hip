@@ -188,6 +188,12 @@ extern "C" int gg_debug_force_frontier(gg_ctx *ctx, int on) {
   return GG_OK;
 }
 
+extern "C" int gg_debug_rank_mode(gg_ctx *ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return GG_ERR_INVALID_ARG;
+  ctx->rank_mode = mode;
+  return GG_OK;
+}
+
 extern "C" int gg_debug_force_legacy_build(gg_ctx *ctx, int on) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   ctx->legacy_build = on != 0;

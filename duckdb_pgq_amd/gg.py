@@ -18,7 +18,7 @@ SYMBOLS = [
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
-    "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault",
+    "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
@@ -93,6 +93,7 @@ def load_library(path: str | None = None):
     lib.gg_khop_partition_mid.argtypes = [P, P, C.c_int, C.POINTER(u64)]
     lib.gg_debug_force_frontier.argtypes = [P, C.c_int]
     lib.gg_debug_force_legacy_build.argtypes = [P, C.c_int]
+    lib.gg_debug_rank_mode.argtypes = [P, C.c_int]
     lib.gg_debug_scan_fault.argtypes = [P, C.c_uint32, u64]
     lib.gg_result_rows.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_fetch.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
@@ -406,6 +407,10 @@ class GG:
 
     def scan_fault(self, spin_limit: int = 0, mute_tile: int = (1 << 64) - 1):
         self._chk(self.lib.gg_debug_scan_fault(self.ctx, spin_limit, mute_tile))
+
+    def rank_mode(self, mode: int):
+        """0: probe the LDS atomic order once (default), 1: ranks from ds_add_rtn, 2: ranks from match masks."""
+        self._chk(self.lib.gg_debug_rank_mode(self.ctx, int(mode)))
 
     def force_legacy_build(self, on: bool):
         self._chk(self.lib.gg_debug_force_legacy_build(self.ctx, int(on)))

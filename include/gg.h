@@ -252,6 +252,10 @@ int gg_debug_force_frontier(gg_ctx *ctx, int on);
 /* Testing knob: force gg_csr_build onto the multi-pass LSD build that graphs of more than 2^22 vertices
  * (and shard builds) take; both builds must export identical arrays. */
 int gg_debug_force_legacy_build(gg_ctx *ctx, int on);
+/* Testing knob: how the bucketed build ranks entries inside a wavefront.  0 (default): probe once whether one
+ * ds_add_rtn serves colliding lanes in lane order and use it if so; 1: use it; 2: match masks by ballots.  Both
+ * must export identical arrays. */
+int gg_debug_rank_mode(gg_ctx *ctx, int mode);
 /* Testing knob (fault injection): tile `mute_tile` of every chained prefix scan never publishes its sum and the
  * tiles behind it give up after `spin_limit` polls instead of 2^24; the call that ran the scan must then
  * fail with GG_ERR_HIP instead of returning a wrong result.  spin_limit 0 and mute_tile UINT64_MAX restore
