@@ -251,6 +251,9 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 #ifndef GG_MID_PIPE
 #define GG_MID_PIPE 1
 #endif
+#ifndef GG_MID_ISPLIT
+#define GG_MID_ISPLIT 96  // runs of at least this many states are split over the workgroup's waves
+#endif
 constexpr int MID_R = 8;  // out-row values per lane per J-block: a J-block covers 64*MID_R = 512 leaves
 
 #define GG_XAD(acc, q, t) asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(q), "v"(t))
@@ -422,6 +425,27 @@ __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, c
   return nruns;
 }
 
+// One J-block: NREG out-row values per lane (loads issue back to back: a lane past the row's end reads the last
+// entry and zeroes it), every state of the slice folded against them.  A lane without a leaf added q ^ 0 = q for
+// every state of the slice: `corr` takes that back.
+template <int NREG>
+__device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *__restrict__ row, uint32_t j0,
+                                          uint32_t dout, int ia, int ib, uint32_t sq, uint32_t (&acc)[MID_R],
+                                          uint32_t &corr) {
+  uint32_t t[MID_R];
+  uint32_t ninv = 0;
+#pragma unroll
+  for (int r = 0; r < NREG; r++) {
+    const uint32_t j = j0 + r * 64;
+    const bool ok = j < dout;
+    const uint32_t w = row[ok ? j : dout - 1];
+    t[r] = ok ? w * DIG_K32 : 0u;  // low half of the leaf term (w * K mod 2^32: a bijection of w)
+    ninv += ok ? 0u : 1u;
+  }
+  mid_accumulate<NREG>(s_q, ia, ib, t, acc);
+  corr += ninv * sq;
+}
+
 // stage 4: fold every staged state against the out-row of its run's middle vertex
 __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nruns, const uint32_t *__restrict__ nbr,
                                               uint32_t (&acc)[MID_R], uint32_t &corr) {
@@ -431,7 +455,7 @@ __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nrun
     const int len = b - a;
     // long runs: every wave takes a slice of the run (i-split) and walks all J-blocks;
     // short runs: the whole run belongs to ONE wave (dealt round-robin), the others skip it at once
-    const bool isplit = len >= 16;
+    const bool isplit = len >= GG_MID_ISPLIT;
     if (!isplit && (rr & (XT / 64 - 1)) != (uint32_t)wave) continue;
     const uint32_t dout = sm.rdout[rr];
     if (dout == 0) continue;
@@ -442,31 +466,20 @@ __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nrun
     const uint32_t sq = sm.pq[ib] - sm.pq[ia];  // sum of the slice's hash states
     // J-blocks of equal size (multiple of 64 leaves, at most 64*MID_R): avoids a nearly empty tail block
     const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
-    const uint32_t jsz = (((dout + nJ - 1) / nJ) + 63) & ~63u;
+    const uint32_t jsz = nJ == 1 ? (dout + 63) & ~63u : (((dout + nJ - 1) / nJ) + 63) & ~63u;  // (no division for <= 512)
     const int nreg = (int)(jsz >> 6);
     for (uint32_t jb = 0; jb < nJ; jb++) {
-      const uint32_t base = jb * jsz;
-      uint32_t t[MID_R];
-      uint32_t ninv = 0;  // registers (among the nreg used) in which this lane holds no leaf
-#pragma unroll
-      for (int r = 0; r < MID_R; r++) {
-        const uint32_t j = base + r * 64 + lane;
-        const bool ok = r < nreg && j < dout;
-        t[r] = ok ? row[j] * DIG_K32 : 0u;  // low half of the leaf term (w * K mod 2^32: a bijection of w)
-        if (!ok && r < nreg) ninv++;
-      }
+      const uint32_t base = jb * jsz + (uint32_t)lane;
       switch (nreg) {
-      case 1: mid_accumulate<1>(sm.q, ia, ib, t, acc); break;
-      case 2: mid_accumulate<2>(sm.q, ia, ib, t, acc); break;
-      case 3: mid_accumulate<3>(sm.q, ia, ib, t, acc); break;
-      case 4: mid_accumulate<4>(sm.q, ia, ib, t, acc); break;
-      case 5: mid_accumulate<5>(sm.q, ia, ib, t, acc); break;
-      case 6: mid_accumulate<6>(sm.q, ia, ib, t, acc); break;
-      case 7: mid_accumulate<7>(sm.q, ia, ib, t, acc); break;
-      default: mid_accumulate<8>(sm.q, ia, ib, t, acc); break;
+      case 1: mid_block<1>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      case 2: mid_block<2>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      case 3: mid_block<3>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      case 4: mid_block<4>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      case 5: mid_block<5>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      case 6: mid_block<6>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      case 7: mid_block<7>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+      default: mid_block<8>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
       }
-      // a lane without a leaf added q ^ 0 = q for every state of the slice
-      corr += ninv * sq;
     }
   }
 }
