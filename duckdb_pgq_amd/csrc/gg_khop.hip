@@ -508,6 +508,115 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
   block_store_partials(mid_sum, total, rows_last, sm.red, partial);
 }
 
+// ---- 3-hop as a product around the LAST inner vertex ----------------------------------------------------------
+// Every 3-hop walk u -> a -> b -> w from every vertex is one pair (2-hop row u -> a -> b, out-edge of b).  The
+// 2-hop rows that end in b are, for every reverse-CSR entry e = (a -> b) of b, the reverse row of a: a two-level
+// flattened index over the reverse entries (foff2[e] = 2-hop rows before entry e), already grouped by b.  A tile
+// of MT consecutive positions is hashed into level-2 states (three fmix64 each) and folded against out(b) exactly
+// like k_expand_mid2's tiles; the frontier kernels instead hash every 3-hop walk once (k_expand_fused2).
+// Runs are long here (sum of in-degrees over in(b), ~8 k states at SF100), so the per-run set-up vanishes.
+__global__ __launch_bounds__(256) void k_mid3_prepare(const uint32_t *__restrict__ roff, const uint32_t *__restrict__ rrow,
+                                                      const uint32_t *__restrict__ rnbr, uint64_t n,
+                                                      uint64_t *__restrict__ foff2,
+                                                      unsigned long long *__restrict__ partial) {
+  __shared__ uint64_t s_red[12];
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t d1 = 0;
+  if (e < n) {
+    const uint32_t a = rnbr[e];
+    foff2[e] = (uint64_t)(roff[a + 1] - roff[a]);
+    d1 = dig_leaf(dig_q((uint64_t)a, 0), rrow[e]);  // the 1-hop row a -> b
+  }
+  block_store_partials(d1, 0, 0, s_red, partial);
+}
+
+__global__ __launch_bounds__(256) void k_tile_partition_mt(const uint64_t *__restrict__ foff, uint64_t n_entries,
+                                                           uint64_t n_tiles, uint32_t *__restrict__ tile_entry) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint64_t target = t * MT;
+  uint64_t lo = 0, hi = n_entries;  // first idx in [0, n_entries] with foff[idx] > target
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (foff[mid] <= target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  tile_entry[t] = (uint32_t)(lo - 1);
+}
+
+__global__ __launch_bounds__(XT) void k_expand_mid3(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                    const uint32_t *__restrict__ roff, const uint32_t *__restrict__ rrow,
+                                                    const uint32_t *__restrict__ rnbr, const uint64_t *__restrict__ foff2,
+                                                    uint64_t n_entries, uint64_t M2,
+                                                    const uint32_t *__restrict__ tile_entry, int emit_mid,
+                                                    unsigned long long *__restrict__ partial) {
+  __shared__ MidShared sm;
+  __shared__ uint64_t s_foff[MT + 1];
+  uint64_t mid_sum = 0, rows_last = 0;
+  uint32_t acc[MID_R], corr = 0;
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) acc[r] = 0;
+  const uint64_t tile = blockIdx.x, i0 = tile_entry[tile];
+  for (uint32_t t = threadIdx.x; t <= MT; t += XT) {
+    const uint64_t gi = i0 + t;
+    s_foff[t] = gi <= n_entries ? foff2[gi] : UINT64_MAX;
+  }
+  __syncthreads();
+  MidRows rows;
+  MidPrep prep;
+#pragma unroll
+  for (int e = 0; e < MID_EPT; e++) {
+    const uint64_t p = tile * MT + (uint64_t)(e * XT) + threadIdx.x;
+    rows.valid[e] = p < M2;
+    rows.x[e] = INVALID_U32;
+    rows.u[e] = 0;
+    prep.q[e] = 0;
+    prep.st[e] = prep.dout[e] = 0;
+    if (rows.valid[e]) {
+      uint32_t lo = 0, hi = MT + 1;  // first idx in the window with s_foff[idx] > p
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_foff[mid] <= p)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      uint64_t ent = i0 + lo - 1, start = s_foff[lo - 1];
+      if (lo == MT + 1) {  // window exhausted by entries without children: finish in global memory
+        uint64_t glo = i0 + MT, ghi = n_entries;
+        while (glo < ghi) {
+          const uint64_t mid = (glo + ghi) >> 1;
+          if (foff2[mid] <= p)
+            glo = mid + 1;
+          else
+            ghi = mid;
+        }
+        ent = glo - 1;
+        start = foff2[ent];
+      }
+      const uint32_t a = rnbr[ent], b = rrow[ent];
+      const uint32_t u = rnbr[(uint64_t)roff[a] + (p - start)];
+      const uint64_t q1 = dig_q(dig_leaf(dig_q((uint64_t)u, 0), a), 1);
+      const uint64_t P2 = dig_leaf(q1, b);
+      if (emit_mid) mid_sum = dsum_add(mid_sum, P2);
+      rows.x[e] = b;
+      prep.q[e] = dig_q(P2, 2);
+      prep.st[e] = off[b];
+      prep.dout[e] = off[b + 1] - prep.st[e];
+      rows_last += (uint64_t)prep.dout[e];
+    }
+  }
+  const uint32_t nruns = mid_stage(sm, rows, prep, M2, tile);
+  mid_fold_tile(sm, nruns, nbr, acc, corr);
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) tsum += acc[r];
+  const uint64_t total = (uint64_t)(uint32_t)(tsum - corr);
+  block_store_partials(mid_sum, total, rows_last, sm.red, partial);
+}
+
 // per-vertex work of the product kernel: in-degree x (1 + out-degree)
 __global__ __launch_bounds__(256) void k_mid_work(const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
                                                   uint64_t V, uint64_t *__restrict__ work) {
@@ -955,6 +1064,68 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
   return GG_OK;
 }
 
+// 1..3-hop count + digest from every vertex through the product kernels (whole graphs)
+int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
+  memset(st, 0, sizeof(*st));
+  GG_TRY(ensure_reverse(ctx, csr));
+  const uint64_t E = csr->E_rev;
+  uint64_t M2 = 0, rows3 = 0, dig1 = 0, dig2 = 0, dig3 = 0;
+  if (E) {
+    uint64_t *foff2 = nullptr;
+    unsigned long long *partial = nullptr, *tmp = nullptr;
+    const uint64_t nb1 = (E + 255) / 256;
+    GG_TRY(ctx->dev_alloc((void **)&foff2, (E + 1) * sizeof(uint64_t)));
+    GG_TRY(ctx->dev_alloc((void **)&partial, nb1 * 4 * sizeof(unsigned long long)));
+    GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
+    GG_LAUNCH(ctx, "mid3_prepare", k_mid3_prepare, dim3((unsigned)nb1), dim3(256), 0, csr->roff, csr->rrow, csr->rnbr,
+              E, foff2, partial);
+    GG_TRY(reduce_partials(ctx, partial, nb1, tmp));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch + 8, tmp, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    GG_TRY(offsets_from_deg(ctx, foff2, E, &M2));  // (synchronises: pin_scratch[8] is the 1-hop digest)
+    dig1 = ctx->pin_scratch[8];
+    ctx->dev_free(partial);
+    partial = nullptr;
+    if (M2) {
+      const uint64_t n_tiles = (M2 + MT - 1) / MT;
+      if (n_tiles > 0x7FFFFFFFull) {
+        set_error("3-hop expansion over %llu 2-hop rows exceeds one launch (2^31 tiles)", (unsigned long long)M2);
+        return GG_ERR_TOO_LARGE;
+      }
+      uint32_t *tile_entry = nullptr;
+      GG_TRY(ctx->dev_alloc((void **)&tile_entry, n_tiles * sizeof(uint32_t)));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      GG_LAUNCH(ctx, "tile_partition", k_tile_partition_mt, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
+                (const uint64_t *)foff2, E, n_tiles, tile_entry);
+      GG_LAUNCH(ctx, "expand_mid3", k_expand_mid3, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr, csr->roff,
+                csr->rrow, csr->rnbr, (const uint64_t *)foff2, E, M2, (const uint32_t *)tile_entry, (int)(k_min <= 2),
+                partial);
+      GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
+      GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+      GG_HIP(hipStreamSynchronize(ctx->stream));
+      dig2 = ctx->pin_scratch[0];
+      dig3 = ctx->pin_scratch[1];
+      rows3 = ctx->pin_scratch[2];
+      ctx->dev_free(tile_entry);
+      ctx->dev_free(partial);
+    }
+    ctx->dev_free(tmp);
+    ctx->dev_free(foff2);
+  }
+  if (k_min <= 1) {
+    st->rows[1] = E;
+    st->digest[1] = dig1;
+  }
+  if (k_min <= 2) {
+    st->rows[2] = M2;
+    st->digest[2] = dig2;
+  }
+  st->rows[3] = rows3;
+  st->digest[3] = dig3;
+  st->traversed_edges = E + M2 + rows3;
+  st->frontier_entries = csr->V + E + M2;
+  return GG_OK;
+}
+
 // materialise walks as int64 id columns (correctness config; level-by-level)
 int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64_t n0, int k_min, int k_max,
                      gg_result *res) {
@@ -1104,6 +1275,9 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
   if (k_max == 2 && src_lo == 0 && src_hi == csr->V && (!ctx->force_frontier || csr->n_parts > 1)) {
     // every vertex is a source: the 2-hop walks are the per-vertex products in(x) x out(x)
     GG_TRY(khop_count_mid(ctx, const_cast<gg_csr *>(csr), 0, csr->V, k_min, stats));
+  } else if (k_max == 3 && src_lo == 0 && src_hi == csr->V && !ctx->force_frontier && csr->n_parts <= 1) {
+    // ... and the 3-hop walks the products {2-hop rows ending in b} x out(b)
+    GG_TRY(khop_count_mid3(ctx, const_cast<gg_csr *>(csr), k_min, stats));
   } else {
     GG_TRY(khop_count(ctx, csr, true, (uint32_t)src_lo, n0, M1, DevFrontier(), k_min, k_max, stats));
   }

@@ -257,20 +257,56 @@ def test_medium_ldbc_shape_end_to_end(gg, orc):
 
 @pytest.mark.parametrize("V,E,seed,dangling,dup", CASES[3:] + [(64, 6000, 41, 0, 200), (1000, 300000, 42, 0, 0)])
 def test_khop_product_kernel_equals_frontier_kernel(gg, orc, V, E, seed, dangling, dup):
-    """All-sources 2-hop runs through the middle-vertex product kernel; it must agree bit-for-bit with
-    the frontier kernels and with the oracle (k_min 1 and 2)."""
+    """All-sources 2-hop and 3-hop counts run through the product kernels (2-hop: around the middle vertex;
+    3-hop: {2-hop rows ending in b} x out(b)); they must agree bit-for-bit with the frontier kernels and with
+    the oracle, for every k_min."""
     vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
     csr, g = build_both(gg, orc, vid, src, dst)
-    for kmin in (1, 2):
-        ref = g.khop(kmin, 2)
-        assert gg.expand_khop(csr, kmin, 2) == ref
-        gg.force_frontier(True)
-        try:
-            assert gg.expand_khop(csr, kmin, 2) == ref
-        finally:
-            gg.force_frontier(False)
+    for kmax in (2, 3):
+        if kmax == 3 and E > 20000:  # (the oracle walks every 3-hop path)
+            continue
+        for kmin in range(1, kmax + 1):
+            ref = g.khop(kmin, kmax)
+            assert gg.expand_khop(csr, kmin, kmax) == ref, (kmin, kmax)
+            gg.force_frontier(True)
+            try:
+                assert gg.expand_khop(csr, kmin, kmax) == ref, (kmin, kmax)
+            finally:
+                gg.force_frontier(False)
     csr.close()
     g.close()
+
+
+def test_three_hop_product_kernel_on_a_skewed_graph(gg):
+    """3-hop product kernel against the frontier kernels on a graph with hubs, isolated vertices and runs of
+    reverse entries without 2-hop rows (windows of the flattened index that hold no children)."""
+    rng = np.random.default_rng(77)
+    V, E = 20_000, 400_000
+    vid = np.arange(V, dtype=np.int64) * 5 + 3
+    src = vid[rng.integers(0, V, E)]
+    dst = vid[rng.integers(0, V, E)]
+    src[:60_000] = vid[rng.integers(0, 4, 60_000)]        # four hubs with huge out-rows
+    dst[60_000:120_000] = vid[rng.integers(4, 8, 60_000)]  # four with huge in-rows
+    # 3000 vertices that are only ever destinations of edges leaving vertices nobody points to
+    lonely_src = vid[V - 6000:V - 3000]
+    keep = ~np.isin(dst, lonely_src)
+    src, dst = src[keep], dst[keep]
+    src = np.concatenate([src, np.repeat(lonely_src, 3)])
+    dst = np.concatenate([dst, vid[rng.integers(V - 3000, V, 9000)]])
+    gg.staging_clear()
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    csr = gg.build_csr()
+    for kmin in (1, 2, 3):
+        got = gg.expand_khop(csr, kmin, 3)
+        gg.force_frontier(True)
+        try:
+            want = gg.expand_khop(csr, kmin, 3)
+        finally:
+            gg.force_frontier(False)
+        assert got == want, kmin
+    assert got["rows"][3] > 10**8
+    csr.close()
 
 
 def test_khop_mid_ranges_partition_the_result(gg, orc):
