@@ -100,6 +100,27 @@ class RefDuckDB:
         self.L.duckdb_destroy_result(C.byref(r))
         return out
 
+    def execute_text(self, sql: str) -> list:
+        """Run sql; return every row as a tuple of strings (None for NULL), whatever the column types."""
+        r = _Result()
+        self.L.duckdb_value_varchar.restype = C.c_void_p
+        self.L.duckdb_value_varchar.argtypes = [C.POINTER(_Result), C.c_uint64, C.c_uint64]
+        if self.L.duckdb_query(self.con, sql.encode(), C.byref(r)) != 0:
+            msg = r.error_message.decode() if r.error_message else "?"
+            self.L.duckdb_destroy_result(C.byref(r))
+            raise RuntimeError(f"reference query failed: {msg}")
+        rows = []
+        for i in range(r.row_count):
+            row = []
+            for c in range(r.column_count):
+                p = self.L.duckdb_value_varchar(C.byref(r), c, i)
+                row.append(C.string_at(p).decode() if p else None)
+                if p:
+                    self.L.duckdb_free(C.c_void_p(p))
+            rows.append(tuple(row))
+        self.L.duckdb_destroy_result(C.byref(r))
+        return rows
+
     def explain(self, sql: str) -> str:
         """Physical plan of sql as text (EXPLAIN's second column)."""
         r = _Result()

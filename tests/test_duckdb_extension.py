@@ -550,3 +550,40 @@ def test_pinned_graphs_are_opt_in_and_never_outlive_a_write(db):
         d.execute("SELECT * FROM gg_graph_unpin()")
         d.execute("PRAGMA gg_ignore_pinned_graphs")
         d.execute("PRAGMA disable_gpu_graph")
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_statements_shaped_like_the_ldbc_friends_queries_give_the_reference_result():
+    """Five statements with the shape of the reference's interactive-complex-3/5/6/9/11 (tests/ldbc_shapes.py:
+    friends UNION friends-of-friends of one person, joined with person / place / message / forum / organisation /
+    tag columns, aggregated, ordered, limited) over a populated database: with the planner rules on, the
+    friends-of-friends join runs as GG_PATH_EXPAND on the GPU, everything above it — the UNION, the joins that
+    fetch the projected person columns, aggregates, ORDER BY, LIMIT — stays with the reference's operators, and
+    every statement returns exactly the rows the reference's own plan returns, in order."""
+    from tests import ldbc_shapes
+    d = R.RefDuckDB(threads=4)
+    ldbc_shapes.populate(d)
+    d.execute(f"LOAD '{EXT}'")
+    try:
+        for name, sql in ldbc_shapes.statements().items():
+            d.execute("PRAGMA disable_gpu_graph")
+            assert "GG_" not in d.explain(sql)
+            cpu = d.execute_text(sql)
+            d.execute("PRAGMA enable_gpu_graph")
+            assert "GG_PATH_EXPAND" in d.explain(sql), name
+            gpu = d.execute_text(sql)
+            assert len(cpu) > 0 and gpu == cpu, name
+        # inside a transaction that changed the edge table the statement still sees its own rows
+        d.execute("PRAGMA enable_gpu_graph")
+        d.execute("BEGIN")
+        d.execute(f"INSERT INTO knows VALUES ('2012-01-01 00:00:00', {ldbc_shapes.PERSON_B}, 424242), "
+                  f"('2012-01-01 00:00:00', 424242, {ldbc_shapes.PERSON_A})")
+        sql = f"select count(*) from {ldbc_shapes.friends(ldbc_shapes.PERSON_B, ldbc_shapes.PERSON_B)}"
+        with_rows = d.execute(sql)[0, 0]
+        d.execute("ROLLBACK")
+        without = d.execute(sql)[0, 0]
+        d.execute("PRAGMA disable_gpu_graph")
+        assert without == d.execute(sql)[0, 0] and with_rows >= without + 1
+    finally:
+        d.execute("PRAGMA disable_gpu_graph")
+        d.close()

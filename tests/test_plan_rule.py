@@ -176,6 +176,7 @@ def test_other_recursive_ctes_are_left_alone(db, sql):
 
 # ---- walks whose vertices share a neighbour in a second edge table (Train Benchmark ConnectedSegments) ----
 from tests.trainbenchmark import connectedsegments_sql  # noqa: E402
+from tests import ldbc_shapes  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -237,9 +238,10 @@ def test_payload_column_keeps_its_join_on_the_cpu(traindb):
 LDBC_DIR = "/root/reference/benchmark/ldbc"
 
 
-def _ldbc_database():
+def _ldbc_database(populated=False):
     """benchmark/ldbc/schema.sql as shipped, one plausible row per table (joins over empty tables are folded
-    to EMPTY_RESULT before any planner rule sees them) and a few knows rows."""
+    to EMPTY_RESULT before any planner rule sees them) and a few knows rows; `populated` adds the few thousand
+    rows of tests/ldbc_shapes.py on top."""
     d = R.RefDuckDB(threads=2)
     ddl = open(os.path.join(LDBC_DIR, "schema.sql")).read()
     for stmt in ddl.split(";"):
@@ -260,16 +262,35 @@ def _ldbc_database():
         d.execute(f"INSERT INTO {name} VALUES (" + ", ".join(defaults.get(c.split("(")[0], "NULL") for c in cols) + ")")
     d.execute("INSERT INTO knows VALUES ('2012-01-01 00:00:00', 21990232556256, 2), ('2012-01-01 00:00:00', 2, 3), "
               "('2012-01-01 00:00:00', 6597069767251, 2), ('2012-01-01 00:00:00', 19791209310731, 2)")
+    if populated:
+        ldbc_shapes.populate(d, create=False)
     d.execute(f"LOAD '{EXT}'")
     return d
 
 
+def test_statements_shaped_like_the_ldbc_queries_get_gpu_operators():
+    """tests/ldbc_shapes.py generates five statements with the shape of interactive-complex-3/5/6/9/11 over a
+    populated database (the GPU suite compares their results under both plans): each gets its friends-of-friends
+    join planned as GG_PATH_EXPAND, and its result under the reference's own plan is not empty."""
+    d = R.RefDuckDB(threads=2)
+    ldbc_shapes.populate(d)
+    d.execute(f"LOAD '{EXT}'")
+    for name, sql in ldbc_shapes.statements().items():
+        assert len(d.execute_text(sql)) > 0, name
+        d.execute("PRAGMA enable_gpu_graph")
+        plan = d.explain(sql)
+        d.execute("PRAGMA disable_gpu_graph")
+        assert "GG_PATH_EXPAND" in plan, (name, plan)
+    d.close()
+
+
 @pytest.mark.skipif(not os.path.isdir(LDBC_DIR), reason="reference tree not present")
-def test_the_references_ldbc_queries_get_gpu_operators():
+@pytest.mark.parametrize("populated", [False, True])
+def test_the_references_ldbc_queries_get_gpu_operators(populated):
     """The LDBC interactive queries of the reference that walk KNOWS twice (friends of friends:
     interactive-complex-3/5/6/9/11) get their `knows k1, knows k2` join planned as GG_PATH_EXPAND — from the
     query files as shipped, inside plans that join the result with person, place, message, ..."""
-    d = _ldbc_database()
+    d = _ldbc_database(populated)
     d.execute("PRAGMA enable_gpu_graph")
     # (interactive-complex-10 and bi-10 hold the same shapes, but their other predicates — string
     # constants, dates — let statistics propagation fold the whole plan to EMPTY_RESULT on one-row tables;
