@@ -1038,10 +1038,11 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
     if (span < DIRECT_MAX_RANGE) span = DIRECT_MAX_RANGE;
     if (span < V) span = V;
     GG_LAUNCH(ctx, "dict_init", k_dict_init, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_cap, tab, 2 * npairs, dir, dm);
+              csr->ht_cap, tab, 2 * npairs, dir, dm, st, (uint32_t)csr->part, (uint32_t)csr->n_parts);
     GG_LAUNCH(ctx, "dict_insert", k_dict_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_cap, tab, dir, dm, idx_bits, q, st, (uint32_t)csr->part, (uint32_t)csr->n_parts);
-    GG_LAUNCH(ctx, "dict_wide", k_dict_wide, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
+              csr->ht_cap, tab, dir, dm, idx_bits, q, st);
+    GG_LAUNCH(ctx, "dict_wide", k_dict_wide, dim3((unsigned)((V + 255) / 256 < 512 ? (V + 255) / 256 : 512)), dim3(256), 0,
+              csr->vid, V, csr->ht,
               csr->ht_cap, (const DirectMap *)dm, st);
   }
 

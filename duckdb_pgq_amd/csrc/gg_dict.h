@@ -194,7 +194,7 @@ __device__ __forceinline__ uint32_t packed_resolve(const unsigned long long *__r
 // ---- the bucketed build's dictionary in two launches (+ one that normally does nothing) -------------------------
 // k_dict_init    clears all three candidate tables and takes the ids' min / max in the same pass
 // k_dict_insert  every thread derives the mode from min / max (thread 0 publishes it), inserts its vertex into the
-//                table of that mode, reports duplicate ids, counts owned vertices (shards)
+//                table of that mode, reports duplicate ids
 // k_dict_wide    only if a packed insert had to give up (mode flipped to DICT_WIDE16): fills the 16-byte table
 __device__ __forceinline__ unsigned long long dict_mode_of(long long min_id, long long max_id, uint64_t V,
                                                            uint32_t idx_bits, uint32_t q, uint32_t *span_bits_out) {
@@ -210,7 +210,9 @@ __device__ __forceinline__ unsigned long long dict_mode_of(long long min_id, lon
 static __global__ __launch_bounds__(256) void k_dict_init(const int64_t *__restrict__ vid, uint64_t V,
                                                           HtSlot *__restrict__ ht, uint64_t cap,
                                                           unsigned long long *__restrict__ tab, uint64_t nslots,
-                                                          uint32_t *__restrict__ dir, DirectMap *__restrict__ dm) {
+                                                          uint32_t *__restrict__ dir, DirectMap *__restrict__ dm,
+                                                          BuildStatus *__restrict__ st, uint32_t part,
+                                                          uint32_t n_parts) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < cap) {
     uint4 e;
@@ -222,12 +224,19 @@ static __global__ __launch_bounds__(256) void k_dict_init(const int64_t *__restr
   }
   if (i < nslots) tab[i] = PK_EMPTY;
   if (i < DIRECT_MAX_RANGE) dir[i] = INVALID_U32;
-  if (blockIdx.x < 64) {  // min / max: 64 workgroups stride over the ids (two same-address atomics each, not two per block)
-    long long lo = INT64_MAX, hi = INT64_MIN;
+  if (blockIdx.x < 64) {  // min / max (and a shard's owned-vertex count): 64 workgroups stride over the ids
+    long long lo = INT64_MAX, hi = INT64_MIN;  // (two or three same-address atomics each, not per block of the grid)
+    uint32_t owned = 0;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += 64ull * blockDim.x) {
       const long long x = vid[v];
       lo = x < lo ? x : lo;
       hi = x > hi ? x : hi;
+      if (n_parts > 1 && owns(x, part, n_parts)) owned++;
+    }
+    if (n_parts > 1) {  // (whole builds own everything: set on the host)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) owned += __shfl_xor(owned, o, 64);
+      if ((threadIdx.x & 63) == 0 && owned) atomicAdd(&st->owned, (unsigned long long)owned);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -284,8 +293,7 @@ static __global__ __launch_bounds__(256) void k_dict_insert(const int64_t *__res
                                                             HtSlot *__restrict__ ht, uint64_t cap,
                                                             unsigned long long *__restrict__ tab,
                                                             uint32_t *__restrict__ dir, DirectMap *__restrict__ dm,
-                                                            uint32_t idx_bits, uint32_t q, BuildStatus *__restrict__ st,
-                                                            uint32_t part, uint32_t n_parts) {
+                                                            uint32_t idx_bits, uint32_t q, BuildStatus *__restrict__ st) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const long long min_id = dm->min_id, max_id = dm->max_id;  // complete: k_dict_init has finished
   uint32_t span_bits;
@@ -297,16 +305,6 @@ static __global__ __launch_bounds__(256) void k_dict_insert(const int64_t *__res
     dm->span_bits = span_bits;
     dm->q = q;
     if (mode != DICT_PACKED8) dm->mode = mode;  // packed: starts as DICT_PACKED8 (host), a failed insert flips it
-  }
-  if (n_parts > 1) {  // owned-vertex count (whole builds own everything: set on the host)
-    __shared__ uint32_t s_owned;
-    if (threadIdx.x == 0) s_owned = 0;
-    __syncthreads();
-    const bool mine = i < V && owns(vid[i < V ? i : 0], part, n_parts);
-    const uint64_t om = __ballot(mine);
-    if ((threadIdx.x & 63) == 0 && om) atomicAdd(&s_owned, (uint32_t)__popcll(om));
-    __syncthreads();
-    if (threadIdx.x == 0 && s_owned) atomicAdd(&st->owned, (unsigned long long)s_owned);
   }
   if (i >= V) return;
   if (mode == DICT_DIRECT) {
@@ -345,10 +343,10 @@ static __global__ __launch_bounds__(256) void k_dict_wide(const int64_t *__restr
                                                           HtSlot *__restrict__ ht, uint64_t cap,
                                                           const DirectMap *__restrict__ dm,
                                                           BuildStatus *__restrict__ st) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) st->dict_mode = dm->mode;  // final: k_dict_insert has finished
+  const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 == 0) st->dict_mode = dm->mode;  // final: k_dict_insert has finished
   if (dm->mode != DICT_WIDE16 || dm->decided == DICT_WIDE16) return;  // normally: nothing to do
-  if (i < V) ht_insert_one(vid, i, ht, cap, st);
+  for (uint64_t i = i0; i < V; i += (uint64_t)gridDim.x * blockDim.x) ht_insert_one(vid, i, ht, cap, st);
 }
 
 }  // namespace gg
