@@ -455,6 +455,57 @@ __global__ __launch_bounds__(256) void k_bfs_pairs_fill_packed(const DistT *__re
   }
 }
 
+// ---- distinct walk endpoints (the UNION of the 1..k-hop endpoint sets of a source list) -----------------------
+// Set image under the edge relation, level by level: bits[h] = out-neighbours of bits[h - 1].  Unlike the BFS
+// there is no seen mask: a vertex that ends walks of several lengths carries several bits.
+__global__ __launch_bounds__(256) void k_set_seed(const uint32_t *__restrict__ dense, uint64_t n,
+                                                  uint32_t *__restrict__ bits) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && dense[i] != INVALID_U32) atomicOr(&bits[dense[i] >> 5], 1u << (dense[i] & 31u));
+}
+
+// sixteen lanes per member vertex walk its row
+__global__ __launch_bounds__(256) void k_set_expand(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                    const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                    uint64_t V) {
+  const uint64_t v = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const uint32_t sub = threadIdx.x & 15u;
+  if (v >= V || !((in[v >> 5] >> (v & 31u)) & 1u)) return;
+  const uint32_t a = off[v], b = off[v + 1];
+  for (uint32_t e = a + sub; e < b; e += 16) {
+    const uint32_t w = nbr[e];
+    const uint32_t bit = 1u << (w & 31u);
+    if (!(out[w >> 5] & bit)) atomicOr(&out[w >> 5], bit);
+  }
+}
+
+// bits is (k_max + 1) consecutive arrays of `words` u32: mask of vertex v = bit h for every level h >= 1 that holds it
+__device__ __forceinline__ uint32_t endpoint_mask(const uint32_t *__restrict__ bits, uint64_t words, int k_max,
+                                                  uint64_t v) {
+  uint32_t m = 0;
+  for (int h = 1; h <= k_max; h++) m |= ((bits[(uint64_t)h * words + (v >> 5)] >> (v & 31u)) & 1u) << h;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void k_endpoint_count(const uint32_t *__restrict__ bits, uint64_t words, int k_max,
+                                                        uint64_t V, uint32_t *__restrict__ counts) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) counts[v] = endpoint_mask(bits, words, k_max, v) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_endpoint_fill(const uint32_t *__restrict__ bits, uint64_t words, int k_max,
+                                                       uint64_t V, const uint32_t *__restrict__ offsets,
+                                                       const int64_t *__restrict__ vid, int64_t *__restrict__ out_id,
+                                                       int64_t *__restrict__ out_mask) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const uint32_t m = endpoint_mask(bits, words, k_max, v);
+  if (m) {
+    out_id[offsets[v]] = vid[v];
+    out_mask[offsets[v]] = (int64_t)m;
+  }
+}
+
 }  // namespace gg
 
 // One BFS with DistT distance cells.  *overflow is set (and nothing is returned) if the frontier is
@@ -895,3 +946,70 @@ extern "C" int gg_bfs_sharded_pairs(gg_bfs_run *run, gg_result **out_result) {
   return GG_OK;
 }
 
+extern "C" int gg_walk_endpoints(gg_ctx *ctx, const gg_csr *csr_c, const int64_t *src_ids, uint64_t n_src, int k_max,
+                                 gg_result **out_result) {
+  if (!out_result) return GG_ERR_INVALID_ARG;
+  *out_result = nullptr;
+  gg_csr *csr = const_cast<gg_csr *>(csr_c);
+  ApiScope scope(ctx);
+  if (!ctx || !csr || csr->ctx != ctx || (n_src && !src_ids) || k_max < 1 || k_max > GG_MAX_HOPS) {
+    set_error("gg_walk_endpoints: bad argument (1 <= k_max <= %d)", GG_MAX_HOPS);
+    return GG_ERR_INVALID_ARG;
+  }
+  if (csr->n_parts > 1) {
+    set_error("gg_walk_endpoints needs a whole CSR, not a shard");
+    return GG_ERR_STATE;
+  }
+  GG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t V = csr->V;
+  gg_result *res = new gg_result();
+  res->ctx = ctx;
+  res->k_min = res->k_max = 1;  // table 1: (vertex id, mask of walk lengths)
+  struct Guard {  // hand the result out only on success
+    gg_result *r;
+    ~Guard() {
+      if (r) gg_result_destroy(r);
+    }
+  } guard{res};
+  if (V && n_src) {
+    const uint64_t words = (V + 31) / 32;
+    int64_t *ids_dev = nullptr;
+    uint32_t *dense = nullptr, *bits = nullptr, *counts = nullptr;
+    uint64_t *total = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&ids_dev, n_src * sizeof(int64_t)));
+    GG_TRY(ctx->dev_alloc((void **)&dense, n_src * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&bits, (uint64_t)(k_max + 1) * words * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&counts, V * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&total, sizeof(uint64_t)));
+    GG_HIP(hipMemcpyAsync(ids_dev, src_ids, n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    GG_HIP(hipStreamSynchronize(s));  // src_ids is caller memory: consumed before return
+    GG_HIP(hipMemsetAsync(bits, 0, (uint64_t)(k_max + 1) * words * sizeof(uint32_t), s));
+    GG_TRY(lookup_ids(ctx, csr, ids_dev, n_src, dense));
+    GG_LAUNCH(ctx, "set_seed", k_set_seed, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, (const uint32_t *)dense, n_src,
+              bits);
+    const unsigned vgrid = (unsigned)((V + 255) / 256), xgrid = (unsigned)((V * 16 + 255) / 256);
+    for (int h = 1; h <= k_max; h++)
+      GG_LAUNCH(ctx, "set_expand", k_set_expand, dim3(xgrid), dim3(256), 0, csr->off, csr->nbr,
+                (const uint32_t *)(bits + (uint64_t)(h - 1) * words), bits + (uint64_t)h * words, V);
+    GG_LAUNCH(ctx, "endpoint_count", k_endpoint_count, dim3(vgrid), dim3(256), 0, (const uint32_t *)bits, words, k_max, V,
+              counts);
+    GG_TRY(scan_exclusive_u32(ctx, counts, counts, V, total));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    GG_TRY(scan_error_fetch(ctx));
+    GG_HIP(hipStreamSynchronize(s));
+    GG_TRY(scan_error_test(ctx));
+    const uint64_t rows = ctx->pin_scratch[0];
+    if (rows) {
+      for (int c = 0; c < 2; c++) GG_TRY(ctx->dev_alloc((void **)&res->cols[1][c], rows * sizeof(int64_t)));
+      GG_LAUNCH(ctx, "endpoint_fill", k_endpoint_fill, dim3(vgrid), dim3(256), 0, (const uint32_t *)bits, words, k_max, V,
+                (const uint32_t *)counts, (const int64_t *)csr->vid, res->cols[1][0], res->cols[1][1]);
+      GG_HIP(hipStreamSynchronize(s));
+      for (int c = 0; c < 2; c++) ctx->keep(res->cols[1][c]);
+      res->rows[1] = rows;
+    }
+  }
+  guard.r = nullptr;
+  *out_result = res;
+  return GG_OK;
+}

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
-    "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
+    "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_walk_endpoints", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
     "gg_bfs_sharded_begin", "gg_bfs_sharded_expand", "gg_bfs_sharded_words", "gg_bfs_sharded_commit",
     "gg_bfs_sharded_pairs", "gg_bfs_sharded_end",
     "gg_profile_enable", "gg_profile_select", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
@@ -110,6 +110,7 @@ def load_library(path: str | None = None):
     lib.gg_csr_lookup.argtypes = [P, P, i64p, u64, C.POINTER(C.c_uint32)]
     lib.gg_bfs64_pairs.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
     lib.gg_bfs64_pairs_packed.argtypes = [P, P, i64p, C.c_int, C.c_int, C.POINTER(BfsStats), C.POINTER(P)]
+    lib.gg_walk_endpoints.argtypes = [P, P, i64p, u64, C.c_int, C.POINTER(P)]
     lib.gg_bfs_sharded_begin.argtypes = [P, P, i64p, C.c_int, C.POINTER(P)]
     lib.gg_bfs_sharded_expand.argtypes = [P, C.POINTER(C.c_void_p), C.POINTER(u64), C.POINTER(u64)]
     lib.gg_bfs_sharded_words.argtypes = [P, C.POINTER(C.c_uint64), C.c_int]
@@ -488,6 +489,26 @@ class GG:
             self.lib.gg_result_destroy(res)
         return out.T.copy(), {"levels": st.levels, "traversed_edges": st.traversed_edges,
                               "active_vertices": st.active_vertices, "reached_pairs": st.reached_pairs}
+
+    def walk_endpoints(self, csr: Csr, sources, k_max: int):
+        """gg_walk_endpoints: (vertex ids, masks) — bit h of a mask: the vertex ends a walk of exactly h edges
+        from one of the sources."""
+        i64p = C.POINTER(C.c_int64)
+        s, ps = _i64(sources)
+        res = C.c_void_p()
+        self._chk(self.lib.gg_walk_endpoints(self.ctx, csr.handle, ps, s.size, k_max, C.byref(res)))
+        try:
+            n = C.c_uint64()
+            self._chk(self.lib.gg_result_rows(res, 1, C.byref(n)))
+            out = np.empty((2, n.value), np.int64)
+            if n.value:
+                ptrs = (i64p * 2)(*[out[c].ctypes.data_as(i64p) for c in range(2)])
+                got = C.c_uint32()
+                self._chk(self.lib.gg_result_fetch(res, 1, 0, n.value, ptrs, C.byref(got)))
+                assert got.value == n.value
+        finally:
+            self.lib.gg_result_destroy(res)
+        return out[0].copy(), out[1].copy()
 
     # ---- graph-sharded BFS (one shard per GPU; see include/gg.h)
     def bfs_sharded_begin(self, shard: Csr, sources) -> "ShardedBfs":

@@ -619,6 +619,57 @@ void PhysicalGGFilteredPaths::GetData(ExecutionContext &context, DataChunk &chun
 }
 
 //===--------------------------------------------------------------------===//
+// Distinct walk endpoints source
+//===--------------------------------------------------------------------===//
+vector<LogicalType> PhysicalGGWalkEndpoints::OutputTypes(int k_max) {
+	return BigintColumns(1 + k_max);
+}
+
+PhysicalGGWalkEndpoints::PhysicalGGWalkEndpoints(shared_ptr<GGGraph> graph_p, vector<int64_t> sources_p, int k_max_p,
+                                                 idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, OutputTypes(k_max_p), estimated_cardinality),
+      graph(move(graph_p)), sources(move(sources_p)), k_max(k_max_p) {
+}
+
+unique_ptr<GlobalSourceState> PhysicalGGWalkEndpoints::GetGlobalSourceState(ClientContext &context) const {
+	auto state = make_unique<GGFilteredGlobalState>();
+	lock_guard<mutex> guard(graph->lock);
+	if (!graph->csr) {
+		throw InternalException("GG_WALK_ENDPOINTS scheduled before the CSR was built");
+	}
+	GGGraph::Check(gg_walk_endpoints(graph->ctx, graph->csr, sources.data(), sources.size(), k_max, &state->result),
+	               "gg_walk_endpoints");
+	uint64_t n = 0;
+	GGGraph::Check(gg_result_rows(state->result, 1, &n), "gg_result_rows");
+	state->rows = n;
+	return move(state);
+}
+
+void PhysicalGGWalkEndpoints::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
+                                      LocalSourceState &lstate) const {
+	auto &gstate = (GGFilteredGlobalState &)gstate_p;
+	if (gstate.offset >= gstate.rows) {
+		return;
+	}
+	int64_t masks[STANDARD_VECTOR_SIZE];
+	int64_t *cols[2] = {FlatVector::GetData<int64_t>(chunk.data[0]), masks};
+	uint32_t n = 0;
+	{
+		lock_guard<mutex> guard(graph->lock);
+		GGGraph::Check(gg_result_fetch(gstate.result, 1, gstate.offset, STANDARD_VECTOR_SIZE, cols, &n),
+		               "gg_result_fetch");
+	}
+	for (int h = 1; h <= k_max; h++) {
+		auto flags = FlatVector::GetData<int64_t>(chunk.data[h]);
+		for (uint32_t i = 0; i < n; i++) {
+			flags[i] = (masks[i] >> h) & 1;
+		}
+	}
+	gstate.offset += n;
+	chunk.SetCardinality(n);
+}
+
+//===--------------------------------------------------------------------===//
 // Shortest path source
 //===--------------------------------------------------------------------===//
 class GGShortestGlobalState : public GlobalSourceState {

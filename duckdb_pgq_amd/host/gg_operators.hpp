@@ -199,6 +199,31 @@ public:
 	}
 };
 
+//! Source: (vertex id BIGINT, h1 BIGINT, ..., hk BIGINT) — one row per vertex that ends a walk of 1..k_max edges from
+//! one of the sources; h = 1 iff a walk of exactly h edges ends there (gg_walk_endpoints).  The device form of the
+//! reference's hash-aggregate dedupe above a UNION of endpoint sets (interactive-complex-3.sql:3-12).
+class PhysicalGGWalkEndpoints : public PhysicalOperator {
+public:
+	PhysicalGGWalkEndpoints(shared_ptr<GGGraph> graph, vector<int64_t> sources, int k_max, idx_t estimated_cardinality);
+
+	static vector<LogicalType> OutputTypes(int k_max);
+
+	shared_ptr<GGGraph> graph;
+	vector<int64_t> sources;
+	int k_max;
+
+public:
+	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
+	             LocalSourceState &lstate) const override;
+	bool IsSource() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_WALK_ENDPOINTS";
+	}
+};
+
 //! Source: (startPerson BIGINT, friend BIGINT, hopCount INTEGER) for every pair reached within
 //! max_hops — the friends_shortest relation of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31.
 //! Sources are processed in batches of 64 bit lanes.

@@ -28,18 +28,21 @@
 #define SYM_INSERT "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_13LogicalInsertE"
 #define SYM_DELETE "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_13LogicalDeleteE"
 #define SYM_UPDATE "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_13LogicalUpdateE"
+#define SYM_DISTINCT "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_15LogicalDistinctE"
 
 typedef void *(*create_plan_fn)(void *ret_slot, void *generator, void *logical_op);
 
 static gg_plan_rule_fn g_rule[GG_PLAN_HOOK_KINDS];
 static create_plan_fn g_orig[GG_PLAN_HOOK_KINDS];
-static const char *const g_sym[GG_PLAN_HOOK_KINDS] = {SYM_JOIN, SYM_AGGR, SYM_INSERT, SYM_DELETE, SYM_UPDATE};
+static const char *const g_sym[GG_PLAN_HOOK_KINDS] = {SYM_JOIN, SYM_AGGR, SYM_INSERT, SYM_DELETE, SYM_UPDATE,
+                                                          SYM_DISTINCT};
 
 void *gg_hook_create_plan_join(void *ret_slot, void *generator, void *op) __asm__(SYM_JOIN);
 void *gg_hook_create_plan_aggregate(void *ret_slot, void *generator, void *op) __asm__(SYM_AGGR);
 void *gg_hook_create_plan_insert(void *ret_slot, void *generator, void *op) __asm__(SYM_INSERT);
 void *gg_hook_create_plan_delete(void *ret_slot, void *generator, void *op) __asm__(SYM_DELETE);
 void *gg_hook_create_plan_update(void *ret_slot, void *generator, void *op) __asm__(SYM_UPDATE);
+void *gg_hook_create_plan_distinct(void *ret_slot, void *generator, void *op) __asm__(SYM_DISTINCT);
 
 struct find_ctx {
   const char *sym;
@@ -109,6 +112,10 @@ void *gg_hook_create_plan_delete(void *ret_slot, void *generator, void *op) {
 
 void *gg_hook_create_plan_update(void *ret_slot, void *generator, void *op) {
   return dispatch(GG_PLAN_HOOK_UPDATE, (void *)gg_hook_create_plan_update, ret_slot, generator, op);
+}
+
+void *gg_hook_create_plan_distinct(void *ret_slot, void *generator, void *op) {
+  return dispatch(GG_PLAN_HOOK_DISTINCT, (void *)gg_hook_create_plan_distinct, ret_slot, generator, op);
 }
 
 int gg_plan_hook_register(int kind, gg_plan_rule_fn rule) {

@@ -14,7 +14,9 @@ enum {
   GG_PLAN_HOOK_INSERT = 2,
   GG_PLAN_HOOK_DELETE = 3,
   GG_PLAN_HOOK_UPDATE = 4,
-  GG_PLAN_HOOK_KINDS = 5
+  /* DISTINCT (the dedupe above a UNION of walk endpoints) */
+  GG_PLAN_HOOK_DISTINCT = 5,
+  GG_PLAN_HOOK_KINDS = 6
 };
 
 /* A rule looks at the logical operator about to be planned.  To take it over it constructs a

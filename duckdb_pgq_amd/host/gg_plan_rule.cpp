@@ -71,6 +71,7 @@
 #include "duckdb/planner/operator/logical_chunk_get.hpp"
 #include "duckdb/planner/operator/logical_comparison_join.hpp"
 #include "duckdb/planner/operator/logical_cteref.hpp"
+#include "duckdb/planner/operator/logical_distinct.hpp"
 #include "duckdb/planner/operator/logical_filter.hpp"
 #include "duckdb/planner/operator/logical_projection.hpp"
 #include "duckdb/planner/operator/logical_recursive_cte.hpp"
@@ -1937,6 +1938,141 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	return move(projection);
 }
 
+//===--------------------------------------------------------------------===//
+// Distinct rule: the dedupe above a UNION of 1-hop and 2-hop endpoints of one source
+//===--------------------------------------------------------------------===//
+// benchmark/ldbc/queries/interactive-complex-3.sql:3-12 (and -5, -6, -9, -11): the friends of a person UNION the
+// friends of those friends,
+//
+//     select dst from e where src = C
+//     union
+//     select e2.dst from e e1, e e2 where e1.src = C and e1.dst = e2.src [and e2.dst <> X ...]
+//
+// which the reference plans as PhysicalUnion under a hash aggregate that dedupes the ids
+// (plan_distinct.cpp:12-78, physical_hash_aggregate.cpp:152-266).  On the device both branches are set images
+// under the edge relation (gg_walk_endpoints): one row per endpoint with a flag per walk length, so the UNION
+// is a filter — in the 1-hop set, or in the 2-hop set and passing the second branch's own predicates on the endpoint —
+// and nothing is left to dedupe.
+unique_ptr<PhysicalOperator> PlanDistinctUnion(LogicalDistinct &op) {
+	if (op.children.size() != 1 || op.types.size() != 1 || op.children[0]->type != LogicalOperatorType::LOGICAL_UNION) {
+		return nullptr;
+	}
+	if (op.distinct_targets.size() > 1 ||
+	    (op.distinct_targets.size() == 1 && (op.distinct_targets[0]->type != ExpressionType::BOUND_REF ||
+	                                         ((BoundReferenceExpression &)*op.distinct_targets[0]).index != 0))) {
+		return nullptr;
+	}
+	auto &setop = *op.children[0];
+	if (setop.children.size() != 2 || setop.types.size() != 1) {
+		return nullptr;
+	}
+	// which branch is the join?
+	LogicalOperator *one = nullptr, *two = nullptr;
+	for (auto &child : setop.children) {
+		if (child->type != LogicalOperatorType::LOGICAL_PROJECTION || child->children.size() != 1 ||
+		    child->expressions.size() != 1 || child->expressions[0]->type != ExpressionType::BOUND_REF) {
+			return nullptr;
+		}
+		(child->children[0]->type == LogicalOperatorType::LOGICAL_COMPARISON_JOIN ? two : one) = child.get();
+	}
+	if (!one || !two) {
+		return nullptr;
+	}
+	// the 2-hop branch: a walk of two edges over one edge table, pinned at its first vertex, endpoint projected
+	PatternInput in2;
+	WalkPattern pattern;
+	auto &join = *two->children[0];
+	if (!CollectJoinTree(join, in2) || !SolveWalkPattern(in2, pattern) || pattern.hops != 2 || pattern.all_sources ||
+	    pattern.sources.size() != 1 || pattern.vertex_table) {
+		return nullptr;
+	}
+	for (auto &entry : pattern.residual) {
+		if (entry.first != 2) {
+			return nullptr; // a predicate on the middle vertex changes which walks exist
+		}
+	}
+	{
+		auto bindings = join.GetColumnBindings();
+		const auto index = ((BoundReferenceExpression &)*two->expressions[0]).index;
+		LeafColumn column;
+		if (index >= bindings.size() || !ResolveLeafColumn(in2, bindings[index], column) ||
+		    pattern.edge_position[column.leaf] != 2 || column.column != pattern.dst_column) {
+			return nullptr;
+		}
+	}
+	// the 1-hop branch: the same table, source and endpoint columns, the same constant, nothing else
+	PatternInput in1;
+	if (!CollectJoinTree(*one, in1) || in1.leaves.size() != 1 || in1.leaves[0].table != pattern.edge_table ||
+	    !in1.filters.empty() || in1.constants.size() != 1 || in1.constants[0].column.column != pattern.src_column ||
+	    in1.constants[0].value != pattern.sources[0] || in1.aliases.empty()) {
+		return nullptr;
+	}
+	{
+		auto &outputs = in1.aliases.back().second; // the projection on top of the branch
+		if (in1.aliases.back().first != ((LogicalProjection &)*one).table_index || outputs.size() != 1 ||
+		    outputs[0].column != pattern.dst_column) {
+			return nullptr;
+		}
+	}
+	auto &table = *pattern.edge_table;
+	if (!ColumnIsNotNull(table, pattern.dst_column) || table.columns[pattern.dst_column].type != op.types[0]) {
+		return nullptr; // a NULL endpoint is a row of the reference's UNION; the vertex set has no NULL
+	}
+
+	const auto spec = GraphSpecOf(pattern);
+	const auto sources = pattern.sources;
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = GGBuildGraph(context, spec);
+		opened.source = make_unique<PhysicalGGWalkEndpoints>(opened.graph, sources, 2, 0);
+	};
+	data->description = table.name + ": " + table.columns[pattern.src_column].name + " -> " +
+	                    table.columns[pattern.dst_column].name + "\ndistinct endpoints of 1..2 hops\nfrom " +
+	                    to_string(sources[0]);
+	auto types = PhysicalGGWalkEndpoints::OutputTypes(2);
+	vector<column_t> column_ids;
+	vector<string> names;
+	for (idx_t c = 0; c < types.size(); c++) {
+		column_ids.push_back(c);
+		names.push_back("c" + to_string(c));
+	}
+	g_rules_fired++;
+	unique_ptr<PhysicalOperator> scan =
+	    make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_walk_endpoints"), move(data), move(column_ids),
+	                                   move(names), nullptr, op.estimated_cardinality);
+	// scan columns: (id, h1, h2).  keep: h1 = 1 OR (h2 = 1 AND the second branch's predicates on the endpoint)
+	auto flag = [](idx_t column) {
+		return make_unique<BoundComparisonExpression>(ExpressionType::COMPARE_EQUAL,
+		                                              make_unique<BoundReferenceExpression>(LogicalType::BIGINT, column),
+		                                              make_unique<BoundConstantExpression>(Value::BIGINT(1)));
+	};
+	unique_ptr<Expression> second = flag(2);
+	if (!pattern.residual.empty()) {
+		auto both = make_unique<BoundConjunctionExpression>(ExpressionType::CONJUNCTION_AND);
+		both->children.push_back(move(second));
+		for (auto &entry : pattern.residual) {
+			both->children.push_back(FilterToExpression(*entry.second, 0));
+		}
+		second = move(both);
+	}
+	auto keep = make_unique<BoundConjunctionExpression>(ExpressionType::CONJUNCTION_OR);
+	keep->children.push_back(flag(1));
+	keep->children.push_back(move(second));
+	vector<unique_ptr<Expression>> predicates;
+	predicates.push_back(move(keep));
+	auto filter = make_unique<PhysicalFilter>(scan->types, move(predicates), op.estimated_cardinality);
+	filter->children.push_back(move(scan));
+	vector<unique_ptr<Expression>> select_list;
+	unique_ptr<Expression> ref = make_unique<BoundReferenceExpression>(LogicalType::BIGINT, 0);
+	if (op.types[0] != LogicalType::BIGINT) {
+		ref = make_unique<BoundCastExpression>(move(ref), op.types[0]);
+	}
+	select_list.push_back(move(ref));
+	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
+	projection->children.push_back(move(filter));
+	return move(projection);
+}
+
 unique_ptr<PhysicalOperator> PlanAggregate(LogicalAggregate &op) {
 	if (auto plan = PlanCountOverJoinChain(op)) {
 		return plan;
@@ -2022,6 +2158,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 	}
 	reg(GG_PLAN_HOOK_JOIN, RuleEntry<LogicalComparisonJoin, PlanJoinChain>);
 	reg(GG_PLAN_HOOK_AGGREGATE, RuleEntry<LogicalAggregate, PlanAggregate>);
+	reg(GG_PLAN_HOOK_DISTINCT, RuleEntry<LogicalDistinct, PlanDistinctUnion>);
 	reg(GG_PLAN_HOOK_INSERT, WriteObserver<LogicalInsert>);
 	reg(GG_PLAN_HOOK_DELETE, WriteObserver<LogicalDelete>);
 	reg(GG_PLAN_HOOK_UPDATE, WriteObserver<LogicalUpdate>);

@@ -28,6 +28,10 @@
  *                                                               src/execution/aggregate_hashtable.cpp:367-504,
  *                                                               src/execution/operator/aggregate/physical_hash_aggregate.cpp:152-266
  *           (the friends/friends_shortest CTE pair of benchmark/ldbc/queries/bi-10-shortestpath.sql:8-31)
+ *   gg_walk_endpoints
+ *        <- PhysicalUnion + the hash-aggregate dedupe above it (friends UNION friends of friends)
+ *                                                               src/execution/physical_plan/plan_distinct.cpp:12-78,
+ *                                                               physical_hash_aggregate.cpp:152-266
  *   gg_vertices_from_edges
  *        <- the implicit vertex set of a join chain over an edge table alone (interactive-complex-3.sql:9-11)
  *   gg_result_filter_common_neighbour
@@ -222,6 +226,18 @@ int gg_bfs64_pairs(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n
  * the source list and the vertex ids (gg_csr_export) themselves. */
 int gg_bfs64_pairs_packed(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, int n_src, int max_hops,
                           gg_bfs_stats *stats, gg_result **out_result);
+
+/* Distinct endpoints of the walks of 1..k_max edges that start at any of the given sources — the device form of
+ *   SELECT dst FROM e WHERE src = C  UNION  SELECT e2.dst FROM e e1, e e2 WHERE e1.src = C AND e1.dst = e2.src
+ * (the friends / friends-of-friends table of benchmark/ldbc/queries/interactive-complex-3.sql:3-12), which the
+ * reference evaluates as PhysicalUnion under a hash-aggregate dedupe
+ * (src/execution/operator/set/physical_union.cpp, src/execution/operator/aggregate/physical_hash_aggregate.cpp:152-266).
+ * Table 1 of *out_result has one row (vertex id, mask) per vertex that ends at least one such walk: bit h of mask
+ * is set iff the vertex ends a walk of exactly h edges (walks, not shortest paths: a vertex can carry several bits,
+ * and a source on a cycle is its own endpoint).  Rows come in vertex-table order; sources that are not vertices
+ * contribute nothing.  Fetch with gg_result_rows(res, 1, &n) / gg_result_fetch(res, 1, offset, n, cols[2], &got). */
+int gg_walk_endpoints(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_max,
+                      gg_result **out_result);
 
 /* ---- graph-sharded 64-lane BFS (one shard of the graph per GPU) ------------------------------- */
 /* The layout north_star names for graphs that do not fit one GPU: `shard` comes from

@@ -119,7 +119,7 @@ def _both_plans(d, sql):
     assert "GG_" not in d.explain(sql)
     cpu = d.execute(sql)
     d.execute("PRAGMA enable_gpu_graph")
-    assert "GG_PATH" in d.explain(sql), d.explain(sql)
+    assert "GG_PATH" in d.explain(sql) or "GG_WALK_ENDPOINTS" in d.explain(sql), d.explain(sql)
     gpu = d.execute(sql)
     d.execute("PRAGMA disable_gpu_graph")
     return cpu, gpu
@@ -383,8 +383,8 @@ def test_plan_rule_predicates_on_walk_positions(db):
     for sql in cases:
         cpu, gpu = _both_plans(d, sql)
         assert cpu.shape[0] > 0 and np.array_equal(sort_rows(cpu), sort_rows(gpu)), sql
-    # the friends + friends-of-friends derived table of interactive-complex-3.sql:3-12, verbatim shape:
-    # the 2-hop branch of the UNION is substituted, the 1-hop branch and the UNION stay with the reference
+    # the friends + friends-of-friends derived table of interactive-complex-3.sql:3-12, verbatim shape: both
+    # branches and the dedupe of the UNION are one device operator (GG_WALK_ENDPOINTS)
     ic3 = (f"select k_person2id from knows where k_person1id = {s} union "
            f"select k2.k_person2id from knows k1, knows k2 where k1.k_person1id = {s} "
            f"and k1.k_person2id = k2.k_person1id and k2.k_person2id <> {s}")
@@ -557,9 +557,10 @@ def test_statements_shaped_like_the_ldbc_friends_queries_give_the_reference_resu
     """Five statements with the shape of the reference's interactive-complex-3/5/6/9/11 (tests/ldbc_shapes.py:
     friends UNION friends-of-friends of one person, joined with person / place / message / forum / organisation /
     tag columns, aggregated, ordered, limited) over a populated database: with the planner rules on, the
-    friends-of-friends join runs as GG_PATH_EXPAND on the GPU, everything above it — the UNION, the joins that
-    fetch the projected person columns, aggregates, ORDER BY, LIMIT — stays with the reference's operators, and
-    every statement returns exactly the rows the reference's own plan returns, in order."""
+    friends UNION friends-of-friends table — both branches and the dedupe — runs as GG_WALK_ENDPOINTS on the GPU,
+    everything above it — the joins that fetch the projected person columns, aggregates, ORDER BY, LIMIT — stays
+    with the reference's operators, and every statement returns exactly the rows the reference's own plan returns,
+    in order."""
     from tests import ldbc_shapes
     d = R.RefDuckDB(threads=4)
     ldbc_shapes.populate(d)
@@ -570,7 +571,7 @@ def test_statements_shaped_like_the_ldbc_friends_queries_give_the_reference_resu
             assert "GG_" not in d.explain(sql)
             cpu = d.execute_text(sql)
             d.execute("PRAGMA enable_gpu_graph")
-            assert "GG_PATH_EXPAND" in d.explain(sql), name
+            assert "GG_WALK_ENDPOINTS" in d.explain(sql), name
             gpu = d.execute_text(sql)
             assert len(cpu) > 0 and gpu == cpu, name
         # inside a transaction that changed the edge table the statement still sees its own rows

@@ -994,3 +994,39 @@ def test_a_scan_tile_that_never_publishes_is_an_error_not_a_wrong_csr(gg, orc):
         gg.scan_fault()
         gg.force_legacy_build(False)
         g.close()
+
+
+def _endpoint_sets(off, nbr, sources_dense, k_max):
+    """CPU restatement: level h = set image of level h - 1 under the oracle's CSR (walk endpoints, no seen mask)."""
+    V = off.size - 1
+    level = np.zeros(V, bool)
+    level[sources_dense] = True
+    masks = np.zeros(V, np.int64)
+    for h in range(1, k_max + 1):
+        nxt = np.zeros(V, bool)
+        for v in np.flatnonzero(level):
+            nxt[nbr[off[v]:off[v + 1]]] = True
+        masks |= nxt.astype(np.int64) << h
+        level = nxt
+    return masks
+
+
+@pytest.mark.parametrize("k_max", [1, 2, 3])
+def test_walk_endpoints_equal_the_union_of_the_hop_sets(gg, orc, k_max):
+    """gg_walk_endpoints — the device form of `SELECT dst ... UNION SELECT e2.dst ...` (friends and friends of
+    friends, interactive-complex-3.sql:3-12) — against set images computed from the oracle's CSR: one row per
+    endpoint, in vertex order, bit h set iff a walk of exactly h edges ends there (sources on cycles included);
+    unknown and duplicate sources, an empty source list, a vertex without edges."""
+    vid, src, dst = datagen.small_graph(3000, 40_000, 61, dangling=8, dup_edges=50)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    o_off, o_nbr, _, o_vid = g.arrays()
+    for sources in (vid[[5]], vid[[5, 5, 77, 2999]], np.concatenate([vid[:40], np.array([-5, 1 << 60], np.int64)]),
+                    np.zeros(0, np.int64), np.array([-7], np.int64)):
+        dense = g.lookup(sources)
+        dense = np.unique(dense[dense >= 0])
+        want = _endpoint_sets(o_off, o_nbr, dense, k_max)
+        ids, masks = gg.walk_endpoints(csr, sources, k_max)
+        keep = np.flatnonzero(want)
+        assert np.array_equal(ids, o_vid[keep]) and np.array_equal(masks, want[keep])
+    csr.close()
+    g.close()

@@ -270,8 +270,9 @@ def _ldbc_database(populated=False):
 
 def test_statements_shaped_like_the_ldbc_queries_get_gpu_operators():
     """tests/ldbc_shapes.py generates five statements with the shape of interactive-complex-3/5/6/9/11 over a
-    populated database (the GPU suite compares their results under both plans): each gets its friends-of-friends
-    join planned as GG_PATH_EXPAND, and its result under the reference's own plan is not empty."""
+    populated database (the GPU suite compares their results under both plans): each gets its friends UNION
+    friends-of-friends table planned as GG_WALK_ENDPOINTS (the dedupe included), and its result under the reference's
+    own plan is not empty."""
     d = R.RefDuckDB(threads=2)
     ldbc_shapes.populate(d)
     d.execute(f"LOAD '{EXT}'")
@@ -280,7 +281,40 @@ def test_statements_shaped_like_the_ldbc_queries_get_gpu_operators():
         d.execute("PRAGMA enable_gpu_graph")
         plan = d.explain(sql)
         d.execute("PRAGMA disable_gpu_graph")
-        assert "GG_PATH_EXPAND" in plan, (name, plan)
+        assert "GG_WALK_ENDPOINTS" in plan and "GG_PATH_EXPAND" not in plan, (name, plan)
+    d.close()
+
+
+def test_unions_that_are_not_friends_and_friends_of_friends_keep_their_dedupe():
+    """The distinct rule takes a UNION only if it is exactly {1-hop endpoints of C} UNION {2-hop endpoints of C
+    [with predicates on the endpoint]} over one edge table.  Anything else keeps the reference's UNION + hash
+    aggregate (the 2-hop branch alone may still become GG_PATH_EXPAND)."""
+    d = R.RefDuckDB(threads=2)
+    ldbc_shapes.populate(d)
+    d.execute("CREATE TABLE knows_nullable (a BIGINT, b BIGINT)")
+    d.execute("INSERT INTO knows_nullable SELECT k_person1id, k_person2id FROM knows")
+    d.execute(f"LOAD '{EXT}'")
+    d.execute("PRAGMA enable_gpu_graph")
+    a, b = ldbc_shapes.PERSON_A, ldbc_shapes.PERSON_B
+    one = "select k_person2id from knows where k_person1id = {}"
+    two = ("select k2.k_person2id from knows k1, knows k2 where k1.k_person1id = {} "
+           "and k1.k_person2id = k2.k_person1id{}")
+    taken = one.format(a) + " union " + two.format(a, "")
+    assert "GG_WALK_ENDPOINTS" in d.explain(taken)
+    assert "GG_WALK_ENDPOINTS" in d.explain(two.format(a, " and k2.k_person2id > 1000000") + " union " + one.format(a))
+    near_misses = [
+        one.format(a) + " union " + two.format(b, ""),                                   # two different people
+        one.format(a) + " union all " + two.format(a, ""),                               # no dedupe asked for
+        one.format(a) + " union " + two.format(a, " and k1.k_person2id <> 5"),           # predicate on the middle vertex
+        one.format(a) + " and k_person2id <> 7 union " + two.format(a, ""),              # predicate on the 1-hop branch
+        "select k_person1id from knows where k_person1id = {} union ".format(a) + two.format(a, ""),  # not the endpoint
+        one.format(a) + " union " + two.format(a, "").replace("select k2.k_person2id", "select k2.k_person1id"),
+        one.format(a) + " except " + two.format(a, ""),
+        ("select b from knows_nullable where a = {0} union select k2.b from knows_nullable k1, knows_nullable k2 "
+         "where k1.a = {0} and k1.b = k2.a").format(a),                                  # a NULL endpoint would be a row
+    ]
+    for sql in near_misses:
+        assert "GG_WALK_ENDPOINTS" not in d.explain(sql), sql
     d.close()
 
 
@@ -295,9 +329,10 @@ def test_the_references_ldbc_queries_get_gpu_operators(populated):
     # (interactive-complex-10 and bi-10 hold the same shapes, but their other predicates — string
     # constants, dates — let statistics propagation fold the whole plan to EMPTY_RESULT on one-row tables;
     # bi-10's friends/friends_shortest text is covered by test_friends_cte_with_min_hop_becomes_bfs)
-    expect = {"interactive-complex-3.sql": "GG_PATH_EXPAND", "interactive-complex-5.sql": "GG_PATH_EXPAND",
-              "interactive-complex-6.sql": "GG_PATH_EXPAND", "interactive-complex-9.sql": "GG_PATH_EXPAND",
-              "interactive-complex-11.sql": "GG_PATH_EXPAND"}
+    # the friends UNION friends-of-friends table of these five is ONE device operator (distinct walk endpoints)
+    expect = {"interactive-complex-3.sql": "GG_WALK_ENDPOINTS", "interactive-complex-5.sql": "GG_WALK_ENDPOINTS",
+              "interactive-complex-6.sql": "GG_WALK_ENDPOINTS", "interactive-complex-9.sql": "GG_WALK_ENDPOINTS",
+              "interactive-complex-11.sql": "GG_WALK_ENDPOINTS"}
     seen = {}
     for name in sorted(os.listdir(os.path.join(LDBC_DIR, "queries"))):
         sql = open(os.path.join(LDBC_DIR, "queries", name)).read().strip().rstrip(";")
@@ -305,7 +340,8 @@ def test_the_references_ldbc_queries_get_gpu_operators(populated):
             plan = d.explain(sql)
         except RuntimeError:
             continue  # a few of the shipped texts do not bind in this version of the reference either
-        seen[name] = [op for op in ("GG_PATH_EXPAND", "GG_PATH_COUNT", "GG_SHORTEST_PATH_BFS", "GG_SAME_NEIGHBOUR_WALKS")
+        seen[name] = [op for op in ("GG_PATH_EXPAND", "GG_PATH_COUNT", "GG_SHORTEST_PATH_BFS", "GG_SAME_NEIGHBOUR_WALKS",
+                                    "GG_WALK_ENDPOINTS")
                       if op in plan]
     d.close()
     for name, op in expect.items():
