@@ -1,0 +1,353 @@
+// gg_pipeline.cpp — the GPU graph's build side as REAL pipeline sinks of the reference's executor.
+//
+// The reference schedules a hash join's build side as a child pipeline whose sink is the join:
+// Executor::BuildPipelines (src/parallel/executor.cpp:385-580) creates a Pipeline per sink operator, makes the
+// consuming pipeline depend on it, and PipelineExecutor drives Sink / Combine / Finalize on the worker threads
+// (src/parallel/pipeline_executor.cpp).  Its switch over PhysicalOperatorType has no case for operators it does not
+// know ("Unimplemented sink type!", executor.cpp:475; "Operator not supported yet" for a non-sink with several
+// children, :571).  PhysicalGGGraphScan is such an operator: a SOURCE (the walks, counts, endpoint sets the GPU
+// produces) whose children are SINKS (the vertex / edge tables flowing into the device graph):
+//
+//     GG_PATH_EXPAND                       <- source of the consuming pipeline
+//       GG_VERTEX_SINK <- SEQ_SCAN person  <- child pipeline 1
+//       GG_EDGE_SINK   <- SEQ_SCAN knows   <- child pipeline 2 (depends on 1: its Finalize builds the CSR)
+//
+// GGBuildPipelinesRule is the missing case.  The maintainers' route is four lines in BuildPipelines' non-sink branch
+// (INTEGRATION.md §3); the reference tree is read-only here, so the interposition shim (gg_plan_hook.c) offers every
+// BuildPipelines call to this rule first, exactly as it does for the CreatePlan rules.  With it the table scans are
+// the reference's own PhysicalTableScan, parallelised and profiled by its executor, and EXPLAIN ANALYZE attributes
+// scan, sink and GPU time to separate operators.
+#include <cstdlib>
+#include <dlfcn.h>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "duckdb.hpp"
+#include "duckdb/execution/operator/scan/physical_table_scan.hpp"
+#include "duckdb/function/table/table_scan.hpp"
+#include "duckdb/catalog/catalog_entry/table_catalog_entry.hpp"
+#include "duckdb/storage/data_table.hpp"
+// Executor::BuildPipelines and the pipeline lists it fills are private; the rule below is the body of a case the
+// reference's own member function would hold.  Nothing else in this file touches non-public members.
+#define private public
+#include "duckdb/execution/executor.hpp"
+#include "duckdb/parallel/pipeline.hpp"
+#include "duckdb/execution/operator/set/physical_recursive_cte.hpp"
+#undef private
+#include "duckdb/execution/operator/helper/physical_execute.hpp"
+#include "duckdb/execution/operator/join/physical_delim_join.hpp"
+
+#include "gg_extension.hpp"
+#include "gg_operators.hpp"
+#include "gg_pipeline.hpp"
+#include "gg_plan_hook.h"
+
+namespace duckdb {
+
+//===--------------------------------------------------------------------===//
+// Lazy sinks: the device context is created when the pipeline starts, never at EXPLAIN / PREPARE
+//===--------------------------------------------------------------------===//
+PhysicalGGLazySink::PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot_p, Kind kind_p, vector<LogicalType> types,
+                                       idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), slot(move(slot_p)),
+      kind(kind_p) {
+}
+
+unique_ptr<GlobalSinkState> PhysicalGGLazySink::GetGlobalSinkState(ClientContext &context) const {
+	lock_guard<mutex> guard(slot->lock);
+	if (kind == VERTICES || kind == EDGES_DERIVE_VERTICES) {
+		slot->graph = make_shared<GGGraph>(0); // first sink of an execution: a fresh graph
+	}
+	if (!slot->graph) {
+		throw InternalException("GG_EDGE_SINK scheduled before its vertex sink");
+	}
+	if (kind == VERTICES) {
+		inner = make_unique<PhysicalGGVertexSink>(slot->graph, types, estimated_cardinality);
+	} else {
+		inner = make_unique<PhysicalGGEdgeSink>(slot->graph, types, estimated_cardinality, false,
+		                                        kind == EDGES_DERIVE_VERTICES);
+	}
+	return inner->GetGlobalSinkState(context);
+}
+
+unique_ptr<LocalSinkState> PhysicalGGLazySink::GetLocalSinkState(ExecutionContext &context) const {
+	return inner->GetLocalSinkState(context);
+}
+
+SinkResultType PhysicalGGLazySink::Sink(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate,
+                                        DataChunk &input) const {
+	return inner->Sink(context, gstate, lstate, input);
+}
+
+void PhysicalGGLazySink::Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const {
+	inner->Combine(context, gstate, lstate);
+}
+
+SinkFinalizeType PhysicalGGLazySink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+                                              GlobalSinkState &gstate) const {
+	return inner->Finalize(pipeline, event, context, gstate);
+}
+
+string PhysicalGGLazySink::GetName() const {
+	return kind == VERTICES ? "GG_VERTEX_SINK" : "GG_EDGE_SINK";
+}
+
+//===--------------------------------------------------------------------===//
+// The scan: sinks below, a GG source inside
+//===--------------------------------------------------------------------===//
+namespace {
+//! Pipeline::Ready creates every pipeline's source state when the pipelines are SCHEDULED (executor.cpp:46-191),
+//! before any of them has run — the graph does not exist yet.  The GG source inside is therefore made on first
+//! use: MaxThreads (asked when the consuming pipeline is launched, after its dependencies), or the first GetData.
+class GraphScanGlobalState : public GlobalSourceState {
+public:
+	GraphScanGlobalState(const PhysicalGGGraphScan &op, ClientContext &context) : op(op), context(context) {
+	}
+	const PhysicalGGGraphScan &op;
+	ClientContext &context;
+	mutex lock;
+	unique_ptr<PhysicalOperator> source;
+	unique_ptr<GlobalSourceState> state;
+
+	void Ensure() {
+		lock_guard<mutex> guard(lock);
+		if (state) {
+			return;
+		}
+		shared_ptr<GGGraph> graph;
+		{
+			lock_guard<mutex> slot_guard(op.slot->lock);
+			graph = op.slot->graph;
+		}
+		if (!graph || !graph->csr) {
+			throw InternalException(op.name + " scheduled before its sinks built the graph");
+		}
+		source = op.factory(graph);
+		state = source->GetGlobalSourceState(context);
+	}
+	idx_t MaxThreads() override {
+		Ensure();
+		return state->MaxThreads();
+	}
+};
+} // namespace
+
+PhysicalGGGraphScan::PhysicalGGGraphScan(vector<LogicalType> types, string name_p, string description_p,
+                                         shared_ptr<GGGraphSlot> slot_p, Factory factory_p, bool parallel_result_p,
+                                         idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), name(move(name_p)),
+      description(move(description_p)), slot(move(slot_p)), factory(move(factory_p)),
+      parallel_result(parallel_result_p) {
+}
+
+unique_ptr<GlobalSourceState> PhysicalGGGraphScan::GetGlobalSourceState(ClientContext &context) const {
+	return make_unique<GraphScanGlobalState>(*this, context);
+}
+
+unique_ptr<LocalSourceState> PhysicalGGGraphScan::GetLocalSourceState(ExecutionContext &context,
+                                                                      GlobalSourceState &gstate_p) const {
+	auto &gstate = (GraphScanGlobalState &)gstate_p;
+	gstate.Ensure();
+	return gstate.source->GetLocalSourceState(context, *gstate.state);
+}
+
+void PhysicalGGGraphScan::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
+                                  LocalSourceState &lstate) const {
+	auto &gstate = (GraphScanGlobalState &)gstate_p;
+	gstate.source->GetData(context, chunk, *gstate.state, lstate);
+}
+
+string PhysicalGGGraphScan::GetName() const {
+	return name;
+}
+
+string PhysicalGGGraphScan::ParamsToString() const {
+	return description;
+}
+
+//! PhysicalTableScan of the given columns of a base table (what plan_get.cpp:47-60 builds for a seq_scan)
+static unique_ptr<PhysicalOperator> BaseTableScan(const GGScanSource &source) {
+	auto &table = *source.table;
+	vector<LogicalType> types;  // of the scanned columns
+	vector<string> names;       // of ALL columns: PhysicalTableScan indexes them by column id (as LogicalGet::names)
+	for (auto column : source.columns) {
+		types.push_back(column == COLUMN_IDENTIFIER_ROW_ID ? LogicalType::BIGINT : table.columns[column].type);
+	}
+	for (auto &column : table.columns) {
+		names.push_back(column.name);
+	}
+	auto bind = make_unique<TableScanBindData>(&table);
+	return make_unique<PhysicalTableScan>(move(types), TableScanFunction::GetFunction(), move(bind), source.columns,
+	                                      move(names), nullptr, table.storage->GetTotalRows());
+}
+
+bool GGPipelineSinksAvailable(ClientContext &context, const GGGraphSpec &spec) {
+	// GG_NO_PIPELINE_SINKS=1: the scan-function route for every plan (the sinks are then driven from the scan's init)
+	if (std::getenv("GG_NO_PIPELINE_SINKS") || !gg_pipeline_rule_registered() || !spec.edges.table ||
+	    (!spec.vertices.Empty() && !spec.vertices.table)) {
+		return false; // views and statements are read through a side connection: the scan-function route
+	}
+	// a connection that asked for pinned graphs may not need to read the tables at all: decided at run time there
+	return !GGGetConnectionFlags(context).pinned_graphs;
+}
+
+unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<LogicalType> types, string name,
+                                             string description, bool parallel_result,
+                                             PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality) {
+	auto slot = make_shared<GGGraphSlot>();
+	auto scan = make_unique<PhysicalGGGraphScan>(move(types), move(name), move(description), slot, move(factory),
+	                                             parallel_result, estimated_cardinality);
+	const bool derive = spec.vertices.Empty();
+	if (!derive) {
+		auto rows = BaseTableScan(spec.vertices);
+		auto sink = make_unique<PhysicalGGLazySink>(slot, PhysicalGGLazySink::VERTICES, rows->types,
+		                                            rows->estimated_cardinality);
+		sink->children.push_back(move(rows));
+		scan->children.push_back(move(sink));
+	}
+	auto rows = BaseTableScan(spec.edges);
+	auto sink = make_unique<PhysicalGGLazySink>(
+	    slot, derive ? PhysicalGGLazySink::EDGES_DERIVE_VERTICES : PhysicalGGLazySink::EDGES, rows->types,
+	    rows->estimated_cardinality);
+	sink->children.push_back(move(rows));
+	scan->children.push_back(move(sink));
+	return move(scan);
+}
+
+//===--------------------------------------------------------------------===//
+// The BuildPipelines case
+//===--------------------------------------------------------------------===//
+// What the reference's own case would do for an operator that is a source over sink children — for every sink the
+// steps of its single-child-sink case (executor.cpp:411-413, 478-503), each sink's pipeline depending on the one
+// before it, the consuming pipeline on all of them.
+//
+// libduckdb's BuildPipelines calls itself directly, so only the call from Executor::Initialize passes the shim.
+// The rule therefore wraps the whole traversal: it hides the sink children of every graph scan (the reference's
+// traversal then takes each scan for the leaf source it is), runs the original, puts the children back and builds
+// the sinks' pipelines under the pipelines that ended up reading from a graph scan.
+using build_pipelines_fn = void (*)(void *, void *, void *);
+
+static void CollectGraphScans(PhysicalOperator *op, vector<PhysicalGGGraphScan *> &scans,
+                              vector<PhysicalRecursiveCTE *> &ctes) {
+	if (!op) {
+		return;
+	}
+	if (auto scan = dynamic_cast<PhysicalGGGraphScan *>(op)) {
+		scans.push_back(scan);
+		return;
+	}
+	for (auto &child : op->children) {
+		CollectGraphScans(child.get(), scans, ctes);
+	}
+	switch (op->type) { // the operators whose sub-plans are not their children (executor.cpp:487-495, 522-527)
+	case PhysicalOperatorType::EXECUTE:
+		CollectGraphScans(((PhysicalExecute &)*op).plan, scans, ctes);
+		break;
+	case PhysicalOperatorType::DELIM_JOIN:
+		CollectGraphScans(((PhysicalDelimJoin &)*op).join.get(), scans, ctes);
+		break;
+	case PhysicalOperatorType::RECURSIVE_CTE:
+		ctes.push_back((PhysicalRecursiveCTE *)op);
+		break;
+	default:
+		break;
+	}
+}
+
+static int GGBuildPipelinesRule(void *executor_p, void *op_p, void *current_p) {
+	vector<PhysicalGGGraphScan *> scans;
+	vector<PhysicalRecursiveCTE *> ctes;
+	CollectGraphScans((PhysicalOperator *)op_p, scans, ctes);
+	if (scans.empty()) {
+		return 0;
+	}
+	auto original = (void *(*)(int))dlsym(RTLD_DEFAULT, "gg_plan_hook_original");
+	auto build = original ? (build_pipelines_fn)original(GG_PLAN_HOOK_PIPELINES) : nullptr;
+	if (!build) {
+		return 0;
+	}
+	auto &executor = *(Executor *)executor_p;
+	auto current = (Pipeline *)current_p;
+	vector<vector<unique_ptr<PhysicalOperator>>> hidden(scans.size());
+	for (idx_t i = 0; i < scans.size(); i++) {
+		hidden[i] = move(scans[i]->children);
+		scans[i]->children.clear();
+	}
+	try {
+		build(executor_p, op_p, current_p);
+	} catch (...) {
+		for (idx_t i = 0; i < scans.size(); i++) {
+			scans[i]->children = move(hidden[i]);
+		}
+		throw;
+	}
+	for (idx_t i = 0; i < scans.size(); i++) {
+		scans[i]->children = move(hidden[i]);
+	}
+	// every pipeline the traversal made (a scan may feed several: union and child pipelines copy their operators)
+	vector<Pipeline *> all {current};
+	vector<vector<shared_ptr<Pipeline>> *> lists {&executor.pipelines};
+	for (auto &entry : executor.union_pipelines) {
+		lists.push_back(&entry.second);
+	}
+	for (auto &entry : executor.child_pipelines) {
+		lists.push_back(&entry.second);
+	}
+	for (auto cte : ctes) {
+		lists.push_back(&cte->pipelines);
+	}
+	for (auto list : lists) {
+		for (auto &pipeline : *list) {
+			all.push_back(pipeline.get());
+		}
+	}
+	vector<shared_ptr<Pipeline>> added;
+	for (auto scan : scans) {
+		vector<Pipeline *> readers;
+		for (auto pipeline : all) {
+			if (pipeline->source == scan) {
+				readers.push_back(pipeline);
+			}
+		}
+		if (readers.size() != 1) {
+			throw InternalException(scan->GetName() + ": expected one pipeline to read from the scan");
+		}
+		shared_ptr<Pipeline> previous;
+		for (auto &child : scan->children) {
+			auto pipeline = make_shared<Pipeline>(executor);
+			pipeline->sink = child.get();
+			child->sink_state.reset();
+			if (previous) {
+				pipeline->AddDependency(previous);
+			}
+			readers[0]->AddDependency(pipeline);
+			build(executor_p, child->children[0].get(), pipeline.get());
+			added.push_back(pipeline);
+			previous = pipeline;
+		}
+	}
+	for (auto &pipeline : added) {
+		executor.pipelines.push_back(pipeline);
+	}
+	return 1;
+}
+
+static bool g_pipeline_rule = false;
+
+void GGRegisterPipelineRule() {
+	auto reg = (int (*)(int, gg_plan_rule_fn))dlsym(RTLD_DEFAULT, "gg_plan_hook_register");
+	auto kinds = (int (*)())dlsym(RTLD_DEFAULT, "gg_plan_hook_kinds");
+	if (!reg || !kinds || kinds() <= GG_PLAN_HOOK_PIPELINES || !dlsym(RTLD_DEFAULT, "gg_plan_hook_original")) {
+		return; // no shim, or one built before it knew this hook
+	}
+	g_pipeline_rule = reg(GG_PLAN_HOOK_PIPELINES, GGBuildPipelinesRule) == 0;
+}
+
+} // namespace duckdb
+
+extern "C" int gg_pipeline_rule_registered() {
+	return duckdb::g_pipeline_rule ? 1 : 0;
+}

@@ -1,0 +1,85 @@
+// gg_pipeline.hpp — the device graph's build side as pipeline sinks of the reference's executor (gg_pipeline.cpp)
+#pragma once
+
+#include <functional>
+
+#include "gg_extension.hpp"
+#include "gg_operators.hpp"
+
+namespace duckdb {
+
+//! Where the sinks of one plan leave the graph they build and its scan picks it up; one graph per execution.
+struct GGGraphSlot {
+	mutex lock;
+	shared_ptr<GGGraph> graph;
+};
+
+//! PhysicalGGVertexSink / PhysicalGGEdgeSink created when the pipeline starts (the device context with them), so a
+//! plan that is only explained or prepared never touches the GPU.
+class PhysicalGGLazySink : public PhysicalOperator {
+public:
+	enum Kind { VERTICES, EDGES, EDGES_DERIVE_VERTICES };
+	PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot, Kind kind, vector<LogicalType> types, idx_t estimated_cardinality);
+
+	shared_ptr<GGGraphSlot> slot;
+	Kind kind;
+	mutable unique_ptr<PhysicalOperator> inner;
+
+public:
+	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
+	unique_ptr<LocalSinkState> GetLocalSinkState(ExecutionContext &context) const override;
+	SinkResultType Sink(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate,
+	                    DataChunk &input) const override;
+	void Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const override;
+	SinkFinalizeType Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+	                          GlobalSinkState &gstate) const override;
+	bool IsSink() const override {
+		return true;
+	}
+	bool ParallelSink() const override {
+		return true;
+	}
+	string GetName() const override;
+};
+
+//! A GG source over the graph its sink children build.  `factory` makes the actual source operator
+//! (PhysicalGGPathExpand, PhysicalGGWalkEndpoints, ...) once the graph exists.
+class PhysicalGGGraphScan : public PhysicalOperator {
+public:
+	using Factory = std::function<unique_ptr<PhysicalOperator>(shared_ptr<GGGraph>)>;
+	PhysicalGGGraphScan(vector<LogicalType> types, string name, string description, shared_ptr<GGGraphSlot> slot,
+	                    Factory factory, bool parallel_result, idx_t estimated_cardinality);
+
+	string name, description;
+	shared_ptr<GGGraphSlot> slot;
+	Factory factory;
+	bool parallel_result;
+
+public:
+	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	unique_ptr<LocalSourceState> GetLocalSourceState(ExecutionContext &context,
+	                                                 GlobalSourceState &gstate) const override;
+	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
+	             LocalSourceState &lstate) const override;
+	bool IsSource() const override {
+		return true;
+	}
+	bool ParallelSource() const override {
+		return parallel_result;
+	}
+	string GetName() const override;
+	string ParamsToString() const override;
+};
+
+//! true if a plan over `spec` can read its tables through pipeline sinks: the BuildPipelines rule is registered with
+//! the shim, every source is a plain table, and the connection did not ask for pinned graphs
+bool GGPipelineSinksAvailable(ClientContext &context, const GGGraphSpec &spec);
+//! GG_<name> scan with the sinks (and the reference's own table scans) of `spec` as children
+unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<LogicalType> types, string name,
+                                             string description, bool parallel_result,
+                                             PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality);
+void GGRegisterPipelineRule();
+
+} // namespace duckdb
+
+extern "C" int gg_pipeline_rule_registered();

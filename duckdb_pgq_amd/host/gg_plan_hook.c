@@ -29,13 +29,14 @@
 #define SYM_DELETE "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_13LogicalDeleteE"
 #define SYM_UPDATE "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_13LogicalUpdateE"
 #define SYM_DISTINCT "_ZN6duckdb21PhysicalPlanGenerator10CreatePlanERNS_15LogicalDistinctE"
+#define SYM_PIPELINES "_ZN6duckdb8Executor14BuildPipelinesEPNS_16PhysicalOperatorEPNS_8PipelineE"
 
 typedef void *(*create_plan_fn)(void *ret_slot, void *generator, void *logical_op);
 
 static gg_plan_rule_fn g_rule[GG_PLAN_HOOK_KINDS];
 static create_plan_fn g_orig[GG_PLAN_HOOK_KINDS];
 static const char *const g_sym[GG_PLAN_HOOK_KINDS] = {SYM_JOIN, SYM_AGGR, SYM_INSERT, SYM_DELETE, SYM_UPDATE,
-                                                          SYM_DISTINCT};
+                                                          SYM_DISTINCT, SYM_PIPELINES};
 
 void *gg_hook_create_plan_join(void *ret_slot, void *generator, void *op) __asm__(SYM_JOIN);
 void *gg_hook_create_plan_aggregate(void *ret_slot, void *generator, void *op) __asm__(SYM_AGGR);
@@ -43,6 +44,8 @@ void *gg_hook_create_plan_insert(void *ret_slot, void *generator, void *op) __as
 void *gg_hook_create_plan_delete(void *ret_slot, void *generator, void *op) __asm__(SYM_DELETE);
 void *gg_hook_create_plan_update(void *ret_slot, void *generator, void *op) __asm__(SYM_UPDATE);
 void *gg_hook_create_plan_distinct(void *ret_slot, void *generator, void *op) __asm__(SYM_DISTINCT);
+/* void Executor::BuildPipelines(PhysicalOperator *op, Pipeline *current): `this`, then the two pointers; no return slot */
+void gg_hook_build_pipelines(void *executor, void *op, void *current) __asm__(SYM_PIPELINES);
 
 struct find_ctx {
   const char *sym;
@@ -116,6 +119,28 @@ void *gg_hook_create_plan_update(void *ret_slot, void *generator, void *op) {
 
 void *gg_hook_create_plan_distinct(void *ret_slot, void *generator, void *op) {
   return dispatch(GG_PLAN_HOOK_DISTINCT, (void *)gg_hook_create_plan_distinct, ret_slot, generator, op);
+}
+
+void gg_hook_build_pipelines(void *executor, void *op, void *current) {
+  /* Only the call from Executor::Initialize arrives here: libduckdb's recursive calls of BuildPipelines are direct.
+   * The rule therefore wraps the whole traversal: it calls the original itself (gg_plan_hook_original). */
+  gg_plan_rule_fn rule = g_rule[GG_PLAN_HOOK_PIPELINES];
+  if (rule && rule(executor, op, current)) return;
+  create_plan_fn orig = original(GG_PLAN_HOOK_PIPELINES, (void *)gg_hook_build_pipelines);
+  if (orig) orig(executor, op, current); /* (same three pointer arguments; nothing is returned) */
+}
+
+void *gg_plan_hook_original(int kind) {
+  static void *const self[GG_PLAN_HOOK_KINDS] = {
+      (void *)gg_hook_create_plan_join,   (void *)gg_hook_create_plan_aggregate, (void *)gg_hook_create_plan_insert,
+      (void *)gg_hook_create_plan_delete, (void *)gg_hook_create_plan_update,    (void *)gg_hook_create_plan_distinct,
+      (void *)gg_hook_build_pipelines};
+  if (kind < 0 || kind >= GG_PLAN_HOOK_KINDS) return NULL;
+  return (void *)original(kind, self[kind]);
+}
+
+int gg_plan_hook_kinds(void) {
+  return GG_PLAN_HOOK_KINDS;
 }
 
 int gg_plan_hook_register(int kind, gg_plan_rule_fn rule) {

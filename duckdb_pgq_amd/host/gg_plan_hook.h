@@ -16,7 +16,10 @@ enum {
   GG_PLAN_HOOK_UPDATE = 4,
   /* DISTINCT (the dedupe above a UNION of walk endpoints) */
   GG_PLAN_HOOK_DISTINCT = 5,
-  GG_PLAN_HOOK_KINDS = 6
+  /* not a CreatePlan: Executor::BuildPipelines(PhysicalOperator *, Pipeline *) — the rule gets (executor, operator,
+   * current pipeline) and returns non-zero if it built the operator's pipelines itself (gg_pipeline.cpp) */
+  GG_PLAN_HOOK_PIPELINES = 6,
+  GG_PLAN_HOOK_KINDS = 7
 };
 
 /* A rule looks at the logical operator about to be planned.  To take it over it constructs a
@@ -26,6 +29,10 @@ typedef int (*gg_plan_rule_fn)(void *ret_slot, void *physical_plan_generator, vo
 
 int gg_plan_hook_register(int kind, gg_plan_rule_fn rule);
 int gg_plan_hook_registered(int kind);
+/* number of hooks this build of the shim knows (an extension newer than the shim checks before registering) */
+int gg_plan_hook_kinds(void);
+/* libduckdb's own definition of the function hook `kind` interposes (NULL if none is loaded) */
+void *gg_plan_hook_original(int kind);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@
 #include "duckdb/planner/operator/logical_delete.hpp"
 #include "duckdb/planner/operator/logical_update.hpp"
 #include "gg_extension.hpp"
+#include "gg_pipeline.hpp"
 #include "gg_plan_hook.h"
 // The rule needs the ClientContext a plan is made for (the switches are per connection), and the generator keeps
 // it private.  Included last, so that only this one class definition is read with the access specifier widened;
@@ -897,6 +898,8 @@ string QualifiedName(TableCatalogEntry &table) {
 //! tables the plan being substituted reads; registered with the generator like LogicalGet's dependency
 //! callback does (plan_get.cpp:50-52), so a prepared statement notices when one of them is dropped
 thread_local vector<CatalogEntry *> g_plan_tables;
+//! the connection whose statement is being planned (set by RuleEntry)
+thread_local ClientContext *g_plan_context = nullptr;
 
 GGScanSource TableColumns(TableCatalogEntry *table, vector<column_t> columns) {
 	g_plan_tables.push_back(table);
@@ -935,6 +938,16 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	                    (all_sources ? string() : "\nfrom " + to_string(sources[0]));
 	data->parallel_result = !count_only;
 	auto types = PhysicalGGPathExpand::OutputTypes(hops, count_only);
+	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {
+		// the tables reach the device through pipeline sinks the reference's executor schedules (gg_pipeline.cpp)
+		g_rules_fired++;
+		return GGMakeGraphScan(
+		    spec, move(types), count_only ? "GG_PATH_COUNT" : "GG_PATH_EXPAND", data->description, !count_only,
+		    [=](shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+			    return make_unique<PhysicalGGPathExpand>(move(graph), hops, hops, count_only, sources, all_sources, 0);
+		    },
+		    estimated_cardinality);
+	}
 	vector<column_t> column_ids;
 	vector<string> names;
 	for (idx_t c = 0; c < types.size(); c++) {
@@ -2030,16 +2043,25 @@ unique_ptr<PhysicalOperator> PlanDistinctUnion(LogicalDistinct &op) {
 	                    table.columns[pattern.dst_column].name + "\ndistinct endpoints of 1..2 hops\nfrom " +
 	                    to_string(sources[0]);
 	auto types = PhysicalGGWalkEndpoints::OutputTypes(2);
-	vector<column_t> column_ids;
-	vector<string> names;
-	for (idx_t c = 0; c < types.size(); c++) {
-		column_ids.push_back(c);
-		names.push_back("c" + to_string(c));
-	}
 	g_rules_fired++;
-	unique_ptr<PhysicalOperator> scan =
-	    make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_walk_endpoints"), move(data), move(column_ids),
-	                                   move(names), nullptr, op.estimated_cardinality);
+	unique_ptr<PhysicalOperator> scan;
+	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {
+		scan = GGMakeGraphScan(
+		    spec, move(types), "GG_WALK_ENDPOINTS", data->description, false,
+		    [=](shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+			    return make_unique<PhysicalGGWalkEndpoints>(move(graph), sources, 2, 0);
+		    },
+		    op.estimated_cardinality);
+	} else {
+		vector<column_t> column_ids;
+		vector<string> names;
+		for (idx_t c = 0; c < types.size(); c++) {
+			column_ids.push_back(c);
+			names.push_back("c" + to_string(c));
+		}
+		scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_walk_endpoints"), move(data),
+		                                      move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	}
 	// scan columns: (id, h1, h2).  keep: h1 = 1 OR (h2 = 1 AND the second branch's predicates on the endpoint)
 	auto flag = [](idx_t column) {
 		return make_unique<BoundComparisonExpression>(ExpressionType::COMPARE_EQUAL,
@@ -2087,6 +2109,7 @@ int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 	}
 	unique_ptr<PhysicalOperator> plan;
 	g_plan_tables.clear();
+	g_plan_context = &((PhysicalPlanGenerator *)generator)->context;
 	try {
 		plan = RULE(*(OP *)logical_operator);
 	} catch (std::exception &) {
@@ -2159,6 +2182,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 	reg(GG_PLAN_HOOK_JOIN, RuleEntry<LogicalComparisonJoin, PlanJoinChain>);
 	reg(GG_PLAN_HOOK_AGGREGATE, RuleEntry<LogicalAggregate, PlanAggregate>);
 	reg(GG_PLAN_HOOK_DISTINCT, RuleEntry<LogicalDistinct, PlanDistinctUnion>);
+	GGRegisterPipelineRule();
 	reg(GG_PLAN_HOOK_INSERT, WriteObserver<LogicalInsert>);
 	reg(GG_PLAN_HOOK_DELETE, WriteObserver<LogicalDelete>);
 	reg(GG_PLAN_HOOK_UPDATE, WriteObserver<LogicalUpdate>);

@@ -588,3 +588,34 @@ def test_statements_shaped_like_the_ldbc_friends_queries_give_the_reference_resu
     finally:
         d.execute("PRAGMA disable_gpu_graph")
         d.close()
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_sinks_run_as_pipelines_of_the_references_executor(db, monkeypatch):
+    """The tables of a substituted plan flow into the device graph through pipeline sinks that the reference's
+    executor schedules (Executor::BuildPipelines case in gg_pipeline.cpp): its profiler reports the sink and the
+    table scan below it as operators of their own, prepared statements rebuild the graph on every execution, and
+    the scan-function route (GG_NO_PIPELINE_SINKS) returns the same rows."""
+    d, vid = db
+    s = int(vid[11])
+    sql = _chain(2, "count(*)")
+    rows = _chain(2, "k2.k_person2id") + f" AND k1.k_person1id = {s}"
+    d.execute("PRAGMA disable_gpu_graph")
+    want_count, want_rows = d.execute(sql), d.execute(rows)
+    d.execute("PRAGMA enable_gpu_graph")
+    try:
+        assert "GG_EDGE_SINK" in d.explain(sql)
+        assert np.array_equal(d.execute(sql), want_count)
+        assert np.array_equal(sort_rows(d.execute(rows)), sort_rows(want_rows))
+        profile = "\n".join(" ".join(str(c) for c in r) for r in d.execute_text("EXPLAIN ANALYZE " + sql))
+        assert "GG_EDGE_SINK" in profile and "SEQ_SCAN" in profile and "GG_PATH_COUNT" in profile
+        d.execute("PREPARE two_hop AS " + sql)
+        for _ in range(3):
+            assert np.array_equal(d.execute("EXECUTE two_hop"), want_count)
+        d.execute("DEALLOCATE two_hop")
+        monkeypatch.setenv("GG_NO_PIPELINE_SINKS", "1")
+        assert "GG_EDGE_SINK" not in d.explain(sql) and "GG_PATH_COUNT" in d.explain(sql)
+        assert np.array_equal(d.execute(sql), want_count)
+        assert np.array_equal(sort_rows(d.execute(rows)), sort_rows(want_rows))
+    finally:
+        d.execute("PRAGMA disable_gpu_graph")

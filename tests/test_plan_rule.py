@@ -285,6 +285,34 @@ def test_statements_shaped_like_the_ldbc_queries_get_gpu_operators():
     d.close()
 
 
+def test_the_build_side_is_planned_as_pipeline_sinks_over_the_references_table_scans(db, monkeypatch):
+    """Join, count and distinct rules hang the tables under the GPU operator as GG_*_SINK operators over the
+    reference's own SEQ_SCANs (scheduled by its executor through the BuildPipelines case, gg_pipeline.cpp).  A
+    connection that uses pinned graphs, or GG_NO_PIPELINE_SINKS, gets the scan-function form (tables read from the
+    scan's init)."""
+    db.execute("PRAGMA enable_gpu_graph")
+    count = "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id"
+    keyed = ("SELECT p0.p_personid, p2.p_personid FROM person p0, knows k1, person p1, knows k2, person p2 "
+             "WHERE p0.p_personid = k1.k_person1id AND k1.k_person2id = p1.p_personid "
+             "AND p1.p_personid = k2.k_person1id AND k2.k_person2id = p2.p_personid")
+    try:
+        plan = db.explain(count)
+        assert "GG_PATH_COUNT" in plan and "GG_EDGE_SINK" in plan and "SEQ_SCAN" in plan and "GG_VERTEX_SINK" not in plan
+        plan = db.explain(keyed)
+        if "GG_PATH_EXPAND" in plan:  # (the keyed form needs a declared-unique key: see the fixture)
+            assert "GG_VERTEX_SINK" in plan and "GG_EDGE_SINK" in plan
+        db.execute("PRAGMA gg_use_pinned_graphs")
+        plan = db.explain(count)
+        assert "GG_PATH_COUNT" in plan and "GG_EDGE_SINK" not in plan
+        db.execute("PRAGMA gg_ignore_pinned_graphs")
+        monkeypatch.setenv("GG_NO_PIPELINE_SINKS", "1")
+        plan = db.explain(count)
+        assert "GG_PATH_COUNT" in plan and "GG_EDGE_SINK" not in plan
+    finally:
+        db.execute("PRAGMA gg_ignore_pinned_graphs")
+        db.execute("PRAGMA disable_gpu_graph")
+
+
 def test_unions_that_are_not_friends_and_friends_of_friends_keep_their_dedupe():
     """The distinct rule takes a UNION only if it is exactly {1-hop endpoints of C} UNION {2-hop endpoints of C
     [with predicates on the endpoint]} over one edge table.  Anything else keeps the reference's UNION + hash
