@@ -47,6 +47,12 @@ constexpr int FB_MAX_HB = 10;                    // bucket bits
 #ifndef GG_FB_NT
 #define GG_FB_NT 1                               // streamed columns bypass the caches' retention (nt loads/stores)
 #endif
+#ifndef GG_FB_SUBNT
+#define GG_FB_SUBNT 0
+#endif
+#ifndef GG_FB_SUBPIPE
+#define GG_FB_SUBPIPE 2  // workgroups per CU of the pipelined k_sub_sort_pipe: its resident set (0: k_sub_sort, one chunk per workgroup)
+#endif
 #ifndef GG_FB_XCD
 #define GG_FB_XCD 1                              // A: consecutive tiles on one XCD (short runs merge in its L2)
 #endif
@@ -503,7 +509,7 @@ constexpr int LEAF_MAXS = GG_FB_LEAF_MAXS;  // 64-entry steps a wave of k_leaf_r
 // and A read 1024 separate lines per tile, as many bytes again as A's payload.)
 //   bstart[dir * (nb + 1) + j]   first position of bucket j in that direction's partitioned array
 //   cstart[i], i = dir * nb + j  first chunk of bucket i (cstart[2 nb] = number of chunks)
-//   part_of[p]                   bucket i of chunk p
+//   part_of[p]                   chunk p: {first entry, end, bucket i} (one load in k_sub_sort instead of a chain)
 __global__ __launch_bounds__(1024) void k_col_partial(const uint32_t *__restrict__ counts, uint64_t nblocks,
                                                      uint32_t ncol, uint32_t gsz, uint32_t *__restrict__ partial,
                                                      uint32_t *__restrict__ coltot /* [ncol], zeroed */) {
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_col_partial(const uint32_t *__restrict
 // one workgroup: bucket starts of both directions (scan of the column totals), chunk table, kept-edge count
 __global__ __launch_bounds__(1024) void k_col_scan(uint32_t *__restrict__ coltot /* in: totals, out: starts */,
                                                    uint32_t nb, uint32_t *__restrict__ bstart,
-                                                   uint32_t *__restrict__ cstart, uint32_t *__restrict__ part_of,
+                                                   uint32_t *__restrict__ cstart, uint4 *__restrict__ part_of,
                                                    BuildStatus *__restrict__ st) {
   __shared__ uint32_t s_b[2 * ((1 << FB_MAX_HB) + 1)];  // bucket starts, both directions
   __shared__ uint32_t s_w[2][16];
@@ -604,7 +610,11 @@ __global__ __launch_bounds__(1024) void k_col_scan(uint32_t *__restrict__ coltot
       const uint32_t len = s_b[dir * (nb + 1) + j + 1] - s_b[dir * (nb + 1) + j];
       const uint32_t n = (len + FB_TILE - 1) / FB_TILE;
       cstart[i] = cex;
-      for (uint32_t c = 0; c < n; c++) part_of[cex + c] = i;  // stores are not waited for: cheap even for one huge bucket
+      const uint32_t b0 = s_b[dir * (nb + 1) + j], b1 = b0 + len;
+      for (uint32_t c = 0; c < n; c++) {  // stores are not waited for: cheap even for one huge bucket
+        const uint32_t c0 = b0 + c * FB_TILE;
+        part_of[cex + c] = make_uint4(c0, c0 + FB_TILE < b1 ? c0 + FB_TILE : b1, i, 0u);
+      }
       cex += n;
     }
   }
@@ -643,22 +653,20 @@ __global__ __launch_bounds__(1024) void k_col_apply(uint32_t *__restrict__ count
 
 // Chunk-local stable sort by sub-bucket, in place.  Element order in a chunk: wave w owns entries
 // [w * FB_WTILE, (w + 1) * FB_WTILE), 64 consecutive entries per step.
-template <bool PACK, bool ROWID>
+template <bool PACK, bool ROWID, int STOP = 0>  // STOP: timing probes (GG_FB_PROBES)
 __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
                                                          uint32_t *__restrict__ epos_f,
                                                          const uint32_t *__restrict__ bstart,
                                                          const uint32_t *__restrict__ cstart,
-                                                         const uint32_t *__restrict__ part_of, FastGeom g,
+                                                         const uint4 *__restrict__ part_of, FastGeom g,
                                                          uint32_t *__restrict__ offs /* [chunk][65] */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_n;
   const uint32_t nb = 1u << g.hb;
   const uint32_t p = blockIdx.x;
+  const uint4 chunk = part_of[p];  // (both loads in flight: entries past the last chunk are allocated, not meaningful)
   if (p >= cstart[2 * nb]) return;
-  const uint32_t i = part_of[p], dir = i / nb, j = i % nb;
-  const uint32_t b0 = bstart[dir * (nb + 1) + j], b1 = bstart[dir * (nb + 1) + j + 1];
-  const uint32_t c0 = b0 + (p - cstart[i]) * FB_TILE;
-  const uint32_t c1 = c0 + FB_TILE < b1 ? c0 + FB_TILE : b1;
+  const uint32_t c0 = chunk.x, c1 = chunk.y, dir = chunk.z / nb;
   uint32_t *__restrict__ buf = dir ? buf_r : buf_f;
   const bool with_pos = ROWID && dir == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -681,7 +689,11 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     ep[it] = 0;
     if (e < c1) {
       if (PACK) {
+#if GG_FB_SUBNT
+        w[it] = ld_stream(buf + e);
+#else
         w[it] = buf[e];
+#endif
         k[it] = w[it] >> g.key_bits;
       } else {
         const uint2 x = reinterpret_cast<const uint2 *>(buf)[e];
@@ -692,6 +704,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     }
   }
   __builtin_amdgcn_wave_barrier();
+  if (STOP == 1) {  // loads only
+    uint32_t acc = 0;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) acc += k[it] ^ w[it];
+    if (acc == 0x12345678u && c1 == 1) offs[0] = acc;
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < FB_ITEMS; it++)
     if (k[it] != INVALID_U32) atomicAdd(&myh[k[it] >> g.leaf], 1u);
@@ -724,6 +743,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     }
   }
   __syncthreads();
+  if (STOP == 2) return;  // + counts and the scan
   volatile uint32_t *cur = myh;
 #pragma unroll
   for (int it = 0; it < FB_ITEMS; it++) {
@@ -761,6 +781,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     }
   }
   __syncthreads();
+  if (STOP == 3) {  // + ranks and staging, no write-out
+    if (xw[threadIdx.x] == 0x12345678u && c1 == 1) offs[0] = 1;
+    return;
+  }
   const uint32_t n = s_n;
 #pragma unroll
   for (int it = 0; it < FB_ITEMS; it++) {
@@ -773,6 +797,106 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
       }
       if (with_pos) epos_f[c0 + s] = xe[s];
     }
+  }
+}
+
+// The same sort for packed words without edge positions (the common case), software-pipelined: a workgroup walks
+// chunks p, p + G, p + 2G, ... and has the NEXT chunk's entries in flight while it counts, ranks and writes the
+// current one.  One chunk per workgroup spends its life in latencies (probe: the loads alone take 105 of the
+// kernel's 195 us at SF100, a third of the HBM rate): header -> entries -> four barrier-separated phases, and 32
+// resident waves per CU do not cover that.
+__global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
+                                                              const uint32_t *__restrict__ cstart,
+                                                              const uint4 *__restrict__ part_of, FastGeom g,
+                                                              uint32_t *__restrict__ offs /* [chunk][65] */) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_n;
+  const uint32_t nb = 1u << g.hb, G = gridDim.x;
+  uint32_t p = blockIdx.x;
+  uint4 chunk = part_of[p];  // (entries past the last chunk are allocated, not meaningful)
+  const uint32_t nchunks = cstart[2 * nb];
+  if (p >= nchunks) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *hw = lds;                    // [FB_WAVES][64] per-wave counts -> cursors (staged slot)
+  uint32_t *dbase = hw + FB_WAVES * 64;  // [65] first staged slot of each sub-bucket
+  uint32_t *xw = dbase + 65;             // staged words
+  uint32_t *myh = hw + wave * 64;
+  const uint32_t mine = (uint32_t)wave * FB_WTILE + lane;  // this lane's first entry inside a chunk
+  uint32_t w[FB_ITEMS], wn[FB_ITEMS];
+  {
+    const uint32_t *__restrict__ src = (chunk.z / nb ? buf_r : buf_f) + chunk.x;
+    const uint32_t len = chunk.y - chunk.x;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) w[it] = mine + it * 64 < len ? ld_stream(src + mine + it * 64) : 0u;
+  }
+  uint4 chunk_n = p + G < nchunks ? part_of[p + G] : make_uint4(0, 0, 0, 0);
+  for (;;) {
+    const bool has_next = p + G < nchunks;  // uniform
+    uint4 chunk_nn = make_uint4(0, 0, 0, 0);
+    if (has_next) {
+      const uint32_t *__restrict__ src = (chunk_n.z / nb ? buf_r : buf_f) + chunk_n.x;
+      const uint32_t len = chunk_n.y - chunk_n.x;
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) wn[it] = mine + it * 64 < len ? ld_stream(src + mine + it * 64) : 0u;
+      if (p + 2 * G < nchunks) chunk_nn = part_of[p + 2 * G];
+    }
+    uint32_t *__restrict__ buf = (chunk.z / nb ? buf_r : buf_f) + chunk.x;
+    const uint32_t len = chunk.y - chunk.x;
+    myh[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++)
+      if (mine + it * 64 < len) atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // <= 64 sub-buckets: wave 0 turns the counts into staged-slot cursors
+      uint32_t tot = 0, cw[FB_WAVES];
+#pragma unroll
+      for (int q = 0; q < FB_WAVES; q++) {
+        cw[q] = hw[q * 64 + lane];
+        tot += cw[q];
+      }
+      uint32_t incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      uint32_t run = incl - tot;
+      dbase[lane] = run;
+      offs[(uint64_t)p * 65 + lane] = run;
+#pragma unroll
+      for (int q = 0; q < FB_WAVES; q++) {
+        hw[q * 64 + lane] = run;
+        run += cw[q];
+      }
+      if (lane == 63) {
+        dbase[64] = incl;
+        offs[(uint64_t)p * 65 + 64] = incl;
+        s_n = incl;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) {  // ranks straight from the wave's cursors (lane-ordered ds_add_rtn)
+      if (mine + it * 64 < len) {
+        const uint32_t pos = atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
+        xw[pos] = w[it];
+      }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) {
+      const uint32_t s = (uint32_t)it * FB_THREADS + threadIdx.x;
+      if (s < n) buf[s] = xw[s];
+    }
+    if (!has_next) break;
+    __syncthreads();  // the stage and the cursors are reused
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) w[it] = wn[it];
+    chunk = chunk_n;
+    chunk_n = chunk_nn;
+    p += G;
   }
 }
 
@@ -1064,13 +1188,14 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
             csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab, (const DirectMap *)dm,
             pairs, g, nblocks64, counts);
   const uint64_t pmax = 2 * (nblocks64 + nb);  // chunks: every bucket may end in a partial one
-  uint32_t *cstart = nullptr, *part_of = nullptr, *offs = nullptr, *substart = nullptr, *partial = nullptr;
+  uint4 *part_of = nullptr;
+  uint32_t *cstart = nullptr, *offs = nullptr, *substart = nullptr, *partial = nullptr;
   const uint32_t ncol = 2 * nb;
   uint32_t gsz = 16;  // tiles per group of the column kernels; at most 512 groups for the single-workgroup step
   while ((nblocks64 + gsz - 1) / gsz > 512) gsz *= 2;
   const uint32_t ngroups = (uint32_t)((nblocks64 + gsz - 1) / gsz);
   GG_TRY(ctx->dev_alloc((void **)&cstart, (2 * nb + 1) * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint4)));
   GG_TRY(ctx->dev_alloc((void **)&offs, pmax * 65 * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * 65 * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&partial, ((uint64_t)ngroups + 1) * ncol * sizeof(uint32_t)));
@@ -1143,15 +1268,41 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<P, R>),                                         \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
   GG_LAUNCH(ctx, "sub_sort", (k_sub_sort<P, R>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, epos_f, \
-            (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint32_t *)part_of, g, offs);                    \
+            (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);                    \
   GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,                         \
             (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);                   \
   GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<P, R>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,                          \
             (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,     \
             (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,     \
             csr->epos, csr->roff, csr->rnbr, csr->rrow)
+#ifdef GG_FB_PROBES
+  if (g.pack && !rowid) {
+#define GG_FB_PROBE_S(N, NAME)                                                                                         \
+  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<true, false, N>),                             \
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                 \
+  GG_LAUNCH(ctx, NAME, (k_sub_sort<true, false, N>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r,    \
+            epos_f, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint4 *)part_of, g, offs)
+    GG_FB_PROBE_S(1, "probe_S_loads");
+    GG_FB_PROBE_S(2, "probe_S_counts");
+    GG_FB_PROBE_S(3, "probe_S_rank");
+#undef GG_FB_PROBE_S
+  }
+#endif
   if (g.pack && rowid) {
     GG_FB_LAUNCH_B(true, true);
+  } else if (g.pack && g.rank_atomic && GG_FB_SUBPIPE) {
+    const uint64_t resident = (uint64_t)ctx->num_cus * GG_FB_SUBPIPE;
+    const unsigned grid_p = (unsigned)(pmax < resident ? pmax : resident);
+    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort_pipe),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    GG_LAUNCH(ctx, "sub_sort", k_sub_sort_pipe, dim3(grid_p), dim3(FB_THREADS), lds_s, part_f, part_r,
+              (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);
+    GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,
+              (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);
+    GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<true, false>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,
+              (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,
+              (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,
+              csr->epos, csr->roff, csr->rnbr, csr->rrow);
   } else if (g.pack) {
     GG_FB_LAUNCH_B(true, false);
   } else if (rowid) {
