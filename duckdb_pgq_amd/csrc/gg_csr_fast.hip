@@ -173,9 +173,10 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
                                              uint32_t low, uint32_t part, uint32_t n_parts, uint32_t *hist_f,
                                              uint32_t *hist_r) {
 #ifndef GG_FB_DB
-#define GG_FB_DB 4
+#define GG_FB_DB 2  // (4 rows per batch need 102 VGPRs = 16 waves per CU: 731 us at SF100 against 695 with 2 and 32 waves)
 #endif
   constexpr int B = GG_FB_DB;  // edge rows per batch: 2*B independent first probes in flight per lane
+  static_assert(FB_ITEMS % B == 0, "a tile is a whole number of batches");
   const int64_t min_id = dm->min_id, max_id = dm->max_id;
   PkGeom pk;
   pk.load(dm);
@@ -260,8 +261,16 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
   }
 }
 
+#ifndef GG_FB_DWAVES
+#define GG_FB_DWAVES 0
+#endif
+#if GG_FB_DWAVES
+#define GG_FB_DATTR __attribute__((amdgpu_waves_per_eu(GG_FB_DWAVES, GG_FB_DWAVES)))
+#else
+#define GG_FB_DATTR
+#endif
 template <bool PROBE = false>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
-__global__ __launch_bounds__(FB_THREADS) void k_densify_pairs(
+__global__ __launch_bounds__(FB_THREADS) GG_FB_DATTR void k_densify_pairs(
     const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
     uint64_t cap, const BuildStatus *__restrict__ st, const uint32_t *__restrict__ dir,
     const unsigned long long *__restrict__ tab, const DirectMap *__restrict__ dm, u32x2 *__restrict__ pairs,
