@@ -35,7 +35,7 @@ traffic = {"_source": f"profiles/{rnd}_{tag}_sf100_pmc_summary.txt", "_note": "H
            f"profiles/{rnd}_{tag}_sf100_pmc_summary.txt): (2*FETCH_SIZE + WRITE_SIZE) * 1024; the factor 2 on FETCH_SIZE is the "
            "gfx950 correction of MI355X_MICROARCH.md (upper bound for our 4-byte-per-lane coalesced loads)"}
 short = {"k_expand_mid2": "expand_mid2", "k_densify_hist": "densify_hist", "k_radix_scatter": "radix_scatter",
-         "k_densify_pairs": "densify_pairs", "k_partition_dual": "partition_dual", "k_sub_sort": "sub_sort", "k_leaf_rows": "leaf_rows"}
+         "k_densify_pairs": "densify_pairs", "k_partition_dual": "partition_dual", "k_sub_sort": "sub_sort", "k_sub_sort_pipe": "sub_sort", "k_leaf_rows": "leaf_rows"}
 acc = collections.defaultdict(list)
 for k, v in res.items():
     n = k.split("::")[-1].split("<")[0]
