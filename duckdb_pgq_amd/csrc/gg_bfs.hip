@@ -9,10 +9,10 @@
 //   PhysicalHashAggregate (min)                     src/execution/operator/aggregate/physical_hash_aggregate.cpp:152-266
 // Here each of up to 64 sources owns one bit lane of a uint64 per vertex.  A level runs in one of two
 // directions, chosen from the frontier's edge count (both give identical bits):
-//   push (light frontier)  k_bfs_compact: frontier words -> active-vertex list (__ballot + popcount)
-//                          k_bfs_push:    wavefront per active vertex, coalesced CSR row read, 8-byte OR
-//                                         into next[w] only for lanes w has not seen
-//                          k_bfs_update:  new = next & ~seen; seen |= new; distances; next frontier + stats
+//   push (light frontier)  k_bfs_push:    a wavefront takes 64 frontier words, ballots the non-empty ones and walks
+//                                         their rows (coalesced CSR row read), 8-byte OR into next[w] only for
+//                                         lanes w has not seen; `next` is a third word buffer, all-zero between levels
+//                          k_bfs_update:  new = next & ~seen; seen |= new; distances; next frontier + stats; next = 0
 //   pull (heavy frontier)  k_bfs_pull:    16 lanes (lists of >= 128: the whole wavefront) per vertex w that
 //                                         still misses lanes: OR of frontier[v] over the in-neighbours
 //                                         (reverse CSR row read + 8-byte gathers from the V-sized, L2-resident frontier),
@@ -59,12 +59,13 @@ __device__ __forceinline__ void write_dist(uint64_t *__restrict__ dist /* [V][64
 }
 
 // block-aggregate (n_active, te, reached) and add to the level counters with three atomics per block
-__device__ __forceinline__ void add_level_stats(uint64_t act, uint64_t te, uint64_t reached, uint64_t *s_red /*12*/,
+__device__ __forceinline__ void add_level_stats(uint64_t act, uint64_t te, uint64_t reached,
+                                                uint64_t *s_red /* 3 per wave of the block */,
                                                 BfsLevel *__restrict__ lv) {
   act = wave_reduce_add_u64(act);
   te = wave_reduce_add_u64(te);
   reached = wave_reduce_add_u64(reached);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
   if (lane == 0) {
     s_red[wave * 3] = act;
     s_red[wave * 3 + 1] = te;
@@ -72,7 +73,8 @@ __device__ __forceinline__ void add_level_stats(uint64_t act, uint64_t te, uint6
   }
   __syncthreads();
   if (threadIdx.x < 3) {
-    const uint64_t s = s_red[threadIdx.x] + s_red[3 + threadIdx.x] + s_red[6 + threadIdx.x] + s_red[9 + threadIdx.x];
+    uint64_t s = 0;
+    for (int w = 0; w < waves; w++) s += s_red[w * 3 + threadIdx.x];
     if (s) atomicAdd(threadIdx.x == 0 ? &lv->n_active : (threadIdx.x == 1 ? &lv->te : &lv->reached),
                      (unsigned long long)s);
   }
@@ -116,11 +118,11 @@ __global__ __launch_bounds__(64) void k_bfs_seed(const uint32_t *__restrict__ sr
 // decides from the statistics of the frontier it starts from (steps[level - 1], written by the level before)
 // whether there is anything to do and in which direction: done (empty frontier), pull (heavy) or push (light).
 // Kernels of the direction not taken return at once.  steps[] also records which of the two word buffers holds the
-// frontier a level produced and whether the other one still has stale bits (after a pull level).
+// frontier a level produced (pull levels ping-pong between them; push levels go through a third, always-clean one).
 struct BfsStep {
   unsigned long long n_active, te, reached;  // BfsLevel of the frontier this level produced
   unsigned long long cur;                    // buffer (0/1) that holds it
-  unsigned long long dirty;                  // the other buffer is not all-zero
+  unsigned long long reserved;
 };
 enum BfsMode : int { BFS_DONE = 0, BFS_PUSH = 1, BFS_PULL = 2 };
 __device__ __forceinline__ int bfs_mode(const BfsStep &prev, uint64_t E) {
@@ -128,93 +130,35 @@ __device__ __forceinline__ int bfs_mode(const BfsStep &prev, uint64_t E) {
   return prev.te * 16 > E ? BFS_PULL : BFS_PUSH;  // heavy frontier: gather instead of scatter
 }
 
-__device__ __forceinline__ void compact_body(const uint64_t *__restrict__ frontier, uint64_t V,
-                                             uint32_t *__restrict__ active, unsigned long long *__restrict__ cursor,
-                                             uint32_t *s_cnt, uint32_t *s_base);
-
-__global__ __launch_bounds__(256) void k_bfs_compact(const uint64_t *__restrict__ frontier, uint64_t V,
-                                                     uint32_t *__restrict__ active,
-                                                     unsigned long long *__restrict__ cursor) {
-  __shared__ uint32_t s_cnt[4];
-  __shared__ uint32_t s_base;
-  compact_body(frontier, V, active, cursor, s_cnt, &s_base);
-}
-
-// push level, first kernel: clear what a pull level left in the spare buffer, then list the active vertices
-__global__ __launch_bounds__(256) void k_bfs_compact_dev(const BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
-                                                         uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
-                                                         uint64_t V, uint32_t *__restrict__ active,
-                                                         unsigned long long *__restrict__ cursors) {
-  __shared__ uint32_t s_cnt[4];
-  __shared__ uint32_t s_base;
-  const BfsStep prev = steps[level - 1];
-  if (bfs_mode(prev, E) != BFS_PUSH) return;
-  uint64_t *front = prev.cur ? f1 : f0, *other = prev.cur ? f0 : f1;
-  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (prev.dirty && v < V) other[v] = 0;
-  compact_body(front, V, active, cursors + level, s_cnt, &s_base);
-}
-
-__device__ __forceinline__ void compact_body(const uint64_t *__restrict__ frontier, uint64_t V,
-                                             uint32_t *__restrict__ active, unsigned long long *__restrict__ cursor,
-                                             uint32_t *s_cnt, uint32_t *s_base_p) {
-#define s_base (*s_base_p)
-  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool on = v < V && frontier[v] != 0;
-  const uint64_t m = __ballot(on);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    s_base = tot ? (uint32_t)atomicAdd(cursor, (unsigned long long)tot) : 0;  // one atomic per block
-  }
-  __syncthreads();
-  uint32_t wbase = s_base;
-  for (int w = 0; w < wave; w++) wbase += s_cnt[w];
-  if (on) active[wbase + __popcll(m & ((1ULL << lane) - 1ULL))] = (uint32_t)v;
-#undef s_base
-}
-
-// push: a wavefront per active vertex (grid-strided)
-__device__ __forceinline__ void push_body(const uint32_t *__restrict__ active, uint64_t n_active,
-                                          const uint64_t *__restrict__ frontier, const uint64_t *__restrict__ seen,
-                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
-                                          uint64_t *__restrict__ next);
-
-__global__ __launch_bounds__(256) void k_bfs_push(const uint32_t *__restrict__ active, uint64_t n_active,
-                                                  const uint64_t *__restrict__ frontier,
-                                                  const uint64_t *__restrict__ seen, const uint32_t *__restrict__ off,
-                                                  const uint32_t *__restrict__ nbr, uint64_t *__restrict__ next) {
-  push_body(active, n_active, frontier, seen, off, nbr, next);
-}
-
+// push level, device-driven: no active-vertex list.  A wave reads 64 consecutive frontier words (one coalesced
+// 512-byte load), ballots the non-empty ones and walks their rows one after the other; light frontiers put about one
+// active vertex in a wave's 64, so the parallelism is the list's without the compaction launch before it.  Pushes
+// go into `fnext`, a buffer of its own that is all-zero between levels (k_bfs_update_dev re-zeroes what it folds),
+// so nothing has to be cleaned after a pull level either.
 __global__ __launch_bounds__(256) void k_bfs_push_dev(const BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
-                                                      uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
-                                                      const uint32_t *__restrict__ active,
-                                                      const uint64_t *__restrict__ seen,
+                                                      const uint64_t *__restrict__ f0, const uint64_t *__restrict__ f1,
+                                                      uint64_t *__restrict__ fnext, const uint64_t *__restrict__ seen,
                                                       const uint32_t *__restrict__ off,
-                                                      const uint32_t *__restrict__ nbr) {
+                                                      const uint32_t *__restrict__ nbr, uint64_t V) {
   const BfsStep prev = steps[level - 1];
   if (bfs_mode(prev, E) != BFS_PUSH) return;
-  push_body(active, prev.n_active, prev.cur ? f1 : f0, seen, off, nbr, prev.cur ? f0 : f1);
-}
-
-__device__ __forceinline__ void push_body(const uint32_t *__restrict__ active, uint64_t n_active,
-                                          const uint64_t *__restrict__ frontier, const uint64_t *__restrict__ seen,
-                                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
-                                          uint64_t *__restrict__ next) {
+  const uint64_t *__restrict__ frontier = prev.cur ? f1 : f0;
   const int lane = threadIdx.x & 63;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  for (uint64_t a = wave0; a < n_active; a += nwaves) {
-    const uint32_t v = active[a];
-    const uint64_t f = frontier[v];
-    const uint32_t b = off[v], e = off[v + 1];
-    for (uint32_t i = b + lane; i < e; i += 64) {
-      const uint32_t w = nbr[i];
-      const uint64_t nf = f & ~seen[w];
-      if (nf) atomicOr((unsigned long long *)&next[w], (unsigned long long)nf);
+  for (uint64_t base = wave0 * 64; base < V; base += nwaves * 64) {
+    const uint64_t mine = base + lane < V ? frontier[base + lane] : 0ULL;
+    uint64_t m = __ballot(mine != 0);
+    while (m) {  // uniform
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const uint64_t f = __shfl(mine, l, 64);
+      const uint32_t b = off[base + l], e = off[base + l + 1];
+      for (uint32_t i = b + lane; i < e; i += 64) {
+        const uint32_t w = nbr[i];
+        const uint64_t nf = f & ~seen[w];
+        if (nf) atomicOr((unsigned long long *)&fnext[w], (unsigned long long)nf);
+      }
     }
   }
 }
@@ -238,17 +182,14 @@ __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ front
 template <typename DistT>
 __global__ __launch_bounds__(256) void k_bfs_update_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
                                                         uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
-                                                        uint64_t *__restrict__ seen, uint64_t V,
-                                                        const uint32_t *__restrict__ off,
+                                                        uint64_t *__restrict__ fnext, uint64_t *__restrict__ seen,
+                                                        uint64_t V, const uint32_t *__restrict__ off,
                                                         uint64_t *__restrict__ dist8) {
   __shared__ uint64_t s_red[12];
   const BfsStep prev = steps[level - 1];
   if (bfs_mode(prev, E) != BFS_PUSH) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the new frontier stays in the same buffer, the spare one is zero again
-    steps[level].cur = prev.cur;
-    steps[level].dirty = 0;
-  }
-  update_body<DistT>(prev.cur ? f1 : f0, seen, prev.cur ? f0 : f1, V, level, off, dist8,
+  if (blockIdx.x == 0 && threadIdx.x == 0) steps[level].cur = prev.cur;  // the new frontier stays in the same buffer
+  update_body<DistT>(prev.cur ? f1 : f0, seen, fnext, V, level, off, dist8,
                      reinterpret_cast<BfsLevel *>(&steps[level]), s_red);
 }
 
@@ -257,20 +198,22 @@ __device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uin
                                             uint64_t *__restrict__ next, uint64_t V, uint32_t level,
                                             const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
                                             BfsLevel *__restrict__ lv, uint64_t *s_red) {
-  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t nw = 0, te = 0;
-  if (v < V) {
+  // grid-strided: the level counters take three same-address atomics per BLOCK, so few blocks
+  uint64_t act = 0, te = 0, reached = 0;
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t s = seen[v];
-    nw = next[v] & ~s;
+    const uint64_t nw = next[v] & ~s;
     next[v] = 0;
     frontier[v] = nw;
     if (nw) {
       seen[v] = s | nw;
       write_dist<DistT>(dist8, v, nw, level);
-      te = off[v + 1] - off[v];
+      te += off[v + 1] - off[v];
+      act += 1;
+      reached += (uint64_t)__popcll(nw);
     }
   }
-  add_level_stats(nw ? 1 : 0, te, (uint64_t)__popcll(nw), s_red, lv);
+  add_level_stats(act, te, reached, s_red, lv);
 }
 
 // pull: four vertices per wavefront, sixteen lanes each (grid-strided); reads fin, writes fout (ping-pong
@@ -300,21 +243,21 @@ __global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ f
   pull_body<DistT>(fin, fout, seen, V, level, off, roff, rnbr, dist8, lv, s_red);
 }
 
+#ifndef GG_BFS_PULL_THREADS
+#define GG_BFS_PULL_THREADS 256  // (1024-thread blocks, a quarter of the level-counter atomics: 395 instead of 401 us per batch, not worth it)
+#endif
 template <typename DistT>
-__global__ __launch_bounds__(256) void k_bfs_pull_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
+__global__ __launch_bounds__(GG_BFS_PULL_THREADS) void k_bfs_pull_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
                                                       uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
                                                       uint64_t *__restrict__ seen, uint64_t V,
                                                       const uint32_t *__restrict__ off,
                                                       const uint32_t *__restrict__ roff,
                                                       const uint32_t *__restrict__ rnbr,
                                                       uint64_t *__restrict__ dist8) {
-  __shared__ uint64_t s_red[12];
+  __shared__ uint64_t s_red[3 * GG_BFS_PULL_THREADS / 64];
   const BfsStep prev = steps[level - 1];
   if (bfs_mode(prev, E) != BFS_PULL) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // every word of the other buffer is written: it is the frontier now
-    steps[level].cur = prev.cur ^ 1ULL;
-    steps[level].dirty = 1;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) steps[level].cur = prev.cur ^ 1ULL;  // every word of the other buffer is written
   pull_body<DistT>(prev.cur ? f1 : f0, prev.cur ? f0 : f1, seen, V, level, off, roff, rnbr, dist8,
                    reinterpret_cast<BfsLevel *>(&steps[level]), s_red);
 }
@@ -533,32 +476,30 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   }
 
   int64_t *ids_dev = nullptr;
-  uint32_t *src_dense = nullptr, *active = nullptr;
-  uint64_t *fa = nullptr, *fb = nullptr, *seen = nullptr, *dist8 = nullptr;
+  uint32_t *src_dense = nullptr;
+  uint64_t *fa = nullptr, *fb = nullptr, *fnext = nullptr, *seen = nullptr, *dist8 = nullptr;
   BfsStep *steps = nullptr;            // steps[L]: the frontier level L produced (L = 0: the seed)
-  unsigned long long *cursors = nullptr;  // one compaction cursor per level
   constexpr size_t STEP_SLOTS = (size_t)MAX_LEVEL + 2;
   GG_TRY(ctx->dev_alloc((void **)&ids_dev, GG_BFS_LANES * sizeof(int64_t)));
   GG_TRY(ctx->dev_alloc((void **)&src_dense, GG_BFS_LANES * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&active, V * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&fa, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&fb, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&fnext, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&seen, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&dist8, V * 64 * sizeof(DistT)));
   GG_TRY(ctx->dev_alloc((void **)&steps, STEP_SLOTS * sizeof(BfsStep)));
-  GG_TRY(ctx->dev_alloc((void **)&cursors, STEP_SLOTS * sizeof(unsigned long long)));
 
   // (pageable source: the runtime stages it before the call returns; no synchronisation needed here)
   GG_HIP(hipMemcpyAsync(ids_dev, src_ids, (size_t)n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
   GG_TRY(lookup_ids(ctx, csr, ids_dev, (uint64_t)n_src, src_dense));
   GG_HIP(hipMemsetAsync(steps, 0, STEP_SLOTS * sizeof(BfsStep), s));
-  GG_HIP(hipMemsetAsync(cursors, 0, STEP_SLOTS * sizeof(unsigned long long), s));
   GG_HIP(hipMemsetAsync(fa, 0, V * sizeof(uint64_t), s));
-  GG_HIP(hipMemsetAsync(fb, 0, V * sizeof(uint64_t), s));  // doubles as the push direction's `next`
+  GG_HIP(hipMemsetAsync(fb, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(fnext, 0, V * sizeof(uint64_t), s));  // the push direction's `next`: all-zero between levels
   GG_HIP(hipMemsetAsync(seen, 0, V * sizeof(uint64_t), s));
   GG_HIP(hipMemsetAsync(dist8, 0xFF, V * 64 * sizeof(DistT), s));
   GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<DistT>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, fa, seen, dist8,
-            reinterpret_cast<BfsLevel *>(steps));  // steps[0]: cur = 0 (fa), dirty = 0 from the memset
+            reinterpret_cast<BfsLevel *>(steps));  // steps[0]: cur = 0 (fa) from the memset
 
   const unsigned vgrid = (unsigned)((V + 255) / 256);
   const uint64_t max_waves = (uint64_t)ctx->num_cus * 32;  // one resident set; grid-stride the rest
@@ -568,11 +509,17 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
 #ifndef GG_BFS_CHUNK
 #define GG_BFS_CHUNK 6
 #endif
+#ifndef GG_BFS_UGRID
+#define GG_BFS_UGRID 2  // blocks per CU of the update kernel
+#endif
   constexpr int BFS_CHUNK = GG_BFS_CHUNK;
   const int level_cap = max_hops >= 0 && max_hops < MAX_LEVEL ? max_hops : MAX_LEVEL;
-  const unsigned push_grid = (unsigned)(((V < max_waves ? V : max_waves) * 64 + 255) / 256);
+  const unsigned ugrid = vgrid < (unsigned)ctx->num_cus * GG_BFS_UGRID ? vgrid : (unsigned)ctx->num_cus * GG_BFS_UGRID;
+  const uint64_t chunks = (V + 63) / 64;  // push: 64 frontier words per wavefront
+  const unsigned push_grid = (unsigned)(((chunks < max_waves ? chunks : max_waves) * 64 + 255) / 256);
   const uint64_t quads = (V + 3) / 4;  // pull: four vertices per wavefront
-  const unsigned pull_grid = (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + 255) / 256);
+  const unsigned pull_grid =
+      (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + GG_BFS_PULL_THREADS - 1) / GG_BFS_PULL_THREADS);
   std::vector<BfsStep> host_steps((size_t)level_cap + 2);
   int launched = 0;  // levels 1..launched are enqueued
   uint64_t reached = 0;
@@ -584,13 +531,11 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
         GG_TRY(ensure_reverse(ctx, csr));
         pull_ready = true;
       }
-      GG_LAUNCH(ctx, "bfs_compact", k_bfs_compact_dev, dim3(vgrid), dim3(256), 0, (const BfsStep *)steps, (uint32_t)level,
-                csr->E, fa, fb, V, active, cursors);
       GG_LAUNCH(ctx, "bfs_push", k_bfs_push_dev, dim3(push_grid), dim3(256), 0, (const BfsStep *)steps, (uint32_t)level,
-                csr->E, fa, fb, (const uint32_t *)active, (const uint64_t *)seen, csr->off, csr->nbr);
-      GG_LAUNCH(ctx, "bfs_update", (k_bfs_update_dev<DistT>), dim3(vgrid), dim3(256), 0, steps, (uint32_t)level, csr->E, fa,
-                fb, seen, V, csr->off, dist8);
-      GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull_dev<DistT>), dim3(pull_grid), dim3(256), 0, steps, (uint32_t)level, csr->E, fa,
+                csr->E, (const uint64_t *)fa, (const uint64_t *)fb, fnext, (const uint64_t *)seen, csr->off, csr->nbr, V);
+      GG_LAUNCH(ctx, "bfs_update", (k_bfs_update_dev<DistT>), dim3(ugrid), dim3(256), 0, steps, (uint32_t)level, csr->E, fa,
+                fb, fnext, seen, V, csr->off, dist8);
+      GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull_dev<DistT>), dim3(pull_grid), dim3(GG_BFS_PULL_THREADS), 0, steps, (uint32_t)level, csr->E, fa,
                 fb, seen, V, csr->off, csr->roff, csr->rnbr, dist8);
     }
     launched = upto;
@@ -682,13 +627,12 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   }
   ctx->dev_free(ids_dev);
   ctx->dev_free(src_dense);
-  ctx->dev_free(active);
+  ctx->dev_free(fnext);
   ctx->dev_free(fa);
   ctx->dev_free(fb);
   ctx->dev_free(seen);
   ctx->dev_free(dist8);
   ctx->dev_free(steps);
-  ctx->dev_free(cursors);
   if (stats) *stats = st;
   return rc;
 }
