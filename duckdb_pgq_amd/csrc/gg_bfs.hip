@@ -154,10 +154,20 @@ __global__ __launch_bounds__(256) void k_bfs_push_dev(const BfsStep *__restrict_
       m &= m - 1;
       const uint64_t f = __shfl(mine, l, 64);
       const uint32_t b = off[base + l], e = off[base + l + 1];
-      for (uint32_t i = b + lane; i < e; i += 64) {
-        const uint32_t w = nbr[i];
-        const uint64_t nf = f & ~seen[w];
-        if (nf) atomicOr((unsigned long long *)&fnext[w], (unsigned long long)nf);
+      // four 64-entry steps of the row at a time: their neighbour loads, then their seen gathers, are in flight
+      // together (a row is walked by ONE wavefront; hubs of the light levels have hundreds of entries)
+      for (uint32_t i = b + lane; i < e; i += 256) {
+        uint32_t w[4];
+        uint64_t sw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = i + 64 * k < e ? nbr[i + 64 * k] : INVALID_U32;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sw[k] = w[k] != INVALID_U32 ? seen[w[k]] : ~0ULL;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint64_t nf = f & ~sw[k];
+          if (nf) atomicOr((unsigned long long *)&fnext[w[k]], (unsigned long long)nf);
+        }
       }
     }
   }
