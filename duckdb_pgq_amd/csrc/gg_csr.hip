@@ -673,18 +673,23 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   GG_TRY(ctx->dev_alloc((void **)&csr->off, (V + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->nbr, (E ? E : 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&csr->epos, (E ? E : 1) * sizeof(uint32_t)));
+  // status block and, 64 bytes behind it, the dictionary descriptor of the bucketed build: one seed copy for both
+  static_assert(sizeof(BuildStatus) <= 64 && sizeof(DirectMap) <= 64, "status + dictionary descriptor: 128 bytes");
   BuildStatus *st = nullptr;
-  GG_TRY(ctx->dev_alloc((void **)&st, sizeof(BuildStatus)));
+  GG_TRY(ctx->dev_alloc((void **)&st, 128));
   BuildStatus init{0ULL, -1LL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+  const DirectMap dm_init{INT64_MAX, INT64_MIN, 0ULL, (unsigned long long)DICT_PACKED8, 0ULL, 0ULL, 0ULL, 0ULL};
+  memset(ctx->pin_scratch, 0, 128);
   memcpy(ctx->pin_scratch, &init, sizeof(init));
-  GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch, sizeof(init), hipMemcpyHostToDevice, s));
-  if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+  memcpy(ctx->pin_scratch + 8, &dm_init, sizeof(dm_init));
+  GG_HIP(hipMemcpyAsync(st, ctx->pin_scratch, 128, hipMemcpyHostToDevice, s));
   // whole graphs and shards of up to 2^22 vertices: forward and reverse CSR by the bucketed build
   // (gg_csr_fast.hip), which also picks and fills the id dictionary; the 16-byte table is then filled only if the
   // densification needs it (ensure_ht does it later for gg_csr_lookup, source lists, the neighbour filter)
   int fast = 0;
-  if (!ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));
+  if (!ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));  // (copies the staged vertex ids itself)
   if (!fast) {
+    if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     GG_LAUNCH(ctx, "ht_init", k_ht_init, dim3((unsigned)((csr->ht_cap + 255) / 256)), dim3(256), 0, csr->ht,
               csr->ht_cap);
     if (V)
@@ -694,8 +699,10 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   if (!fast) GG_TRY(ctx->dev_alloc((void **)&csr->row, (E ? E : 1) * sizeof(uint32_t)));
 
   unsigned long long *kept_dev = nullptr, *kept_rev_dev = nullptr;
-  GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
-  GG_HIP(hipMemsetAsync(kept_dev, 0, sizeof(unsigned long long), s));
+  if (!fast) {
+    GG_TRY(ctx->dev_alloc((void **)&kept_dev, sizeof(unsigned long long)));
+    GG_HIP(hipMemsetAsync(kept_dev, 0, sizeof(unsigned long long), s));
+  }
   uint32_t *rkey_sorted = nullptr;
   if (shard && !fast) {
     GG_TRY(ctx->dev_alloc((void **)&kept_rev_dev, sizeof(unsigned long long)));
@@ -777,9 +784,9 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
               (uint64_t)0, (const unsigned long long *)kept_dev, V, csr->off, (const unsigned long long *)ctx->dev_err);
     GG_LAUNCH(ctx, "publish_kept", k_publish_kept, dim3(1), dim3(64), 0, (const uint64_t *)kept_dev,
               (const uint64_t *)kept_rev_dev, st);
-  } else {  // the gather of explicit rowids below reads the kept count from kept_dev
-    GG_HIP(hipMemcpyAsync(kept_dev, &st->kept, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
   }
+  // (the bucketed build left the kept count in the status block: the gather of explicit rowids reads it there)
+  const unsigned long long *kept_count = fast ? (const unsigned long long *)&st->kept : kept_dev;
   csr->has_rowid = !shard && ctx->keep_edge_rowid;
   if (ctx->rowid_explicit && E && csr->has_rowid) {
     // rows staged without rowids never wrote the rowid column: their rowid is their position
@@ -789,13 +796,14 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
                 ctx->c_rowid.dev + range.first, (int64_t)range.first, range.second);
     GG_TRY(ctx->dev_alloc((void **)&csr->eid, E * sizeof(int64_t)));
     GG_LAUNCH(ctx, "gather_rowid", k_gather_rowid, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, csr->epos,
-              ctx->c_rowid.dev, (const unsigned long long *)kept_dev, csr->eid,
+              ctx->c_rowid.dev, kept_count, csr->eid,
               (const unsigned long long *)ctx->dev_err);
   }
 
   // status back to the host (the only synchronisation of the build): duplicate check, sentinel
   // vertex, kept-edge count
-  GG_HIP(hipMemcpyAsync(&st->scan_error, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+  if (!fast)  // (the bucketed build runs no chained scan)
+    GG_HIP(hipMemcpyAsync(&st->scan_error, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
   GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, s));
   GG_HIP(hipStreamSynchronize(s));
   BuildStatus hs;

@@ -1160,18 +1160,25 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   uint32_t q = 9;  // slot pairs = 2^q: the smallest power of two with a load factor <= GG_FB_LOAD_PCT
   while ((2ull << q) * GG_FB_LOAD_PCT < V * 100) q++;
   const uint64_t npairs = 1ull << q;
-  GG_TRY(ctx->dev_alloc((void **)&dm, sizeof(DirectMap)));
+  dm = reinterpret_cast<DirectMap *>(reinterpret_cast<unsigned long long *>(st) + 8);  // seeded with st (csr_build_impl)
   GG_TRY(ctx->dev_alloc((void **)&dir, DIRECT_MAX_RANGE * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&tab, 2 * npairs * sizeof(unsigned long long)));
-  const DirectMap dm_init{INT64_MAX, INT64_MIN, 0ULL, (unsigned long long)DICT_PACKED8, 0ULL, 0ULL, 0ULL, 0ULL};
-  memcpy(ctx->pin_scratch + 8, &dm_init, sizeof(dm_init));  // (the first words carry the BuildStatus seed)
-  GG_HIP(hipMemcpyAsync(dm, ctx->pin_scratch + 8, sizeof(dm_init), hipMemcpyHostToDevice, s));
+  // column totals of the counter matrix (zeroed by k_dict_init): allocated here, used by the column kernels below
+  const uint32_t ncol = 2 * nb;
+  uint32_t gsz = 16;  // tiles per group of the column kernels; at most 512 groups for the single-workgroup step
+  while ((nblocks64 + gsz - 1) / gsz > 512) gsz *= 2;
+  const uint32_t ngroups = (uint32_t)((nblocks64 + gsz - 1) / gsz);
+  uint32_t *partial = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&partial, ((uint64_t)ngroups + 1) * ncol * sizeof(uint32_t)));
+  uint32_t *coltot = partial + (uint64_t)ngroups * ncol;  // column totals, then column (= bucket) starts
   {
     uint64_t span = csr->ht_cap > 2 * npairs ? csr->ht_cap : 2 * npairs;
     if (span < DIRECT_MAX_RANGE) span = DIRECT_MAX_RANGE;
     if (span < V) span = V;
-    GG_LAUNCH(ctx, "dict_init", k_dict_init, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_cap, tab, 2 * npairs, dir, dm, st, (uint32_t)csr->part, (uint32_t)csr->n_parts);
+    GG_LAUNCH(ctx, "dict_init", k_dict_init, dim3((unsigned)((span + 255) / 256)), dim3(256), 0,
+              (const int64_t *)ctx->c_vid.dev, V, csr->ht,
+              csr->ht_cap, tab, 2 * npairs, dir, dm, st, (uint32_t)csr->part, (uint32_t)csr->n_parts, csr->vid, coltot,
+              ncol);
     GG_LAUNCH(ctx, "dict_insert", k_dict_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
               csr->ht_cap, tab, dir, dm, idx_bits, q, st);
     GG_LAUNCH(ctx, "dict_wide", k_dict_wide, dim3((unsigned)((V + 255) / 256 < 512 ? (V + 255) / 256 : 512)), dim3(256), 0,
@@ -1198,18 +1205,11 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
             pairs, g, nblocks64, counts);
   const uint64_t pmax = 2 * (nblocks64 + nb);  // chunks: every bucket may end in a partial one
   uint4 *part_of = nullptr;
-  uint32_t *cstart = nullptr, *offs = nullptr, *substart = nullptr, *partial = nullptr;
-  const uint32_t ncol = 2 * nb;
-  uint32_t gsz = 16;  // tiles per group of the column kernels; at most 512 groups for the single-workgroup step
-  while ((nblocks64 + gsz - 1) / gsz > 512) gsz *= 2;
-  const uint32_t ngroups = (uint32_t)((nblocks64 + gsz - 1) / gsz);
+  uint32_t *cstart = nullptr, *offs = nullptr, *substart = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&cstart, (2 * nb + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint4)));
   GG_TRY(ctx->dev_alloc((void **)&offs, pmax * 65 * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * 65 * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&partial, ((uint64_t)ngroups + 1) * ncol * sizeof(uint32_t)));
-  uint32_t *coltot = partial + (uint64_t)ngroups * ncol;  // column totals, then column (= bucket) starts
-  GG_HIP(hipMemsetAsync(coltot, 0, ncol * sizeof(uint32_t), s));
   GG_LAUNCH(ctx, "col_partial", k_col_partial, dim3(ngroups), dim3(1024), 0, (const uint32_t *)counts, nblocks64, ncol, gsz,
             partial, coltot);
   GG_LAUNCH(ctx, "col_scan", k_col_scan, dim3(1), dim3(1024), 0, coltot, nb, bstart, cstart, part_of, st);
@@ -1321,7 +1321,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   }
 #undef GG_FB_LAUNCH_B
 
-  for (void *p : {(void *)dm, (void *)dir, (void *)tab, (void *)pairs, (void *)counts, (void *)bstart, (void *)total,
+  for (void *p : {(void *)dir, (void *)tab, (void *)pairs, (void *)counts, (void *)bstart, (void *)total,
                   (void *)part_f, (void *)part_r, (void *)epos_f, (void *)cstart, (void *)part_of, (void *)offs,
                   (void *)substart, (void *)partial})
     ctx->dev_free(p);

@@ -212,8 +212,13 @@ static __global__ __launch_bounds__(256) void k_dict_init(const int64_t *__restr
                                                           unsigned long long *__restrict__ tab, uint64_t nslots,
                                                           uint32_t *__restrict__ dir, DirectMap *__restrict__ dm,
                                                           BuildStatus *__restrict__ st, uint32_t part,
-                                                          uint32_t n_parts) {
+                                                          uint32_t n_parts, int64_t *__restrict__ vid_copy,
+                                                          uint32_t *__restrict__ zero_u32, uint32_t n_zero) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (small jobs that would otherwise be commands of their own on the stream, ~5 us each: the CSR's copy of the
+  // staged vertex ids, the column totals of the counter matrix)
+  if (i < V) vid_copy[i] = vid[i];
+  if (i < n_zero) zero_u32[i] = 0;
   if (i < cap) {
     uint4 e;
     e.x = 0u;

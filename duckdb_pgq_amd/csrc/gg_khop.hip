@@ -488,8 +488,10 @@ __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nrun
 __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
                                                     const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
                                                     uint64_t fbase, uint64_t M, int emit_mid,
-                                                    unsigned long long *__restrict__ partial) {
+                                                    unsigned long long *__restrict__ partial,
+                                                    unsigned long long *__restrict__ zero3) {
   __shared__ MidShared sm;
+  if (blockIdx.x == 0 && threadIdx.x < 3) zero3[threadIdx.x] = 0;  // k_reduce_partials' accumulators (next kernel)
   uint64_t mid_sum = 0, rows_last = 0;
   uint32_t corr = 0;
   uint32_t acc[MID_R];
@@ -870,8 +872,9 @@ struct Sums {  // device: [0]=mid digest [1]=last digest [2]=rows_last
   unsigned long long *dev = nullptr;
 };
 
-int reduce_partials(gg_ctx *ctx, unsigned long long *partial, uint64_t nblocks, unsigned long long *out3) {
-  GG_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), ctx->stream));
+int reduce_partials(gg_ctx *ctx, unsigned long long *partial, uint64_t nblocks, unsigned long long *out3,
+                    bool zeroed = false /* the producer kernel cleared out3 */) {
+  if (!zeroed) GG_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(unsigned long long), ctx->stream));
   if (nblocks) {
     unsigned grid = (unsigned)((nblocks + 255) / 256);
     if (grid > 64) grid = 64;
@@ -1043,8 +1046,8 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
     GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
     GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
     GG_LAUNCH(ctx, "expand_mid2", k_expand_mid2, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr, csr->rrow,
-              csr->rnbr, fbase, M, (int)(k_min <= 1), partial);
-    GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
+              csr->rnbr, fbase, M, (int)(k_min <= 1), partial, tmp);
+    GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp, true));
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(hipStreamSynchronize(ctx->stream));
     dig1 = ctx->pin_scratch[0];
