@@ -178,7 +178,7 @@ template <typename DistT>
 __device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
                                             uint64_t *__restrict__ next, uint64_t V, uint32_t level,
                                             const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
-                                            BfsLevel *__restrict__ lv, uint64_t *s_red);
+                                            BfsLevel *__restrict__ lv, uint64_t *s_red, uint32_t blocks);
 
 template <typename DistT>
 __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
@@ -186,31 +186,19 @@ __global__ __launch_bounds__(256) void k_bfs_update(uint64_t *__restrict__ front
                                                     const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
                                                     BfsLevel *__restrict__ lv) {
   __shared__ uint64_t s_red[12];
-  update_body<DistT>(frontier, seen, next, V, level, off, dist8, lv, s_red);
-}
-
-template <typename DistT>
-__global__ __launch_bounds__(256) void k_bfs_update_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
-                                                        uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
-                                                        uint64_t *__restrict__ fnext, uint64_t *__restrict__ seen,
-                                                        uint64_t V, const uint32_t *__restrict__ off,
-                                                        uint64_t *__restrict__ dist8) {
-  __shared__ uint64_t s_red[12];
-  const BfsStep prev = steps[level - 1];
-  if (bfs_mode(prev, E) != BFS_PUSH) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) steps[level].cur = prev.cur;  // the new frontier stays in the same buffer
-  update_body<DistT>(prev.cur ? f1 : f0, seen, fnext, V, level, off, dist8,
-                     reinterpret_cast<BfsLevel *>(&steps[level]), s_red);
+  update_body<DistT>(frontier, seen, next, V, level, off, dist8, lv, s_red, 0);
 }
 
 template <typename DistT>
 __device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uint64_t *__restrict__ seen,
                                             uint64_t *__restrict__ next, uint64_t V, uint32_t level,
                                             const uint32_t *__restrict__ off, uint64_t *__restrict__ dist8,
-                                            BfsLevel *__restrict__ lv, uint64_t *s_red) {
-  // grid-strided: the level counters take three same-address atomics per BLOCK, so few blocks
+                                            BfsLevel *__restrict__ lv, uint64_t *s_red, uint32_t blocks) {
+  // grid-strided over `blocks` blocks (default: the grid): the level counters take three same-address atomics per
+  // BLOCK, so few blocks
+  if (!blocks) blocks = gridDim.x;
   uint64_t act = 0, te = 0, reached = 0;
-  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (uint64_t)blocks * blockDim.x) {
     const uint64_t s = seen[v];
     const uint64_t nw = next[v] & ~s;
     next[v] = 0;
@@ -253,23 +241,46 @@ __global__ __launch_bounds__(256) void k_bfs_pull(const uint64_t *__restrict__ f
   pull_body<DistT>(fin, fout, seen, V, level, off, roff, rnbr, dist8, lv, s_red);
 }
 
-#ifndef GG_BFS_PULL_THREADS
-#define GG_BFS_PULL_THREADS 256  // (1024-thread blocks, a quarter of the level-counter atomics: 395 instead of 401 us per batch, not worth it)
-#endif
+// Second (and last) kernel of a device-driven level: after a push it folds `fnext` into the new frontier (on its
+// first `update_blocks` blocks), on a heavy frontier it IS the level (pull).  One launch for either direction: a
+// kernel that finds nothing to do still costs 4-5 us of stream time, and a five-level search had eleven of those.
 template <typename DistT>
-__global__ __launch_bounds__(GG_BFS_PULL_THREADS) void k_bfs_pull_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
-                                                      uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
-                                                      uint64_t *__restrict__ seen, uint64_t V,
-                                                      const uint32_t *__restrict__ off,
-                                                      const uint32_t *__restrict__ roff,
-                                                      const uint32_t *__restrict__ rnbr,
-                                                      uint64_t *__restrict__ dist8) {
-  __shared__ uint64_t s_red[3 * GG_BFS_PULL_THREADS / 64];
+__global__ __launch_bounds__(256) void k_bfs_finish_dev(BfsStep *__restrict__ steps, uint32_t level, uint64_t E,
+                                                        uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
+                                                        uint64_t *__restrict__ fnext, uint64_t *__restrict__ seen,
+                                                        uint64_t V, const uint32_t *__restrict__ off,
+                                                        const uint32_t *__restrict__ roff,
+                                                        const uint32_t *__restrict__ rnbr,
+                                                        uint64_t *__restrict__ dist8, uint32_t update_blocks) {
+  __shared__ uint64_t s_red[12];
   const BfsStep prev = steps[level - 1];
-  if (bfs_mode(prev, E) != BFS_PULL) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) steps[level].cur = prev.cur ^ 1ULL;  // every word of the other buffer is written
-  pull_body<DistT>(prev.cur ? f1 : f0, prev.cur ? f0 : f1, seen, V, level, off, roff, rnbr, dist8,
-                   reinterpret_cast<BfsLevel *>(&steps[level]), s_red);
+  const int mode = bfs_mode(prev, E);
+  if (mode == BFS_DONE) return;
+  BfsLevel *lv = reinterpret_cast<BfsLevel *>(&steps[level]);
+  if (mode == BFS_PUSH) {
+    if (blockIdx.x >= update_blocks) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) steps[level].cur = prev.cur;  // the new frontier stays in the same buffer
+    update_body<DistT>(prev.cur ? f1 : f0, seen, fnext, V, level, off, dist8, lv, s_red, update_blocks);
+  } else {
+    if (blockIdx.x == 0 && threadIdx.x == 0) steps[level].cur = prev.cur ^ 1ULL;  // every word of the other buffer is written
+    pull_body<DistT>(prev.cur ? f1 : f0, prev.cur ? f0 : f1, seen, V, level, off, roff, rnbr, dist8, lv, s_red);
+  }
+}
+
+// the word buffers, seen words and distance cells of a batch in one launch (six memsets were six commands)
+__global__ __launch_bounds__(256) void k_bfs_clear(uint64_t *__restrict__ f0, uint64_t *__restrict__ f1,
+                                                   uint64_t *__restrict__ fnext, uint64_t *__restrict__ seen,
+                                                   uint64_t *__restrict__ dist_words, uint64_t V, uint64_t n_dist_words,
+                                                   uint64_t *__restrict__ steps_words, uint64_t n_steps_words) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t i = t; i < V; i += stride) {
+    f0[i] = 0;
+    f1[i] = 0;
+    fnext[i] = 0;
+    seen[i] = 0;
+  }
+  for (uint64_t i = t; i < n_dist_words; i += stride) dist_words[i] = ~0ULL;
+  for (uint64_t i = t; i < n_steps_words; i += stride) steps_words[i] = 0;
 }
 
 template <typename DistT>
@@ -502,12 +513,15 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   // (pageable source: the runtime stages it before the call returns; no synchronisation needed here)
   GG_HIP(hipMemcpyAsync(ids_dev, src_ids, (size_t)n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
   GG_TRY(lookup_ids(ctx, csr, ids_dev, (uint64_t)n_src, src_dense));
-  GG_HIP(hipMemsetAsync(steps, 0, STEP_SLOTS * sizeof(BfsStep), s));
-  GG_HIP(hipMemsetAsync(fa, 0, V * sizeof(uint64_t), s));
-  GG_HIP(hipMemsetAsync(fb, 0, V * sizeof(uint64_t), s));
-  GG_HIP(hipMemsetAsync(fnext, 0, V * sizeof(uint64_t), s));  // the push direction's `next`: all-zero between levels
-  GG_HIP(hipMemsetAsync(seen, 0, V * sizeof(uint64_t), s));
-  GG_HIP(hipMemsetAsync(dist8, 0xFF, V * 64 * sizeof(DistT), s));
+  {
+    const uint64_t dist_words = V * 64 * sizeof(DistT) / sizeof(uint64_t);
+    const uint64_t steps_words = STEP_SLOTS * sizeof(BfsStep) / sizeof(uint64_t);
+    const uint64_t most = dist_words > steps_words ? dist_words : steps_words;
+    uint64_t blocks = (most + 256 * 8 - 1) / (256 * 8);  // eight words per thread
+    if (blocks > (uint64_t)ctx->num_cus * 16) blocks = (uint64_t)ctx->num_cus * 16;
+    GG_LAUNCH(ctx, "bfs_clear", k_bfs_clear, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, fa, fb, fnext, seen, dist8, V,
+              dist_words, reinterpret_cast<uint64_t *>(steps), steps_words);
+  }
   GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<DistT>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, fa, seen, dist8,
             reinterpret_cast<BfsLevel *>(steps));  // steps[0]: cur = 0 (fa) from the memset
 
@@ -528,8 +542,7 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   const uint64_t chunks = (V + 63) / 64;  // push: 64 frontier words per wavefront
   const unsigned push_grid = (unsigned)(((chunks < max_waves ? chunks : max_waves) * 64 + 255) / 256);
   const uint64_t quads = (V + 3) / 4;  // pull: four vertices per wavefront
-  const unsigned pull_grid =
-      (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + GG_BFS_PULL_THREADS - 1) / GG_BFS_PULL_THREADS);
+  const unsigned pull_grid = (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + 255) / 256);
   std::vector<BfsStep> host_steps((size_t)level_cap + 2);
   int launched = 0;  // levels 1..launched are enqueued
   uint64_t reached = 0;
@@ -543,10 +556,8 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
       }
       GG_LAUNCH(ctx, "bfs_push", k_bfs_push_dev, dim3(push_grid), dim3(256), 0, (const BfsStep *)steps, (uint32_t)level,
                 csr->E, (const uint64_t *)fa, (const uint64_t *)fb, fnext, (const uint64_t *)seen, csr->off, csr->nbr, V);
-      GG_LAUNCH(ctx, "bfs_update", (k_bfs_update_dev<DistT>), dim3(ugrid), dim3(256), 0, steps, (uint32_t)level, csr->E, fa,
-                fb, fnext, seen, V, csr->off, dist8);
-      GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull_dev<DistT>), dim3(pull_grid), dim3(GG_BFS_PULL_THREADS), 0, steps, (uint32_t)level, csr->E, fa,
-                fb, seen, V, csr->off, csr->roff, csr->rnbr, dist8);
+      GG_LAUNCH(ctx, "bfs_finish", (k_bfs_finish_dev<DistT>), dim3(pull_grid > ugrid ? pull_grid : ugrid), dim3(256), 0, steps,
+                (uint32_t)level, csr->E, fa, fb, fnext, seen, V, csr->off, csr->roff, csr->rnbr, dist8, (uint32_t)ugrid);
     }
     launched = upto;
     GG_HIP(hipMemcpyAsync(host_steps.data(), steps, (size_t)(launched + 1) * sizeof(BfsStep), hipMemcpyDeviceToHost, s));
