@@ -665,19 +665,36 @@ __global__ __launch_bounds__(256) void k_compact_sources(const uint32_t *__restr
                                                          uint32_t *__restrict__ fv, uint64_t *__restrict__ fq,
                                                          uint64_t *__restrict__ fdeg, const uint32_t *__restrict__ off,
                                                          unsigned long long *__restrict__ cursor) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t d = i < n ? dense[i] : INVALID_U32;
-  const bool ok = d != INVALID_U32;
-  const uint64_t m = __ballot(ok);
-  const int lane = threadIdx.x & 63;
-  uint64_t base = 0;
-  if (lane == 0 && m) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-  base = __shfl(base, 0, 64);
-  if (ok) {
-    uint64_t o = base + __popcll(m & ((1ULL << lane) - 1ULL));
-    fv[o] = d;
-    fq[o] = dig_q((uint64_t)d, 0);
-    fdeg[o] = (uint64_t)(off[d + 1] - off[d]);
+  // a block takes 1024 consecutive sources (four per thread) and ONE returning atomic on the cursor: one per
+  // wavefront was 9 000 same-address round trips for the 577 k Segment seeds of ConnectedSegments SF1024 (112 us)
+  __shared__ uint32_t s_cnt[16];
+  __shared__ unsigned long long s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t d[4];
+  uint64_t m[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = (uint64_t)blockIdx.x * 1024 + (uint64_t)k * 256 + threadIdx.x;
+    d[k] = i < n ? dense[i] : INVALID_U32;
+    m[k] = __ballot(d[k] != INVALID_U32);
+    if (lane == 0) s_cnt[k * 4 + wave] = (uint32_t)__popcll(m[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int q = 0; q < 16; q++) tot += s_cnt[q];
+    s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ULL;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (d[k] == INVALID_U32) continue;
+    uint64_t o = s_base;
+    for (int q = 0; q < k * 4 + wave; q++) o += s_cnt[q];
+    o += (uint64_t)__popcll(m[k] & ((1ULL << lane) - 1ULL));
+    fv[o] = d[k];
+    fq[o] = dig_q((uint64_t)d[k], 0);
+    fdeg[o] = (uint64_t)(off[d[k] + 1] - off[d[k]]);
   }
 }
 
@@ -1152,7 +1169,7 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
     GG_TRY(ctx->dev_alloc((void **)&fq, (n0 ? n0 : 1) * sizeof(uint64_t)));
     // fv0 holds only valid dense indices, so compaction is the identity here; reuse it for degrees
     if (n0)
-      GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, fv0, n0,
+      GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n0 + 1023) / 1024)), dim3(256), 0, fv0, n0,
                 tmpv, fq, foff, csr->off, (unsigned long long *)cursor);
     // compaction may permute entries across waves: take the permuted list as level 0
     if (n0) GG_HIP(hipMemcpyAsync(c0, tmpv, n0 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1341,7 +1358,7 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
     GG_HIP(hipMemcpyAsync(ids_dev, src_ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     GG_HIP(hipStreamSynchronize(ctx->stream));  // src_ids is caller memory: consumed before return
     GG_TRY(lookup_ids(ctx, csr, ids_dev, n, dense));
-    GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dense, n,
+    GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, dense, n,
               f0.fv, f0.fq, f0.foff, csr->off, cursor);
     GG_TRY(read_u64(ctx, (const uint64_t *)cursor, &n_valid));
     GG_TRY(offsets_from_deg(ctx, f0.foff, n_valid, &M1));
