@@ -501,7 +501,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 #ifndef GG_FB_LEAF_TARGET
 #define GG_FB_LEAF_TARGET 2048  // entries per leaf aimed at: between half of this and this
 #endif
-constexpr int LEAF_WAVES = 4;    // waves (= leaves) per workgroup of k_leaf_rows
+#ifndef GG_FB_LEAF_WAVES
+#define GG_FB_LEAF_WAVES 1  // (4 leaves per workgroup hold their LDS until the largest is done: 366 us against 349 at SF100)
+#endif
+constexpr int LEAF_WAVES = GG_FB_LEAF_WAVES;  // waves (= leaves) per workgroup of k_leaf_rows
 #ifndef GG_FB_LEAF_MAXS
 #define GG_FB_LEAF_MAXS 24
 #endif
