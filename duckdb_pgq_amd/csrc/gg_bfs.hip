@@ -24,6 +24,10 @@
 // SURVEY.md F4).  Algorithmic bytes per level: 8V + 16Va + 24*TE_level (+ 24V update) — SURVEY §8d.
 #include "gg_internal.h"
 
+#ifndef GG_BFS_PULL_FACTOR
+#define GG_BFS_PULL_FACTOR 16  // a level pulls when its frontier has more than E / this many edges
+#endif
+
 using namespace gg;
 
 namespace gg {
@@ -127,7 +131,7 @@ struct BfsStep {
 enum BfsMode : int { BFS_DONE = 0, BFS_PUSH = 1, BFS_PULL = 2 };
 __device__ __forceinline__ int bfs_mode(const BfsStep &prev, uint64_t E) {
   if (prev.n_active == 0) return BFS_DONE;
-  return prev.te * 16 > E ? BFS_PULL : BFS_PUSH;  // heavy frontier: gather instead of scatter
+  return prev.te * GG_BFS_PULL_FACTOR > E ? BFS_PULL : BFS_PUSH;  // heavy frontier: gather instead of scatter
 }
 
 // push level, device-driven: no active-vertex list.  A wave reads 64 consecutive frontier words (one coalesced
