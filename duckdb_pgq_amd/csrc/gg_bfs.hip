@@ -13,7 +13,7 @@
 //                                         their rows (coalesced CSR row read), 8-byte OR into next[w] only for
 //                                         lanes w has not seen; `next` is a third word buffer, all-zero between levels
 //                          k_bfs_update:  new = next & ~seen; seen |= new; distances; next frontier + stats; next = 0
-//   pull (heavy frontier)  k_bfs_pull:    16 lanes (lists of >= 128: the whole wavefront) per vertex w that
+//   pull (heavy frontier)  k_bfs_pull:    16 lanes per vertex w that
 //                                         still misses lanes: OR of frontier[v] over the in-neighbours
 //                                         (reverse CSR row read + 8-byte gathers from the V-sized, L2-resident frontier),
 //                                         no atomics; writes the next frontier, seen, distances and the
@@ -25,7 +25,7 @@
 #include "gg_internal.h"
 
 #ifndef GG_BFS_PULL_FACTOR
-#define GG_BFS_PULL_FACTOR 16  // a level pulls when its frontier has more than E / this many edges
+#define GG_BFS_PULL_FACTOR 8  // a level pulls when its frontier has more than E / this many edges (16: 0.65 ms per batch, 8: 0.62, 4: 0.66 at SF100)
 #endif
 
 using namespace gg;
@@ -221,12 +221,7 @@ __device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uin
 // pull: four vertices per wavefront, sixteen lanes each (grid-strided); reads fin, writes fout (ping-pong
 // frontiers).  In-degrees are heavy-tailed (SF100: median 27, mean 89, max ~1000): a whole wavefront per
 // vertex leaves 40 % of the lanes idle and runs one dependent seen -> offsets -> list -> frontier chain at a
-// time, so short lists go to a 16-lane group each, four chains in flight per wave, and only lists of
-// PULL_HEAVY entries or more are walked by all 64 lanes, one after the other.
-#ifndef GG_PULL_HEAVY
-#define GG_PULL_HEAVY 128
-#endif
-constexpr uint32_t PULL_HEAVY = GG_PULL_HEAVY;
+// time, so every list goes to a 16-lane group, four chains in flight per wave.
 
 template <typename DistT>
 __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
@@ -306,13 +301,14 @@ __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint
       b = roff[w];
       e = roff[w + 1];
     }
-    const bool heavy = e - b >= PULL_HEAVY;
     uint64_t acc = 0;
     {
       // a 16-lane group walks its list 16 entries per trip and stops as soon as the lanes w still misses are all
       // found (checked every second trip): in the levels where the frontier is most of the graph a vertex is
-      // complete after one or two trips instead of the 5.5 an average list takes
-      bool walking = !heavy && b < e;
+      // complete after one or two trips instead of the 5.5 an average list takes.  (Long lists used to be handed to
+      // the whole wavefront, one after the other: with the early stop that only made the other three groups wait —
+      // 462 us of pull levels per batch at SF100 against 389 without.)
+      bool walking = b < e;
       uint32_t i0 = b;
       for (int trip = 1; __any(walking); trip++) {
         if (walking) {
@@ -331,17 +327,6 @@ __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);  // stays inside the 16-lane group
-    uint64_t hm = __ballot(heavy && gl == 0);  // bit 16*g: group g's vertex wants the whole wave
-    while (hm) {
-      const int leader = __ffsll((long long)hm) - 1;
-      hm &= hm - 1;
-      const uint32_t hb = __shfl(b, leader, 64), he = __shfl(e, leader, 64);
-      uint64_t a = 0;
-      for (uint32_t i = hb + lane; i < he; i += 64) a |= fin[rnbr[i]];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) a |= __shfl_xor(a, o, 64);
-      if (group == (leader >> 4)) acc = a;
-    }
     const uint64_t nw = acc & ~s;
     if (gl == 0 && valid) {
       fout[w] = nw;
