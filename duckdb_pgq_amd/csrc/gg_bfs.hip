@@ -24,6 +24,12 @@
 // SURVEY.md F4).  Algorithmic bytes per level: 8V + 16Va + 24*TE_level (+ 24V update) — SURVEY §8d.
 #include "gg_internal.h"
 
+#ifndef GG_PULL_LANES
+#define GG_PULL_LANES 8   // lanes per vertex in the pull kernels (SF100 pull levels per batch: 32 lanes 443 us, 16: 348, 8: 296, 4: 299, 2: 388)
+#endif
+#ifndef GG_PULL_CHECK
+#define GG_PULL_CHECK 1   // trips between two looks whether the vertex is complete (1: 296 us, 2: 306, 4: 329)
+#endif
 #ifndef GG_BFS_PULL_FACTOR
 #define GG_BFS_PULL_FACTOR 8  // a level pulls when its frontier has more than E / this many edges (16: 0.65 ms per batch, 8: 0.62, 4: 0.66 at SF100)
 #endif
@@ -288,11 +294,12 @@ __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint
                                           const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
                                           const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
                                           BfsLevel *__restrict__ lv, uint64_t *s_red) {
-  const int lane = threadIdx.x & 63, group = lane >> 4, gl = lane & 15;
+  constexpr int L = GG_PULL_LANES, VPW = 64 / L;  // lanes per vertex, vertices per wavefront
+  const int lane = threadIdx.x & 63, group = lane / L, gl = lane % L;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
   uint64_t act = 0, te = 0, reached = 0;  // accumulated by the first lane of each group
-  for (uint64_t wbase = wave0 * 4; wbase < V; wbase += nwaves * 4) {
+  for (uint64_t wbase = wave0 * VPW; wbase < V; wbase += nwaves * VPW) {
     const uint64_t w = wbase + group;
     const bool valid = w < V;
     const uint64_t s = valid ? seen[w] : ~0ULL;
@@ -303,10 +310,10 @@ __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint
     }
     uint64_t acc = 0;
     {
-      // a 16-lane group walks its list 16 entries per trip and stops as soon as the lanes w still misses are all
-      // found (checked every second trip): in the levels where the frontier is most of the graph a vertex is
+      // a lane group walks its list L entries per trip and stops as soon as the lanes w still misses are all
+      // found (checked every GG_PULL_CHECK trips): in the levels where the frontier is most of the graph a vertex is
       // complete after one or two trips instead of the 5.5 an average list takes.  (Long lists used to be handed to
-      // the whole wavefront, one after the other: with the early stop that only made the other three groups wait —
+      // the whole wavefront, one after the other: with the early stop that only made the other groups wait —
       // 462 us of pull levels per batch at SF100 against 389 without.)
       bool walking = b < e;
       uint32_t i0 = b;
@@ -314,19 +321,19 @@ __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint
         if (walking) {
           const uint32_t i = i0 + gl;
           if (i < e) acc |= fin[rnbr[i]];
-          i0 += 16;
+          i0 += L;
           if (i0 >= e) walking = false;
         }
-        if ((trip & 1) == 0) {
+        if ((trip % GG_PULL_CHECK) == 0) {
           uint64_t g = acc;
 #pragma unroll
-          for (int o = 8; o > 0; o >>= 1) g |= __shfl_xor(g, o, 64);
+          for (int o = L / 2; o > 0; o >>= 1) g |= __shfl_xor(g, o, 64);
           if ((g | s) == ~0ULL) walking = false;
         }
       }
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);  // stays inside the 16-lane group
+    for (int o = L / 2; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);  // stays inside the lane group
     const uint64_t nw = acc & ~s;
     if (gl == 0 && valid) {
       fout[w] = nw;
@@ -530,7 +537,7 @@ static int bfs_run(gg_ctx *ctx, gg_csr *csr, const int64_t *src_ids, int n_src, 
   const unsigned ugrid = vgrid < (unsigned)ctx->num_cus * GG_BFS_UGRID ? vgrid : (unsigned)ctx->num_cus * GG_BFS_UGRID;
   const uint64_t chunks = (V + 63) / 64;  // push: 64 frontier words per wavefront
   const unsigned push_grid = (unsigned)(((chunks < max_waves ? chunks : max_waves) * 64 + 255) / 256);
-  const uint64_t quads = (V + 3) / 4;  // pull: four vertices per wavefront
+  const uint64_t quads = (V + 64 / GG_PULL_LANES - 1) / (64 / GG_PULL_LANES);  // pull: 64 / GG_PULL_LANES vertices per wavefront
   const unsigned pull_grid = (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + 255) / 256);
   std::vector<BfsStep> host_steps((size_t)level_cap + 2);
   int launched = 0;  // levels 1..launched are enqueued
@@ -816,7 +823,7 @@ extern "C" int gg_bfs_sharded_expand(gg_bfs_run *run, void **next_words_dev, uin
   run->level++;
   if (V) {
     const uint64_t max_waves = (uint64_t)ctx->num_cus * 32;
-    const uint64_t quads = (V + 3) / 4;
+    const uint64_t quads = (V + 64 / GG_PULL_LANES - 1) / (64 / GG_PULL_LANES);
     const uint64_t waves = quads < max_waves ? quads : max_waves;
     GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull<uint8_t>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, run->front,
               run->next, run->seen, V, run->level, csr->off, csr->roff, csr->rnbr, run->dist8, run->lv);
