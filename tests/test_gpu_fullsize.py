@@ -69,3 +69,31 @@ def test_sf100_size_independent_properties(gg):
     dist, st = gg.bfs64(csr2, sources, -1, targets=sources)
     assert np.array_equal(dist, dist.T) and st["levels"] >= 3
     csr2.close()
+
+
+def test_sf10_three_hop_product_kernel_equals_frontier_kernels(gg):
+    """288 G three-hop walks at SF10: the product kernel ({2-hop rows ending in b} x out(b)) and the frontier kernels
+    (one hash per walk) return the same counts, digests and traversed-edge totals for every k_min; the distinct
+    endpoints of 1..2-hop walks from 64 sources (gg_walk_endpoints) are the vertices a bounded BFS reaches, the
+    sources that lie on a 2-cycle included."""
+    vid, src, dst = datagen.ldbc("sf10")
+    stage(gg, vid, src, dst)
+    csr = gg.build_csr()
+    for kmin in (1, 3):
+        got = gg.expand_khop(csr, kmin, 3)
+        gg.force_frontier(True)
+        try:
+            want = gg.expand_khop(csr, kmin, 3)
+        finally:
+            gg.force_frontier(False)
+        assert got == want, kmin
+    assert got["rows"][3] > 2 * 10**11
+    sources = datagen.pick_sources(vid, 64, 11)
+    ids, masks = gg.walk_endpoints(csr, sources, 2)
+    dist, _ = gg.bfs64(csr, sources, 2)
+    reached = vid[np.flatnonzero(((dist == 1) | (dist == 2)).any(axis=0))]
+    # walk endpoints = BFS vertices at distance 1..2, plus sources that end a 2-walk (distance 0 in the BFS)
+    extra = np.setdiff1d(ids, reached)
+    assert np.isin(reached, ids).all() and np.isin(extra, sources).all()
+    assert ((masks & ~0b110) == 0).all() and (masks != 0).all()
+    csr.close()
