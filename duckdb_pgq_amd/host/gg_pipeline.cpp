@@ -104,10 +104,24 @@ namespace {
 //! use: MaxThreads (asked when the consuming pipeline is launched, after its dependencies), or the first GetData.
 class GraphScanGlobalState : public GlobalSourceState {
 public:
-	GraphScanGlobalState(const PhysicalGGGraphScan &op, ClientContext &context) : op(op), context(context) {
+	GraphScanGlobalState(const PhysicalGGGraphScan &op, ClientContext &context)
+	    : op(op), context(context), slot(op.slot), keep_graph(op.keep_graph) {
 	}
-	const PhysicalGGGraphScan &op;
+	~GraphScanGlobalState() override {
+		// the executor drops its pipelines (and this state with them) when the statement is done: the device graph goes
+		// with it, a prepared plan does not sit on HBM between executions.  (The plan itself may already be gone here:
+		// only what this state holds on its own is touched.)
+		state.reset();
+		source.reset();
+		if (!keep_graph) {
+			lock_guard<mutex> guard(slot->lock);
+			slot->graph.reset();
+		}
+	}
+	const PhysicalGGGraphScan &op;  // (valid while the plan runs: Ensure, MaxThreads)
 	ClientContext &context;
+	shared_ptr<GGGraphSlot> slot;
+	bool keep_graph;
 	mutex lock;
 	unique_ptr<PhysicalOperator> source;
 	unique_ptr<GlobalSourceState> state;
@@ -273,6 +287,7 @@ static int GGBuildPipelinesRule(void *executor_p, void *op_p, void *current_p) {
 	auto current = (Pipeline *)current_p;
 	vector<vector<unique_ptr<PhysicalOperator>>> hidden(scans.size());
 	for (idx_t i = 0; i < scans.size(); i++) {
+		scans[i]->keep_graph = !ctes.empty();
 		hidden[i] = move(scans[i]->children);
 		scans[i]->children.clear();
 	}

@@ -54,6 +54,9 @@ public:
 	shared_ptr<GGGraphSlot> slot;
 	Factory factory;
 	bool parallel_result;
+	//! set while the plan's pipelines are built: the scan sits in a plan with a recursive CTE, whose pipelines are
+	//! reset and re-run per iteration — the graph then lives as long as the plan
+	mutable bool keep_graph = false;
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
