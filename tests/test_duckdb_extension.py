@@ -619,3 +619,31 @@ def test_sinks_run_as_pipelines_of_the_references_executor(db, monkeypatch):
         assert np.array_equal(sort_rows(d.execute(rows)), sort_rows(want_rows))
     finally:
         d.execute("PRAGMA disable_gpu_graph")
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_pipeline_sinks_inside_a_plan_with_a_recursive_cte(db):
+    """A join chain taken over by the join rule inside a statement that also runs a recursive CTE: the chain's
+    sinks get their pipelines next to the CTE's own (which the executor resets and re-runs per iteration), and the
+    statement returns the reference's rows — whether the chain feeds the CTE's seed or is joined with its result."""
+    d, vid = db
+    s = int(vid[3])
+    seed_chain = ("WITH RECURSIVE reach(x, hop) AS ("
+                  f"SELECT k2.k_person2id, 2 FROM knows k1, knows k2 WHERE k1.k_person1id = {s} AND k1.k_person2id = k2.k_person1id "
+                  "UNION SELECT k.k_person2id, r.hop + 1 FROM reach r, knows k WHERE r.x = k.k_person1id AND r.hop < 3) "
+                  "SELECT count(*), sum(x % 1000), max(hop) FROM reach")
+    beside = ("WITH RECURSIVE up(n) AS (SELECT 1 UNION SELECT n + 1 FROM up WHERE n < 4) "
+              "SELECT up.n, c.walks FROM up, (SELECT count(*) AS walks FROM knows k1, knows k2 "
+              "WHERE k1.k_person2id = k2.k_person1id) c ORDER BY up.n")
+    for sql in (seed_chain, beside):
+        d.execute("PRAGMA disable_gpu_graph")
+        cpu = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        try:
+            plan = d.explain(sql)
+            gpu = d.execute(sql)
+            again = d.execute(sql)
+        finally:
+            d.execute("PRAGMA disable_gpu_graph")
+        assert "GG_PATH" in plan and "GG_EDGE_SINK" in plan, plan
+        assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu) and np.array_equal(cpu, again), sql
