@@ -647,3 +647,31 @@ def test_pipeline_sinks_inside_a_plan_with_a_recursive_cte(db):
             d.execute("PRAGMA disable_gpu_graph")
         assert "GG_PATH" in plan and "GG_EDGE_SINK" in plan, plan
         assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu) and np.array_equal(cpu, again), sql
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_several_substituted_scans_in_one_plan(db):
+    """Two (three) GPU scans in one statement, each with its own sink pipelines: under UNION ALL (the second scan
+    is the source of a union pipeline), on both sides of a join, and under a UNION that is deduped."""
+    d, vid = db
+    a, b = int(vid[5]), int(vid[9])
+    two = "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id"
+    three = ("SELECT count(*) FROM knows k1, knows k2, knows k3 WHERE k1.k_person2id = k2.k_person1id "
+             "AND k2.k_person2id = k3.k_person1id")
+    ends = "SELECT k2.k_person2id AS v FROM knows k1, knows k2 WHERE k1.k_person1id = {} AND k1.k_person2id = k2.k_person1id"
+    cases = [
+        f"{two} UNION ALL {three} UNION ALL {two}",
+        f"SELECT count(*) FROM ({ends.format(a)}) x, ({ends.format(b)}) y WHERE x.v = y.v",
+        f"SELECT count(*) FROM ({ends.format(a)} UNION {ends.format(b)}) u",
+    ]
+    for sql in cases:
+        d.execute("PRAGMA disable_gpu_graph")
+        cpu = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        try:
+            plan = d.explain(sql)
+            gpu = d.execute(sql)
+        finally:
+            d.execute("PRAGMA disable_gpu_graph")
+        assert plan.count("GG_EDGE_SINK") >= 2, plan
+        assert np.array_equal(sort_rows(cpu), sort_rows(gpu)), sql
