@@ -11,6 +11,9 @@ import duckdb_pgq_amd as pkg  # noqa: E402
 from duckdb_pgq_amd.gg import KhopStats  # noqa: E402
 
 scale = sys.argv[1] if len(sys.argv) > 1 else "sf10"
+if len(sys.argv) > 2:  # a libgg variant (scripts/build_variants.py)
+    from duckdb_pgq_amd import gg as ggmod
+    ggmod._lib = ggmod.load_library(os.path.abspath(sys.argv[2]))
 vid, src, dst = pkg.datagen.ldbc(scale)
 g = pkg.GG(0)
 g.append_vertices(vid)
