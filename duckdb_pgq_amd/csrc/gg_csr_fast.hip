@@ -27,6 +27,7 @@
 // Algorithmic bytes: SURVEY.md §8d, 32E + 8V (densification) + 32E + 16V (CSR without rowid).
 #include "gg_dict.h"
 #include "gg_internal.h"
+#include "gg_runs.h"
 
 using namespace gg;
 
@@ -362,10 +363,21 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
   for (int dir = 0; dir < 2; dir++) {
     for (uint32_t i = threadIdx.x; i < FB_WAVES * nb; i += FB_THREADS) hw[i] = 0;
     __syncthreads();
+    // (decided once per wave and direction, on its first 64 rows: the table's order does not change in between)
+    const bool runs = wave_has_runs((dir ? v[0] : u[0]) >> g.low,
+                                    u[0] != INVALID_U32 && !((dir ? v[0] : u[0]) & FB_SKIP), lane);
+    if (runs) {
 #pragma unroll
-    for (int it = 0; it < FB_ITEMS; it++) {
-      const uint32_t key = dir ? v[it] : u[it];
-      if (u[it] != INVALID_U32 && !(key & FB_SKIP)) atomicAdd(&myh[key >> g.low], 1u);
+      for (int it = 0; it < FB_ITEMS; it++) {
+        const uint32_t key = dir ? v[it] : u[it];
+        run_add<false>(myh, key >> g.low, u[it] != INVALID_U32 && !(key & FB_SKIP), lane);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) {
+        const uint32_t key = dir ? v[it] : u[it];
+        if (u[it] != INVALID_U32 && !(key & FB_SKIP)) atomicAdd(&myh[key >> g.low], 1u);
+      }
     }
     __syncthreads();
     // per bucket: wave counts -> staged-slot cursors (first staged slot of the bucket + the waves before); the
@@ -419,46 +431,61 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
     if (STOP == 2) continue;  // timing probe: counts and scans only
     // rank inside the tile (stable) and stage in LDS in bucket order
     volatile uint32_t *cur = myh;
-#pragma unroll
-    for (int it = 0; it < FB_ITEMS; it++) {
-      const uint32_t key = dir ? v[it] : u[it], pay = (dir ? u[it] : v[it]) & ~FB_SKIP;
-      const bool valid = u[it] != INVALID_U32 && !(key & FB_SKIP);  // (shards: this direction's endpoint is owned)
-      const uint32_t d = valid ? key >> g.low : 0u;
-      uint64_t m = __ballot(valid);
-      uint32_t pos = 0;
-      bool counted = false;  // the cursor already moved
-      if (g.rank_atomic) {
-        // one bucket for the whole wave (edge tables sorted by an endpoint): lanes in order, one add
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, m ? __ffsll((unsigned long long)m) - 1 : 0);
-        if (__ballot(valid && d != d0) != 0) {
-          if (valid) pos = atomicAdd((uint32_t *)&cur[d], 1u);
-          counted = true;
-        }
+    auto stage = [&](int it, uint32_t pos, uint32_t key, uint32_t pay, uint32_t d) {
+      if (PACK) {
+        xw[pos] = ((key & low_mask) << g.key_bits) | pay;
       } else {
-#if GG_FB_MATCH_OR
-        m = match_or(mm, d, valid, lane);
-#else
-        for (uint32_t bit = 0; bit < g.hb; bit++) {  // match mask: same bucket within the wave
-          const uint64_t bb = __ballot((d >> bit) & 1u);
-          m &= ((d >> bit) & 1u) ? bb : ~bb;
-        }
-#endif
+        xw[pos] = key & low_mask;
+        xp[pos] = pay;
       }
-      if (valid) {
-        if (!counted) pos = cur[d] + __popcll(m & lane_lt);
-        if (PACK) {
-          xw[pos] = ((key & low_mask) << g.key_bits) | pay;
+      if (ROWID && dir == 0) xe[pos] = (uint32_t)(wbase + (uint64_t)it * 64 + lane);
+      xd[pos] = (uint16_t)d;
+    };
+    if (g.rank_atomic && !runs) {  // the common case on its own: sixteen adds in flight, no wave-wide tests between
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) {
+        const uint32_t key = dir ? v[it] : u[it], pay = (dir ? u[it] : v[it]) & ~FB_SKIP;
+        if (u[it] != INVALID_U32 && !(key & FB_SKIP)) {  // (shards: this direction's endpoint is owned)
+          const uint32_t d = key >> g.low;
+          stage(it, atomicAdd((uint32_t *)&cur[d], 1u), key, pay, d);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) {
+        const uint32_t key = dir ? v[it] : u[it], pay = (dir ? u[it] : v[it]) & ~FB_SKIP;
+        const bool valid = u[it] != INVALID_U32 && !(key & FB_SKIP);
+        const uint32_t d = valid ? key >> g.low : 0u;
+        uint64_t m = __ballot(valid);
+        uint32_t pos = 0;
+        bool counted = false;  // the cursor already moved
+        if (g.rank_atomic) {
+          // runs: one bucket for the whole wave (a bucket is tens of thousands of entries), lanes in order, one
+          // add.  (run_add<true> here costs nine registers, and the workgroup its second slot on the CU.)
+          const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, m ? __ffsll((unsigned long long)m) - 1 : 0);
+          if (__ballot(valid && d != d0) != 0) {
+            if (valid) pos = atomicAdd((uint32_t *)&cur[d], 1u);
+            counted = true;
+          }
         } else {
-          xw[pos] = key & low_mask;
-          xp[pos] = pay;
+#if GG_FB_MATCH_OR
+          m = match_or(mm, d, valid, lane);
+#else
+          for (uint32_t bit = 0; bit < g.hb; bit++) {  // match mask: same bucket within the wave
+            const uint64_t bb = __ballot((d >> bit) & 1u);
+            m &= ((d >> bit) & 1u) ? bb : ~bb;
+          }
+#endif
         }
-        if (ROWID && dir == 0) xe[pos] = (uint32_t)(wbase + (uint64_t)it * 64 + lane);
-        xd[pos] = (uint16_t)d;
-      }
-      if (!counted) {  // uniform
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));  // lowest lane of each group
-        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+          if (!counted) pos = cur[d] + __popcll(m & lane_lt);
+          stage(it, pos, key, pay, d);
+        }
+        if (!counted) {  // uniform
+          __builtin_amdgcn_wave_barrier();
+          if (valid && (m & lane_lt) == 0) atomicAdd((uint32_t *)&cur[d], (uint32_t)__popcll(m));  // lowest lane of each group
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
     __syncthreads();
@@ -723,9 +750,15 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     if (acc == 0x12345678u && c1 == 1) offs[0] = acc;
     return;
   }
+  const bool runs = wave_has_runs(k[0] >> g.leaf, k[0] != INVALID_U32, lane);  // (see k_partition_dual)
+  if (runs) {
 #pragma unroll
-  for (int it = 0; it < FB_ITEMS; it++)
-    if (k[it] != INVALID_U32) atomicAdd(&myh[k[it] >> g.leaf], 1u);
+    for (int it = 0; it < FB_ITEMS; it++) run_add<false>(myh, k[it] >> g.leaf, k[it] != INVALID_U32, lane);
+  } else {
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++)
+      if (k[it] != INVALID_U32) atomicAdd(&myh[k[it] >> g.leaf], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < 64) {  // <= 64 sub-buckets: wave 0 turns the counts into staged-slot cursors
     uint32_t tot = 0, cw[FB_WAVES];
@@ -764,12 +797,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     uint64_t m = __ballot(valid);
     uint32_t pos = 0;
     bool counted = false;
-    if (g.rank_atomic) {  // (see k_partition_dual)
-      const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)sb, m ? __ffsll((unsigned long long)m) - 1 : 0);
-      if (__ballot(valid && sb != s0) != 0) {
-        if (valid) pos = atomicAdd((uint32_t *)&cur[sb], 1u);
-        counted = true;
+    if (g.rank_atomic) {
+      if (runs) {
+        pos = run_add<true>((uint32_t *)cur, sb, valid, lane);
+      } else if (valid) {
+        pos = atomicAdd((uint32_t *)&cur[sb], 1u);
       }
+      counted = true;
     } else {
       for (uint32_t bit = 0; bit < g.sub; bit++) {  // match mask: same sub-bucket within the wave
         const uint64_t bb = __ballot((sb >> bit) & 1u);
@@ -856,9 +890,16 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restri
     const uint32_t len = chunk.y - chunk.x;
     myh[lane] = 0;
     __builtin_amdgcn_wave_barrier();
+    const bool runs = wave_has_runs(w[0] >> (g.key_bits + g.leaf), mine < len, lane);  // (see k_partition_dual)
+    if (runs) {
 #pragma unroll
-    for (int it = 0; it < FB_ITEMS; it++)
-      if (mine + it * 64 < len) atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
+      for (int it = 0; it < FB_ITEMS; it++)
+        run_add<false>(myh, w[it] >> (g.key_bits + g.leaf), mine + it * 64 < len, lane);
+    } else {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++)
+        if (mine + it * 64 < len) atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < 64) {  // <= 64 sub-buckets: wave 0 turns the counts into staged-slot cursors
       uint32_t tot = 0, cw[FB_WAVES];
@@ -888,11 +929,20 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restri
       }
     }
     __syncthreads();
+    if (runs) {
 #pragma unroll
-    for (int it = 0; it < FB_ITEMS; it++) {  // ranks straight from the wave's cursors (lane-ordered ds_add_rtn)
-      if (mine + it * 64 < len) {
-        const uint32_t pos = atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
-        xw[pos] = w[it];
+      for (int it = 0; it < FB_ITEMS; it++) {
+        const bool valid = mine + it * 64 < len;
+        const uint32_t pos = run_add<true>(myh, w[it] >> (g.key_bits + g.leaf), valid, lane);
+        if (valid) xw[pos] = w[it];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) {  // ranks straight from the wave's cursors (lane-ordered ds_add_rtn)
+        if (mine + it * 64 < len) {
+          const uint32_t pos = atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
+          xw[pos] = w[it];
+        }
       }
     }
     __syncthreads();
@@ -972,6 +1022,7 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
   uint32_t kw[LEAF_MAXS], pw[PACK ? 1 : LEAF_MAXS], ew[ROWID ? LEAF_MAXS : 1];
   uint32_t have = 0;  // bit q: kw[q] holds an entry
   bool single = false;
+  bool runs = false;  // the leaf's entries come in runs of one vertex (decided on its first 64)
 #pragma unroll 1
   for (int pass = 0; pass < 2; pass++) {
     for (uint32_t cg = 0; cg < nch || cg == 0; cg += 64) {
@@ -1020,9 +1071,18 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
           }
         }
         if (pass == 0) {
+          if (cg == 0 && r == 0)
+            runs = wave_has_runs((PACK ? kw[0] >> g.key_bits : kw[0]) & leaf_mask, have & 1u, lane);
+          if (runs) {
 #pragma unroll
-          for (int q = 0; q < LEAF_MAXS; q++)
-            if ((have >> q) & 1u) atomicAdd(&lc[(PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask], 1u);
+            for (int q = 0; q < LEAF_MAXS; q++)
+              if (r + q < T)  // uniform
+                run_add<false>(lc, (PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask, (have >> q) & 1u, lane);
+          } else {
+#pragma unroll
+            for (int q = 0; q < LEAF_MAXS; q++)
+              if ((have >> q) & 1u) atomicAdd(&lc[(PACK ? kw[q] >> g.key_bits : kw[q]) & leaf_mask], 1u);
+          }
         } else {
           volatile uint32_t *cur = lc;
 #pragma unroll
@@ -1034,7 +1094,11 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
             uint64_t m = __ballot(valid);
             uint32_t rel = 0;
             if (g.rank_atomic) {
-              if (valid) rel = atomicAdd((uint32_t *)&cur[d], 1u);
+              if (runs) {
+                rel = run_add<true>((uint32_t *)cur, d, valid, lane);
+              } else if (valid) {
+                rel = atomicAdd((uint32_t *)&cur[d], 1u);
+              }
             } else {
               for (uint32_t bit = 0; bit < g.leaf; bit++) {  // match mask: same vertex within the wave
                 const uint64_t bb = __ballot((d >> bit) & 1u);

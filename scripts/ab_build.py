@@ -25,6 +25,10 @@ if ids_mode:  # same graph, other vertex ids: "dense" (direct-address array) or 
     mul = 1 if ids_mode == "dense" else int(ids_mode[3:])
     vid = (rng.permutation(vid.size).astype(np.int64)) * mul + 12345
     src, dst = vid[ds], vid[dd]
+if os.environ.get("AB_SORT", "0") == "1":  # an edge table sorted by source id (as LDBC ships knows)
+    import numpy as np
+    order = np.argsort(src, kind="stable")
+    src, dst = src[order], dst[order]
 out = {}
 ref = None
 for rep in range(2):

@@ -884,6 +884,71 @@ def test_bfs64_pairs_packed_words_decode_to_the_same_rows(gg, orc):
     g.close()
 
 
+@pytest.mark.parametrize("order", ["src", "dst", "src_dst", "half"])
+@pytest.mark.parametrize("V,E", [(65, 3000), (1024, 50_000), (70_000, 600_000), (300_000, 2_000_000)])
+@pytest.mark.parametrize("rowid", [False, True])
+def test_edge_tables_sorted_by_an_endpoint(gg, orc, order, V, E, rowid):
+    """A table sorted by an endpoint (LDBC ships `knows` that way) puts runs of one key side by side: the build's
+    counters then take one add per run (gg_runs.h) instead of one per lane.  Same arrays as the oracle, in
+    both rank modes, whichever column the table is sorted by -- and when only half of it is."""
+    rng = np.random.default_rng(V + E + len(order))
+    vid = datagen.person_ids(V, 5)
+    # skewed degrees: runs from one entry to thousands
+    src = vid[np.minimum((rng.pareto(1.2, E) * V / 50).astype(np.int64), V - 1)]
+    dst = vid[rng.integers(0, V, E)]
+    if order == "src":
+        o = np.argsort(src, kind="stable")
+    elif order == "dst":
+        o = np.argsort(dst, kind="stable")
+    elif order == "src_dst":
+        o = np.lexsort((dst, src))
+    else:
+        o = np.concatenate([np.argsort(src[: E // 2], kind="stable"), np.arange(E // 2, E)])
+    src, dst = src[o], dst[o]
+    gg.set_edge_rowid(rowid)
+    try:
+        rc, g = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        o_off, o_nbr, o_eid, o_vid = g.arrays()
+        want = g.khop(1, 2) if E <= 600_000 else None
+        for mode in (1, 2):
+            gg.rank_mode(mode)
+            gg.staging_clear()
+            gg.append_vertices(vid)
+            gg.append_edges(src, dst)
+            csr = gg.build_csr()
+            off, nbr, eid, v2 = csr.export()
+            assert np.array_equal(off, o_off), mode
+            assert np.array_equal(nbr, o_nbr), mode
+            assert np.array_equal(v2, o_vid), mode
+            assert np.array_equal(eid, o_eid) if rowid else np.all(eid == -1), mode
+            if want is not None:
+                assert gg.expand_khop(csr, 1, 2) == want, mode  # (the reverse rows)
+            csr.close()
+        g.close()
+    finally:
+        gg.rank_mode(0)
+        gg.set_edge_rowid(False)
+
+
+def test_run_add_ranks_lane_by_lane(tmp_path):
+    """gg::run_add (gg_runs.h) against a sequential count over 4 M entries, from random keys to runs of hundreds
+    with invalid lanes and ragged tails; the program touches only its own LDS counters and output slots."""
+    import json
+    import pathlib
+    import shutil
+    import subprocess
+    root = pathlib.Path(__file__).resolve().parents[1]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "ubench_runadd"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-I", str(root / "duckdb_pgq_amd" / "csrc"),
+                    str(root / "scripts" / "ubench_runadd.hip"), "-o", str(exe)], check=True, timeout=300)
+    out = subprocess.run([str(exe)], check=True, timeout=120, capture_output=True, text=True).stdout
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["bad_ranks"] == 0 and res["bad_counts"] == 0, res
+    assert 0 < res["waves_with_runs"] < res["waves"], res
+
+
 def _ids_for(kind, V, rng):
     if kind == "sparse":      # LDBC-like magnitude: packed 8-byte dictionary slots
         return datagen.person_ids(V, 11)
