@@ -249,7 +249,10 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // staged state of the run is folded against it (LDS broadcast read + 4 VALU ops per walk).  The kernel
 // is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
 #ifndef GG_MID_PIPE
-#define GG_MID_PIPE 1
+#define GG_MID_PIPE 2
+#endif
+#ifndef GG_MID_RUNLANES
+#define GG_MID_RUNLANES 1
 #endif
 #ifndef GG_MID_ISPLIT
 #define GG_MID_ISPLIT 128  // runs of at least this many states are split over the workgroup's waves
@@ -277,6 +280,36 @@ __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int 
   int i = ia;
   for (; i < ib && (i & 3); i++) mid_fold<NREG>(s_q[i], t, acc);
   if (i + 4 <= ib) {
+#if GG_MID_PIPE == 2
+    // two groups of four per trip with fixed roles (no register copies between trips)
+    uint4 c0 = *reinterpret_cast<const uint4 *>(s_q + i);
+    for (; i + 12 <= ib; i += 8) {
+      const uint4 c1 = *reinterpret_cast<const uint4 *>(s_q + i + 4);
+      mid_fold<NREG>(c0.x, t, acc);
+      mid_fold<NREG>(c0.y, t, acc);
+      mid_fold<NREG>(c0.z, t, acc);
+      mid_fold<NREG>(c0.w, t, acc);
+      c0 = *reinterpret_cast<const uint4 *>(s_q + i + 8);
+      mid_fold<NREG>(c1.x, t, acc);
+      mid_fold<NREG>(c1.y, t, acc);
+      mid_fold<NREG>(c1.z, t, acc);
+      mid_fold<NREG>(c1.w, t, acc);
+    }
+    if (i + 8 <= ib) {
+      const uint4 c1 = *reinterpret_cast<const uint4 *>(s_q + i + 4);
+      mid_fold<NREG>(c0.x, t, acc);
+      mid_fold<NREG>(c0.y, t, acc);
+      mid_fold<NREG>(c0.z, t, acc);
+      mid_fold<NREG>(c0.w, t, acc);
+      c0 = c1;
+      i += 4;
+    }
+    mid_fold<NREG>(c0.x, t, acc);
+    mid_fold<NREG>(c0.y, t, acc);
+    mid_fold<NREG>(c0.z, t, acc);
+    mid_fold<NREG>(c0.w, t, acc);
+    i += 4;
+#else
     uint4 cur = *reinterpret_cast<const uint4 *>(s_q + i);
     for (; i + 8 <= ib; i += 4) {
       const uint4 nxt = *reinterpret_cast<const uint4 *>(s_q + i + 4);
@@ -291,6 +324,7 @@ __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int 
     mid_fold<NREG>(cur.z, t, acc);
     mid_fold<NREG>(cur.w, t, acc);
     i += 4;
+#endif
   }
   for (; i < ib; i++) mid_fold<NREG>(s_q[i], t, acc);
 #else
@@ -449,7 +483,58 @@ __device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *_
 // stage 4: fold every staged state against the out-row of its run's middle vertex
 __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nruns, const uint32_t *__restrict__ nbr,
                                               uint32_t (&acc)[MID_R], uint32_t &corr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+#if GG_MID_RUNLANES
+  // Run descriptors 64 at a time, one per lane; the wave then walks only the runs it owns (ballot), with the
+  // descriptor in scalar registers.  (Every wave stepping through every run, three quarters of them only to skip
+  // them, was a seventh of the kernel's VALU instructions.)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
+    const uint32_t rl = r0 + (uint32_t)lane;
+    int la = 0, llen = 0;
+    uint32_t ldout = 0, lst = 0;
+    if (rl < nruns) {
+      la = (int)sm.run[rl];
+      llen = (int)sm.run[rl + 1] - la;
+      ldout = sm.rdout[rl];
+      lst = sm.rst[rl];
+    }
+    // long runs: every wave takes a slice of the run (i-split) and walks all J-blocks;
+    // short runs: the whole run belongs to ONE wave (dealt round-robin)
+    uint64_t todo = __ballot(rl < nruns && ldout != 0 &&
+                             (llen >= GG_MID_ISPLIT || (rl & (XT / 64 - 1)) == (uint32_t)wave));
+    while (todo) {
+      const int l = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const int a = __builtin_amdgcn_readlane(la, l), len = __builtin_amdgcn_readlane(llen, l);
+      const uint32_t dout = (uint32_t)__builtin_amdgcn_readlane((int)ldout, l);
+      const uint32_t *__restrict__ row = nbr + (uint32_t)__builtin_amdgcn_readlane((int)lst, l);
+      const bool isplit = len >= GG_MID_ISPLIT;
+      const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
+      const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : a + len;
+      if (ia >= ib) continue;
+      const uint32_t sq = sm.pq[ib] - sm.pq[ia];  // sum of the slice's hash states
+      // J-blocks of equal size (multiple of 64 leaves, at most 64*MID_R): avoids a nearly empty tail block
+      const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
+      const uint32_t jsz = nJ == 1 ? (dout + 63) & ~63u : (((dout + nJ - 1) / nJ) + 63) & ~63u;  // (no division for <= 512)
+      const int nreg = (int)(jsz >> 6);
+      for (uint32_t jb = 0; jb < nJ; jb++) {
+        const uint32_t base = jb * jsz + (uint32_t)lane;
+        switch (nreg) {
+        case 1: mid_block<1>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        case 2: mid_block<2>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        case 3: mid_block<3>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        case 4: mid_block<4>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        case 5: mid_block<5>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        case 6: mid_block<6>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        case 7: mid_block<7>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        default: mid_block<8>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
+        }
+      }
+    }
+  }
+#else
+  const int wave = threadIdx.x >> 6;
   for (uint32_t rr = 0; rr < nruns; rr++) {
     const int a = (int)sm.run[rr], b = (int)sm.run[rr + 1];
     const int len = b - a;
@@ -482,6 +567,7 @@ __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nrun
       }
     }
   }
+#endif
 }
 
 // One tile per workgroup.
