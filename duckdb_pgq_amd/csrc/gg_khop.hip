@@ -403,6 +403,27 @@ __device__ __forceinline__ void mid_prepare(const uint32_t *__restrict__ off, co
   }
 }
 
+// Inclusive prefix sums (mod 2^32) across the wave's lanes with data-parallel-primitive moves instead of
+// ds_bpermute: four shifts inside each row of 16 lanes, then the totals of rows 0 / 2 into rows 1 / 3 and the total
+// of the lower half into the upper.  Call with the whole wave active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {  // the moved value; 0 where no lane feeds this one
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_scan_incl(uint32_t v) {  // within rows of 16 lanes
+  v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  v = row_scan_incl(v);
+  v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // stage 3: LDS image of the tile (states, their prefix sums, runs of equal middle vertex).  Returns the
 // number of runs.  Contains three workgroup barriers; the caller must have finished reading the previous image.
 __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, const MidPrep &p, uint64_t M,
@@ -414,15 +435,20 @@ __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, c
     const uint32_t idx = e * XT + threadIdx.x;
     sm.q[idx] = (uint32_t)p.q[e];
     sm.x[idx] = r.x[e];
-    plo[e] = (uint32_t)p.q[e];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {  // inclusive scan (mod 2^32) inside the wave
-      const uint32_t a = __shfl_up(plo[e], o, 64);
-      if (lane >= o) plo[e] += a;
-    }
+    plo[e] = wave_scan_incl((uint32_t)p.q[e]);  // (mod 2^32)
     if (lane == 63) sm.wsum[e * (XT / 64) + wave] = plo[e];
   }
   __syncthreads();
+  // sums of the segments before each segment: lane s holds segment s, one scan over the first row of 16 lanes
+  auto seg_scan = [&](const uint32_t *per_seg, uint32_t &incl) {
+    const uint32_t v = lane < MID_SEG ? per_seg[lane] : 0u;
+    incl = row_scan_incl(v);
+    return incl - v;
+  };
+  static_assert(MID_SEG <= 16, "segment scan covers 16 lanes");
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  uint32_t s_incl;
+  const uint32_t s_excl = seg_scan(sm.wsum, s_incl);
   bool head[MID_EPT];
   uint64_t hm[MID_EPT];
 #pragma unroll
@@ -430,23 +456,19 @@ __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, c
     const uint32_t idx = e * XT + threadIdx.x;
     head[e] = r.valid[e] && (idx == 0 || sm.x[idx - 1] != r.x[e]);
     hm[e] = __ballot(head[e]);
-    const int seg = e * (XT / 64) + wave;
+    const int seg = e * (XT / 64) + uwave;
     if (lane == 0) sm.wcnt[seg] = (uint32_t)__popcll(hm[e]);
-    uint32_t sbase = 0;
-    for (int w = 0; w < seg; w++) sbase += sm.wsum[w];
-    sm.pq[idx + 1] = sbase + plo[e];
+    sm.pq[idx + 1] = (uint32_t)__builtin_amdgcn_readlane((int)s_excl, seg) + plo[e];
   }
   if (threadIdx.x == 0) sm.pq[0] = 0;
   __syncthreads();
-  uint32_t nruns = 0;
-#pragma unroll
-  for (int w = 0; w < MID_SEG; w++) nruns += sm.wcnt[w];
+  uint32_t c_incl;
+  const uint32_t c_excl = seg_scan(sm.wcnt, c_incl);
+  const uint32_t nruns = (uint32_t)__builtin_amdgcn_readlane((int)c_incl, MID_SEG - 1);
 #pragma unroll
   for (int e = 0; e < MID_EPT; e++) {
+    const uint32_t hbase = (uint32_t)__builtin_amdgcn_readlane((int)c_excl, e * (XT / 64) + uwave);
     if (head[e]) {
-      const int seg = e * (XT / 64) + wave;
-      uint32_t hbase = 0;
-      for (int w = 0; w < seg; w++) hbase += sm.wcnt[w];
       const uint32_t rr = hbase + __popcll(hm[e] & ((1ULL << lane) - 1ULL));
       sm.run[rr] = e * XT + threadIdx.x;
       sm.rst[rr] = p.st[e];
