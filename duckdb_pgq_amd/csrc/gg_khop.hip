@@ -251,6 +251,9 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 #ifndef GG_MID_PIPE
 #define GG_MID_PIPE 2
 #endif
+#ifndef GG_MID_BUFFER
+#define GG_MID_BUFFER 1
+#endif
 #ifndef GG_MID_RUNLANES
 #define GG_MID_RUNLANES 1
 #endif
@@ -490,6 +493,18 @@ __device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *_
                                           uint32_t &corr) {
   uint32_t t[MID_R];
   uint32_t ninv = 0;
+#if GG_MID_BUFFER
+  // the out-row as a buffer of dout words (descriptor in scalar registers, the run is the same in every lane): a
+  // lane past the row's end reads 0 without a compare or a clamped index, the NREG offsets are immediates
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(row), 0, (int)(dout * 4u), 0x00020000);
+  const uint32_t voff = j0 * 4u;
+#pragma unroll
+  for (int r = 0; r < NREG; r++)
+    t[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + r * 256u, 0, 0) * DIG_K32;
+  const uint32_t left = dout > j0 ? (dout - j0 + 63u) >> 6 : 0u;  // registers of this lane that hold a leaf
+  ninv = NREG - (left < (uint32_t)NREG ? left : (uint32_t)NREG);
+#else
 #pragma unroll
   for (int r = 0; r < NREG; r++) {
     const uint32_t j = j0 + r * 64;
@@ -498,6 +513,7 @@ __device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *_
     t[r] = ok ? w * DIG_K32 : 0u;  // low half of the leaf term (w * K mod 2^32: a bijection of w)
     ninv += ok ? 0u : 1u;
   }
+#endif
   mid_accumulate<NREG>(s_q, ia, ib, t, acc);
   corr += ninv * sq;
 }
