@@ -532,6 +532,9 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 #define GG_FB_LEAF_WAVES 1  // (4 leaves per workgroup hold their LDS until the largest is done: 366 us against 349 at SF100)
 #endif
 constexpr int LEAF_WAVES = GG_FB_LEAF_WAVES;  // waves (= leaves) per workgroup of k_leaf_rows
+#ifndef GG_FB_LEAF_READLANE
+#define GG_FB_LEAF_READLANE 1
+#endif
 #ifndef GG_FB_LEAF_MAXS
 #define GG_FB_LEAF_MAXS 24
 #endif
@@ -1014,6 +1017,11 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
   const uint64_t vfirst = ((uint64_t)j << g.low) + ((uint64_t)s << g.leaf);  // first vertex of the leaf
   lc[lane] = 0;
   const bool staged = n <= CAPW;  // wave-uniform
+#if GG_FB_LEAF_READLANE
+  // packed words: positions are u32, so the whole partition is one buffer (entries are bounded by their run)
+  const __amdgpu_buffer_rsrc_t buf_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(buf), 0, (int)0xFFFFFFFCu, 0x00020000);
+#endif
 
   // The leaf's entries: run `s` of every chunk of the bucket, chunk after chunk.  Chunks are taken 64 at a time
   // (lane c holds chunk c's run); a run is walked in 64-entry steps.  pass 0 counts, pass 1 places; when the
@@ -1053,13 +1061,24 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
             if (!PACK) pw[PACK ? 0 : q] = 0;
             if (ROWID) ew[ROWID ? q : 0] = 0;
             if (t < T) {  // uniform
-              const int cc = __popcll(__ballot(sincl <= t));  // the run this step belongs to
+              const int cc = __popcll(__ballot(sincl <= t));  // the run this step belongs to (< 64: t < T)
+#if GG_FB_LEAF_READLANE
+              // (the run is the same for every lane: v_readlane into scalar registers, no ds_bpermute before the load)
+              const uint32_t kidx = (t - (uint32_t)__builtin_amdgcn_readlane((int)sexcl, cc)) * 64 + lane;
+              const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)src, cc) + kidx;
+              if (kidx < (uint32_t)__builtin_amdgcn_readlane((int)len, cc)) {
+#else
               const uint32_t kidx = (t - (uint32_t)__shfl(sexcl, cc, 64)) * 64 + lane;
               const uint32_t e = (uint32_t)__shfl(src, cc, 64) + kidx;
               if (kidx < (uint32_t)__shfl(len, cc, 64)) {
+#endif
                 have |= 1u << q;
                 if (PACK) {
+#if GG_FB_LEAF_READLANE
+                  kw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(buf_rs, e * 4u, 0, 0);  // (32-bit offset)
+#else
                   kw[q] = buf[e];
+#endif
                 } else {
                   const uint2 x = reinterpret_cast<const uint2 *>(buf)[e];
                   kw[q] = x.x;
