@@ -229,6 +229,32 @@ __device__ __forceinline__ void update_body(uint64_t *__restrict__ frontier, uin
 // vertex leaves 40 % of the lanes idle and runs one dependent seen -> offsets -> list -> frontier chain at a
 // time, so every list goes to a 16-lane group, four chains in flight per wave.
 
+// OR over a lane group of L lanes, the result in every lane of the group.  Groups of 8 use data-parallel-primitive
+// moves (two swaps inside the quads, then the mirror image of the 8 lanes, which lies in the other quad) instead
+// of three dependent ds_bpermute round trips per 32-bit half; the reduction sits inside the pull loop's
+// load -> test -> next load chain.  Call with the whole wave active.
+#ifndef GG_PULL_DPP
+#define GG_PULL_DPP 1
+#endif
+template <int L>
+__device__ __forceinline__ uint64_t group_or(uint64_t g) {
+#if GG_PULL_DPP
+  if (L == 8) {
+    uint32_t lo = (uint32_t)g, hi = (uint32_t)(g >> 32);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+    hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false);
+    hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+    lo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x141 /* row_half_mirror */, 0xF, 0xF, false);
+    hi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x141, 0xF, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+  }
+#endif
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) g |= __shfl_xor(g, o, 64);  // stays inside the lane group
+  return g;
+}
+
 template <typename DistT>
 __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint64_t *__restrict__ fout,
                                           uint64_t *__restrict__ seen, uint64_t V, uint32_t level,
@@ -325,15 +351,11 @@ __device__ __forceinline__ void pull_body(const uint64_t *__restrict__ fin, uint
           if (i0 >= e) walking = false;
         }
         if ((trip % GG_PULL_CHECK) == 0) {
-          uint64_t g = acc;
-#pragma unroll
-          for (int o = L / 2; o > 0; o >>= 1) g |= __shfl_xor(g, o, 64);
-          if ((g | s) == ~0ULL) walking = false;
+          if ((group_or<L>(acc) | s) == ~0ULL) walking = false;
         }
       }
     }
-#pragma unroll
-    for (int o = L / 2; o > 0; o >>= 1) acc |= __shfl_xor(acc, o, 64);  // stays inside the lane group
+    acc = group_or<L>(acc);
     const uint64_t nw = acc & ~s;
     if (gl == 0 && valid) {
       fout[w] = nw;
