@@ -1017,11 +1017,6 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
   const uint64_t vfirst = ((uint64_t)j << g.low) + ((uint64_t)s << g.leaf);  // first vertex of the leaf
   lc[lane] = 0;
   const bool staged = n <= CAPW;  // wave-uniform
-#if GG_FB_LEAF_READLANE
-  // packed words: positions are u32, so the whole partition is one buffer (entries are bounded by their run)
-  const __amdgpu_buffer_rsrc_t buf_rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(buf), 0, (int)0xFFFFFFFCu, 0x00020000);
-#endif
 
   // The leaf's entries: run `s` of every chunk of the bucket, chunk after chunk.  Chunks are taken 64 at a time
   // (lane c holds chunk c's run); a run is walked in 64-entry steps.  pass 0 counts, pass 1 places; when the
@@ -1065,8 +1060,10 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
 #if GG_FB_LEAF_READLANE
               // (the run is the same for every lane: v_readlane into scalar registers, no ds_bpermute before the load)
               const uint32_t kidx = (t - (uint32_t)__builtin_amdgcn_readlane((int)sexcl, cc)) * 64 + lane;
-              const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)src, cc) + kidx;
-              if (kidx < (uint32_t)__builtin_amdgcn_readlane((int)len, cc)) {
+              const uint32_t run_src = (uint32_t)__builtin_amdgcn_readlane((int)src, cc);
+              const uint32_t run_len = (uint32_t)__builtin_amdgcn_readlane((int)len, cc);
+              const uint32_t e = run_src + kidx;
+              if (kidx < run_len) {
 #else
               const uint32_t kidx = (t - (uint32_t)__shfl(sexcl, cc, 64)) * 64 + lane;
               const uint32_t e = (uint32_t)__shfl(src, cc, 64) + kidx;
@@ -1075,7 +1072,12 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
                 have |= 1u << q;
                 if (PACK) {
 #if GG_FB_LEAF_READLANE
-                  kw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(buf_rs, e * 4u, 0, 0);  // (32-bit offset)
+                  // the run as a buffer of its own (scalar 64-bit base: partitions of more than 2^30 entries are
+                  // fine, the vector offset stays inside one chunk)
+                  kw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(buf + run_src), 0, (int)(run_len * 4u),
+                                                        0x00020000),
+                      kidx * 4u, 0, 0);
 #else
                   kw[q] = buf[e];
 #endif
