@@ -764,8 +764,125 @@ struct gg_bfs_run {
   uint32_t level = 0;
   int64_t *ids_dev = nullptr;
   uint64_t *front = nullptr, *next = nullptr, *seen = nullptr, *dist8 = nullptr;
-  gg::BfsLevel *lv = nullptr;
+  uint64_t *acc = nullptr;  // push levels OR into this buffer (all-zero between levels)
+  gg::BfsLevel *lv = nullptr;  // [0] the level's result, [1] statistics of the frontier it starts from
+  uint64_t levels_push = 0, levels_pull = 0;
 };
+
+namespace gg {
+
+// ---- graph-sharded levels: direction chosen per level and per rank -----------------------------------------------
+// Every rank holds the whole frontier.  A heavy frontier is pulled over the reverse rows of the owned vertices
+// (k_bfs_pull).  A light one is PUSHED along the same edges grouped by source (pin_off / pin_nbr: row u = the owned
+// destinations of u's edges): only owned words are touched, so seen words, distances and statistics stay with the
+// owner and the ranks' word arrays keep disjoint supports — the one all-reduce per level stays a SUM, whichever
+// direction each rank took (a rank decides from ITS edges: te = entries of the frontier's rows in its pin CSR).
+__global__ __launch_bounds__(256) void k_pin_count(const uint32_t *__restrict__ rnbr, uint64_t n,
+                                                   uint32_t *__restrict__ cnt) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) atomicAdd(&cnt[rnbr[e]], 1u);
+}
+__global__ __launch_bounds__(256) void k_pin_fill(const uint32_t *__restrict__ rnbr, const uint32_t *__restrict__ rrow,
+                                                  uint64_t n, uint32_t *__restrict__ cursor,
+                                                  uint32_t *__restrict__ pin_nbr) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) pin_nbr[atomicAdd(&cursor[rnbr[e]], 1u)] = rrow[e];  // (order inside a row does not matter to a BFS)
+}
+// cursor[v] = pin_off[v] after the fill ran: shift back by the row lengths is not needed, the scan is kept apart
+__global__ __launch_bounds__(256) void k_copy_u32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+static int ensure_push_in(gg_ctx *ctx, gg_csr *csr) {
+  if (csr->pin_off) return GG_OK;
+  const uint64_t V = csr->V, n = csr->E_rev;
+  hipStream_t s = ctx->stream;
+  uint32_t *cnt = nullptr, *pin_off = nullptr, *pin_nbr = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&pin_off, (V + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&pin_nbr, (n ? n : 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&cnt, (V + 1) * sizeof(uint32_t)));
+  GG_HIP(hipMemsetAsync(cnt, 0, (V + 1) * sizeof(uint32_t), s));
+  if (n)
+    GG_LAUNCH(ctx, "pin_count", k_pin_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, csr->rnbr, n, cnt);
+  GG_TRY(scan_exclusive_u32(ctx, cnt, pin_off, V + 1, nullptr));
+  GG_LAUNCH(ctx, "pin_copy", k_copy_u32, dim3((unsigned)((V + 1 + 255) / 256)), dim3(256), 0, pin_off, cnt, V + 1);
+  if (n)
+    GG_LAUNCH(ctx, "pin_fill", k_pin_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, csr->rnbr, csr->rrow, n, cnt,
+              pin_nbr);
+  GG_TRY(scan_error_fetch(ctx));
+  GG_HIP(hipStreamSynchronize(s));
+  GG_TRY(scan_error_test(ctx));
+  ctx->dev_free(cnt);
+  csr->pin_off = pin_off;
+  csr->pin_nbr = pin_nbr;
+  ctx->keep(pin_off);
+  ctx->keep(pin_nbr);
+  return GG_OK;
+}
+
+// statistics of the frontier a sharded level starts from, against this rank's push rows
+__global__ __launch_bounds__(256) void k_shard_frontier_stats(const uint64_t *__restrict__ front, uint64_t V,
+                                                              const uint32_t *__restrict__ pin_off,
+                                                              BfsLevel *__restrict__ st) {
+  __shared__ uint64_t s_red[12];
+  uint64_t act = 0, te = 0;
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (uint64_t)gridDim.x * blockDim.x) {
+    if (front[v]) {
+      act += 1;
+      te += pin_off[v + 1] - pin_off[v];
+    }
+  }
+  add_level_stats(act, te, 0, s_red, st);
+}
+__device__ __forceinline__ bool shard_pushes(const BfsLevel &st, uint64_t E_rev) {
+  return st.te * GG_BFS_PULL_FACTOR <= E_rev;  // (an empty frontier pushes nothing and folds nothing: cheapest)
+}
+// push along the pin rows: the same walk as k_bfs_push_dev, into `acc`
+__global__ __launch_bounds__(256) void k_shard_push(const BfsLevel *__restrict__ st, uint64_t E_rev,
+                                                    const uint64_t *__restrict__ frontier, uint64_t *__restrict__ acc,
+                                                    const uint64_t *__restrict__ seen,
+                                                    const uint32_t *__restrict__ pin_off,
+                                                    const uint32_t *__restrict__ pin_nbr, uint64_t V) {
+  if (!shard_pushes(*st, E_rev)) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t base = wave0 * 64; base < V; base += nwaves * 64) {
+    const uint64_t mine = base + lane < V ? frontier[base + lane] : 0ULL;
+    uint64_t m = __ballot(mine != 0);
+    while (m) {  // uniform
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const uint64_t f = __shfl(mine, l, 64);
+      const uint32_t b = pin_off[base + l], e = pin_off[base + l + 1];
+      for (uint32_t i = b + lane; i < e; i += 64) {
+        const uint32_t w = pin_nbr[i];
+        const uint64_t nf = f & ~seen[w];
+        if (nf) atomicOr((unsigned long long *)&acc[w], (unsigned long long)nf);
+      }
+    }
+  }
+}
+// second kernel of a sharded level: fold the pushes into the exchange words, or pull them
+template <typename DistT>
+__global__ __launch_bounds__(256) void k_shard_finish(const BfsLevel *__restrict__ st, uint64_t E_rev,
+                                                      const uint64_t *__restrict__ front, uint64_t *__restrict__ next,
+                                                      uint64_t *__restrict__ acc, uint64_t *__restrict__ seen, uint64_t V,
+                                                      uint32_t level, const uint32_t *__restrict__ off,
+                                                      const uint32_t *__restrict__ roff,
+                                                      const uint32_t *__restrict__ rnbr, uint64_t *__restrict__ dist8,
+                                                      BfsLevel *__restrict__ lv, uint32_t update_blocks) {
+  __shared__ uint64_t s_red[12];
+  if (shard_pushes(*st, E_rev)) {
+    if (blockIdx.x >= update_blocks) return;
+    update_body<DistT>(next, seen, acc, V, level, off, dist8, lv, s_red, update_blocks);
+  } else {
+    pull_body<DistT>(front, next, seen, V, level, off, roff, rnbr, dist8, lv, s_red);
+  }
+}
+
+}  // namespace gg
 
 extern "C" void gg_bfs_sharded_end(gg_bfs_run *run) {
   if (!run) return;
@@ -773,7 +890,7 @@ extern "C" void gg_bfs_sharded_end(gg_bfs_run *run) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (void *p : {(void *)run->ids_dev, (void *)run->front, (void *)run->next, (void *)run->seen, (void *)run->dist8,
-                  (void *)run->lv})
+                  (void *)run->acc, (void *)run->lv})
     ctx->dev_free(p);
   delete run;
 }
@@ -808,10 +925,18 @@ extern "C" int gg_bfs_sharded_begin(gg_ctx *ctx, const gg_csr *csr_c, const int6
   GG_TRY(ctx->dev_alloc((void **)&run->next, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&run->seen, V * sizeof(uint64_t)));
   GG_TRY(ctx->dev_alloc((void **)&run->dist8, V * 64 * sizeof(uint8_t)));
-  GG_TRY(ctx->dev_alloc((void **)&run->lv, sizeof(BfsLevel)));
+  GG_TRY(ctx->dev_alloc((void **)&run->acc, V * sizeof(uint64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&run->lv, 2 * sizeof(BfsLevel)));
   for (void *p : {(void *)run->ids_dev, (void *)run->front, (void *)run->next, (void *)run->seen, (void *)run->dist8,
-                  (void *)run->lv})
+                  (void *)run->acc, (void *)run->lv})
     ctx->keep(p);
+  if (csr->V && csr->n_parts > 1) {  // (a whole CSR pushes along its forward rows)
+    if (!csr->rrow) {
+      set_error("gg_bfs_sharded: the shard has no reverse COO column");
+      return GG_ERR_INVALID_ARG;
+    }
+    GG_TRY(ensure_push_in(ctx, csr));
+  }
   if (n_src) GG_HIP(hipMemcpyAsync(run->ids_dev, src_ids, (size_t)n_src * sizeof(int64_t), hipMemcpyHostToDevice, s));
   GG_HIP(hipStreamSynchronize(s));
   GG_TRY(lookup_ids(ctx, csr, run->ids_dev, (uint64_t)n_src, src_dense));
@@ -819,7 +944,8 @@ extern "C" int gg_bfs_sharded_begin(gg_ctx *ctx, const gg_csr *csr_c, const int6
   GG_HIP(hipMemsetAsync(run->next, 0, V * sizeof(uint64_t), s));
   GG_HIP(hipMemsetAsync(run->seen, 0, V * sizeof(uint64_t), s));
   GG_HIP(hipMemsetAsync(run->dist8, 0xFF, V * 64 * sizeof(uint8_t), s));
-  GG_HIP(hipMemsetAsync(run->lv, 0, sizeof(BfsLevel), s));
+  GG_HIP(hipMemsetAsync(run->acc, 0, V * sizeof(uint64_t), s));
+  GG_HIP(hipMemsetAsync(run->lv, 0, 2 * sizeof(BfsLevel), s));
   if (csr->V)
     GG_LAUNCH(ctx, "bfs_seed", (k_bfs_seed<uint8_t>), dim3(1), dim3(64), 0, src_dense, n_src, csr->off, run->front,
               run->seen, run->dist8, run->lv, (const int64_t *)csr->vid, (uint32_t)csr->part, (uint32_t)csr->n_parts);
@@ -841,22 +967,44 @@ extern "C" int gg_bfs_sharded_expand(gg_bfs_run *run, void **next_words_dev, uin
     return GG_ERR_TOO_LARGE;
   }
   const uint64_t V = csr->V;
-  GG_HIP(hipMemsetAsync(run->lv, 0, sizeof(BfsLevel), s));
+  GG_HIP(hipMemsetAsync(run->lv, 0, 2 * sizeof(BfsLevel), s));
   run->level++;
   if (V) {
+    // three launches, the direction decided on the device from the frontier's statistics (no read-back in between)
+    const uint32_t *pin_off = csr->n_parts > 1 ? csr->pin_off : csr->off;
+    const uint32_t *pin_nbr = csr->n_parts > 1 ? csr->pin_nbr : csr->nbr;
+    const uint64_t E_rev = csr->E_rev;
+    const unsigned vgrid = (unsigned)((V + 255) / 256);
+    const unsigned ugrid = vgrid < (unsigned)ctx->num_cus * 2 ? vgrid : (unsigned)ctx->num_cus * 2;
     const uint64_t max_waves = (uint64_t)ctx->num_cus * 32;
+    const uint64_t chunks = (V + 63) / 64;
+    const unsigned push_grid = (unsigned)(((chunks < max_waves ? chunks : max_waves) * 64 + 255) / 256);
     const uint64_t quads = (V + 64 / GG_PULL_LANES - 1) / (64 / GG_PULL_LANES);
-    const uint64_t waves = quads < max_waves ? quads : max_waves;
-    GG_LAUNCH(ctx, "bfs_pull", (k_bfs_pull<uint8_t>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, run->front,
-              run->next, run->seen, V, run->level, csr->off, csr->roff, csr->rnbr, run->dist8, run->lv);
+    const unsigned pull_grid = (unsigned)(((quads < max_waves ? quads : max_waves) * 64 + 255) / 256);
+    GG_LAUNCH(ctx, "bfs_shard_stats", k_shard_frontier_stats, dim3(ugrid), dim3(256), 0, run->front, V, pin_off,
+              run->lv + 1);
+    GG_LAUNCH(ctx, "bfs_shard_push", k_shard_push, dim3(push_grid), dim3(256), 0, run->lv + 1, E_rev, run->front, run->acc,
+              run->seen, pin_off, pin_nbr, V);
+    GG_LAUNCH(ctx, "bfs_shard_finish", (k_shard_finish<uint8_t>), dim3(pull_grid > ugrid ? pull_grid : ugrid), dim3(256), 0,
+              run->lv + 1, E_rev, run->front, run->next, run->acc, run->seen, V, run->level, csr->off, csr->roff, csr->rnbr,
+              run->dist8, run->lv, ugrid);
   }
-  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, run->lv, sizeof(BfsLevel), hipMemcpyDeviceToHost, s));
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, run->lv, 2 * sizeof(BfsLevel), hipMemcpyDeviceToHost, s));
   GG_HIP(hipStreamSynchronize(s));  // the words are complete in memory: the caller's collective may read them
-  BfsLevel h;
+  BfsLevel h, st;
   memcpy(&h, ctx->pin_scratch, sizeof(h));
+  memcpy(&st, (const char *)ctx->pin_scratch + sizeof(h), sizeof(st));
+  if (V) (st.te * GG_BFS_PULL_FACTOR <= csr->E_rev ? run->levels_push : run->levels_pull)++;
   if (next_words_dev) *next_words_dev = run->next;
   if (n_words) *n_words = V;
   if (new_pairs_local) *new_pairs_local = h.reached;
+  return GG_OK;
+}
+
+extern "C" int gg_bfs_sharded_levels(const gg_bfs_run *run, uint64_t *push_levels, uint64_t *pull_levels) {
+  if (!run) return GG_ERR_INVALID_ARG;
+  if (push_levels) *push_levels = run->levels_push;
+  if (pull_levels) *pull_levels = run->levels_pull;
   return GG_OK;
 }
 

@@ -637,6 +637,8 @@ extern "C" void gg_csr_destroy(gg_csr *csr) {
     ctx->dev_free(csr->roff);
     ctx->dev_free(csr->rnbr);
     ctx->dev_free(csr->rrow);
+    ctx->dev_free(csr->pin_off);
+    ctx->dev_free(csr->pin_nbr);
   }
   delete csr;
 }

@@ -210,6 +210,10 @@ struct gg_csr {
   uint32_t *roff = nullptr;    // V+1
   uint32_t *rnbr = nullptr;    // E   source u of the reverse entry
   uint32_t *rrow = nullptr;    // E   destination x of the reverse entry (COO view, sorted by x)
+  // the reverse entries grouped by SOURCE (gg_bfs.hip: ensure_push_in, shards only, on first use): row u lists
+  // the owned destinations of u's edges, so a shard can push a light frontier into the words it owns
+  uint32_t *pin_off = nullptr; // V+1
+  uint32_t *pin_nbr = nullptr; // E_rev
 };
 
 struct gg_result {

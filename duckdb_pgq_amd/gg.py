@@ -23,7 +23,7 @@ SYMBOLS = [
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_walk_endpoints", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
     "gg_bfs_sharded_begin", "gg_bfs_sharded_expand", "gg_bfs_sharded_words", "gg_bfs_sharded_commit",
-    "gg_bfs_sharded_pairs", "gg_bfs_sharded_end",
+    "gg_bfs_sharded_pairs", "gg_bfs_sharded_end", "gg_bfs_sharded_levels",
     "gg_profile_enable", "gg_profile_select", "gg_profile_reset", "gg_profile_count", "gg_profile_get",
 ]
 
@@ -116,6 +116,7 @@ def load_library(path: str | None = None):
     lib.gg_bfs_sharded_words.argtypes = [P, C.POINTER(C.c_uint64), C.c_int]
     lib.gg_bfs_sharded_commit.argtypes = [P]
     lib.gg_bfs_sharded_pairs.argtypes = [P, C.POINTER(P)]
+    lib.gg_bfs_sharded_levels.argtypes = [P, C.POINTER(u64), C.POINTER(u64)]
     lib.gg_bfs_sharded_end.argtypes = [P]
     lib.gg_bfs_sharded_end.restype = None
     lib.gg_profile_enable.argtypes = [P, C.c_int]
@@ -164,6 +165,12 @@ class ShardedBfs:
 
     def commit(self):
         self.gg._chk(self.gg.lib.gg_bfs_sharded_commit(self.handle))
+
+    def levels(self):
+        """(levels this rank pushed, levels it pulled) so far."""
+        push, pull = C.c_uint64(), C.c_uint64()
+        self.gg._chk(self.gg.lib.gg_bfs_sharded_levels(self.handle, C.byref(push), C.byref(pull)))
+        return int(push.value), int(pull.value)
 
     def pairs(self) -> np.ndarray:
         i64p = C.POINTER(C.c_int64)
@@ -537,6 +544,7 @@ class GG:
                     r.commit()
                 level += 1
             rows = [r.pairs() for r in runs]
+            self.last_sharded_levels = [r.levels() for r in runs]  # (pushed, pulled) per rank
             return np.concatenate(rows, axis=0), level
         finally:
             for r in runs:

@@ -243,7 +243,10 @@ int gg_walk_endpoints(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, ui
 /* The layout north_star names for graphs that do not fit one GPU: `shard` comes from
  * gg_csr_build_shard; every rank holds the whole frontier (one uint64 of 64 lanes per vertex) and owns the
  * seen words, distances and result rows of its vertices.  Per level, on every rank:
- *     gg_bfs_sharded_expand   pull the next frontier words of the owned vertices (zero elsewhere);
+ *     gg_bfs_sharded_expand   the next frontier words of the owned vertices (zero elsewhere): pulled over
+ *                             their reverse rows when the frontier is heavy, pushed along the same edges
+ *                             grouped by source when it is light (each rank decides from its own edges;
+ *                             either way only owned words are written);
  *                             *next_words_dev points at the n_words uint64 words in HBM
  *     (exchange)              combine the ranks' words — disjoint supports, so a SUM all-reduce (RCCL through
  *                             torch.distributed on a view of that memory) is their OR; the library does
@@ -259,6 +262,8 @@ int gg_bfs_sharded_expand(gg_bfs_run *run, void **next_words_dev, uint64_t *n_wo
 int gg_bfs_sharded_words(gg_bfs_run *run, uint64_t *host_words, int write_back);
 int gg_bfs_sharded_commit(gg_bfs_run *run);
 int gg_bfs_sharded_pairs(gg_bfs_run *run, gg_result **out_result);
+/* how many levels this rank pushed / pulled so far (diagnostic) */
+int gg_bfs_sharded_levels(const gg_bfs_run *run, uint64_t *push_levels, uint64_t *pull_levels);
 void gg_bfs_sharded_end(gg_bfs_run *run);
 
 /* ---- in-library kernel timing (HIP events on the library's own stream) ---------------------- */

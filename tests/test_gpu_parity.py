@@ -835,6 +835,37 @@ def test_graph_sharded_bfs_equals_the_whole_graph_bfs(gg, orc, n_parts, V, E, se
     gg.set_edge_rowid(True)
 
 
+@pytest.mark.parametrize("n_parts", [1, 3, 8])
+@pytest.mark.parametrize("V,E,n_src,seed", [(3000, 40000, 3, 41), (20000, 400000, 64, 42), (500, 900, 2, 43)])
+def test_graph_sharded_bfs_pushes_light_levels_and_pulls_heavy_ones(gg, orc, n_parts, V, E, n_src, seed):
+    """Direction-optimising levels in the graph-sharded BFS: a rank pushes a light frontier along its edges grouped
+    by source (into owned words only, so the exchange stays a SUM) and pulls a heavy one; ranks decide on their own.
+    Rows equal the whole-graph BFS whichever mix of directions the ranks took."""
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=2)
+    sources = datagen.pick_sources(vid, n_src, seed)
+    gg.staging_clear()
+    gg.set_edge_rowid(False)
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    whole = gg.build_csr()
+    expect, st = gg.bfs64_pairs(whole, sources, -1)
+    shards = [gg.build_csr_shard(p, n_parts) for p in range(n_parts)] if n_parts > 1 else [whole]
+    got, levels = gg.bfs_sharded_emulated(shards, sources, -1)
+    assert np.array_equal(sort_rows(got), sort_rows(expect))
+    per_rank = gg.last_sharded_levels
+    assert all(push + pull == levels + 1 for push, pull in per_rank), (per_rank, levels)  # (+ the level that found nothing)
+    assert sum(push for push, _ in per_rank) > 0, per_rank  # the seeds' level is light everywhere
+    if E >= 40000:
+        assert sum(pull for _, pull in per_rank) > 0, per_rank  # the middle levels cover most of the graph
+    got2, _ = gg.bfs_sharded_emulated(shards, sources, -1)  # the push rows are cached on the shard
+    assert np.array_equal(sort_rows(got2), sort_rows(expect))
+    for c in shards:
+        if c is not whole:
+            c.close()
+    whole.close()
+    gg.set_edge_rowid(True)
+
+
 def test_profile_select_times_only_the_named_kernels(gg, orc):
     vid, src, dst = datagen.small_graph(2000, 30000, 71)
     gg.staging_clear()
