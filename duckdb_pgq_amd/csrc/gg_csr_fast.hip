@@ -399,12 +399,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
         }
       }
       const uint32_t mine = tot[0] + tot[1];
-      uint32_t incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
+      const uint32_t incl = wave_scan_incl(mine);  // (DPP moves, gg_internal.h)
       if (lane == 63) misc[wave] = incl;
       __syncthreads();
       uint32_t wb = 0, all = 0;
@@ -634,12 +629,7 @@ __global__ __launch_bounds__(1024) void k_col_scan(uint32_t *__restrict__ coltot
       mine += (len + FB_TILE - 1) / FB_TILE;
     }
   }
-  uint32_t cincl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(cincl, o, 64);
-    if (lane >= o) cincl += t;
-  }
+  const uint32_t cincl = wave_scan_incl(mine);  // (DPP moves, gg_internal.h)
   __syncthreads();
   if (lane == 63) s_w[0][wave] = cincl;
   __syncthreads();
@@ -770,12 +760,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
       cw[q] = hw[q * 64 + lane];
       tot += cw[q];
     }
-    uint32_t incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
+    const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
     uint32_t run = incl - tot;
     dbase[lane] = run;
     offs[(uint64_t)p * 65 + lane] = run;
@@ -911,12 +896,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restri
         cw[q] = hw[q * 64 + lane];
         tot += cw[q];
       }
-      uint32_t incl = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
+      const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
       uint32_t run = incl - tot;
       dbase[lane] = run;
       offs[(uint64_t)p * 65 + lane] = run;
@@ -976,12 +956,7 @@ __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ 
   const uint32_t p0 = cstart[i], p1 = cstart[i + 1];
   uint32_t tot = 0;
   for (uint32_t p = p0; p < p1; p++) tot += offs[(uint64_t)p * 65 + lane + 1] - offs[(uint64_t)p * 65 + lane];
-  uint32_t incl = tot;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
+  const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
   const uint32_t b0 = bstart[dir * (nb + 1) + j];
   substart[(uint64_t)i * 65 + lane] = b0 + incl - tot;
   if (lane == 63) substart[(uint64_t)i * 65 + 64] = b0 + incl;
@@ -1037,12 +1012,7 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
       }
       const uint32_t src = b0 + c * FB_TILE + so;  // position of the run's first entry
       const uint32_t st_c = (len + 63) / 64;       // steps of this run
-      uint32_t sincl = st_c;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(sincl, o, 64);
-        if (lane >= o) sincl += t;
-      }
+      const uint32_t sincl = wave_scan_incl(st_c);  // (DPP moves, gg_internal.h)
       const uint32_t sexcl = sincl - st_c;
       const uint32_t T = __shfl(sincl, 63, 64);  // steps in this group of chunks
       if (pass == 0) single = nch <= 64 && T <= LEAF_MAXS;
@@ -1150,12 +1120,7 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
       // row offsets of the leaf's vertices (lane d = vertex d); lc becomes the relative cursor
       __builtin_amdgcn_wave_barrier();
       const uint32_t cnt = (uint32_t)lane < leafW ? lc[lane] : 0u;
-      uint32_t incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
+      const uint32_t incl = wave_scan_incl(cnt);  // (DPP moves, gg_internal.h)
       if ((uint32_t)lane < leafW) {
         const uint64_t vtx = vfirst + (uint32_t)lane;
         if (vtx <= V) o_off[vtx] = t0 + incl - cnt;  // vtx == V: the closing offset

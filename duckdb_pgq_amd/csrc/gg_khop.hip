@@ -406,27 +406,6 @@ __device__ __forceinline__ void mid_prepare(const uint32_t *__restrict__ off, co
   }
 }
 
-// Inclusive prefix sums (mod 2^32) across the wave's lanes with data-parallel-primitive moves instead of
-// ds_bpermute: four shifts inside each row of 16 lanes, then the totals of rows 0 / 2 into rows 1 / 3 and the total
-// of the lower half into the upper.  Call with the whole wave active.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {  // the moved value; 0 where no lane feeds this one
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ uint32_t row_scan_incl(uint32_t v) {  // within rows of 16 lanes
-  v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
-  v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
-  v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
-  v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
-  v = row_scan_incl(v);
-  v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
-
 // stage 3: LDS image of the tile (states, their prefix sums, runs of equal middle vertex).  Returns the
 // number of runs.  Contains three workgroup barriers; the caller must have finished reading the previous image.
 __device__ __forceinline__ uint32_t mid_stage(MidShared &sm, const MidRows &r, const MidPrep &p, uint64_t M,
