@@ -139,7 +139,7 @@ public:
 		if (!graph || !graph->csr) {
 			throw InternalException(op.name + " scheduled before its sinks built the graph");
 		}
-		source = op.factory(graph);
+		source = op.factory(context, graph);
 		state = source->GetGlobalSourceState(context);
 	}
 	idx_t MaxThreads() override {

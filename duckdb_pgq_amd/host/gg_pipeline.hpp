@@ -46,7 +46,8 @@ public:
 //! (PhysicalGGPathExpand, PhysicalGGWalkEndpoints, ...) once the graph exists.
 class PhysicalGGGraphScan : public PhysicalOperator {
 public:
-	using Factory = std::function<unique_ptr<PhysicalOperator>(shared_ptr<GGGraph>)>;
+	//! (the context is the executing statement's: a factory may read more rows in its transaction, e.g. BFS seeds)
+	using Factory = std::function<unique_ptr<PhysicalOperator>(ClientContext &, shared_ptr<GGGraph>)>;
 	PhysicalGGGraphScan(vector<LogicalType> types, string name, string description, shared_ptr<GGGraphSlot> slot,
 	                    Factory factory, bool parallel_result, idx_t estimated_cardinality);
 

@@ -943,7 +943,7 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 		g_rules_fired++;
 		return GGMakeGraphScan(
 		    spec, move(types), count_only ? "GG_PATH_COUNT" : "GG_PATH_EXPAND", data->description, !count_only,
-		    [=](shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+		    [=](ClientContext &, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
 			    return make_unique<PhysicalGGPathExpand>(move(graph), hops, hops, count_only, sources, all_sources, 0);
 		    },
 		    estimated_cardinality);
@@ -1910,9 +1910,7 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	const auto seed_scan = TableColumns(vertex_table, {vertex_key});
 	const int max_hops = (int)in.max_hops;
 	const bool lone_sources = !validated;
-	auto data = make_unique<GGFunctionData>();
-	data->open = [=](ClientContext &context, GGOpened &opened) {
-		opened.graph = GGBuildGraph(context, spec);
+	auto read_seeds = [=](ClientContext &context) {
 		auto sources = GGScanInt64Column(context, seed_scan);
 		if (!all_vertices || !seed_filters.empty()) {
 			std::unordered_set<int64_t> wanted(seed_constants.begin(), seed_constants.end());
@@ -1928,7 +1926,12 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 			}
 			sources.resize(kept);
 		}
-		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, move(sources), max_hops, 0, lone_sources);
+		return sources;
+	};
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = GGBuildGraph(context, spec);
+		opened.source = make_unique<PhysicalGGShortestPath>(opened.graph, read_seeds(context), max_hops, 0, lone_sources);
 	};
 	data->description = edge_table->name + ": " + edge_table->columns[src].name + " -> " + edge_table->columns[dst].name +
 	                    "\nmin hops <= " + to_string(max_hops) + "\nvertices: " +
@@ -1944,8 +1947,19 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 	vector<column_t> column_ids = {0, 1, 2};
 	vector<string> names = {"startPerson", "friend", "hopCount"};
 	g_rules_fired++;
-	auto scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_shortest_path_bfs"), move(data),
-	                                           move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	unique_ptr<PhysicalOperator> scan;
+	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {
+		// the tables reach the device through pipeline sinks (gg_pipeline.cpp); the seeds are read when the graph exists
+		scan = GGMakeGraphScan(
+		    spec, move(types), "GG_SHORTEST_PATH_BFS", data->description, true,
+		    [=](ClientContext &context, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+			    return make_unique<PhysicalGGShortestPath>(move(graph), read_seeds(context), max_hops, 0, lone_sources);
+		    },
+		    op.estimated_cardinality);
+	} else {
+		scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_shortest_path_bfs"), move(data),
+		                                      move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	}
 	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
 	projection->children.push_back(move(scan));
 	return move(projection);
@@ -2048,7 +2062,7 @@ unique_ptr<PhysicalOperator> PlanDistinctUnion(LogicalDistinct &op) {
 	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {
 		scan = GGMakeGraphScan(
 		    spec, move(types), "GG_WALK_ENDPOINTS", data->description, false,
-		    [=](shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+		    [=](ClientContext &, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
 			    return make_unique<PhysicalGGWalkEndpoints>(move(graph), sources, 2, 0);
 		    },
 		    op.estimated_cardinality);

@@ -207,7 +207,14 @@ def test_plan_rule_friends_cte_gives_the_reference_result(db):
         cpu = d.execute(sql)
         d.execute("PRAGMA enable_gpu_graph")
         assert "GG_SHORTEST_PATH_BFS" in d.explain(sql), d.explain(sql)
+        assert "GG_EDGE_SINK" in d.explain(sql)  # tables through pipeline sinks; GG_NO_PIPELINE_SINKS: from the scan's init
         gpu = d.execute(sql)
+        os.environ["GG_NO_PIPELINE_SINKS"] = "1"
+        try:
+            assert "GG_EDGE_SINK" not in d.explain(sql) and "GG_SHORTEST_PATH_BFS" in d.explain(sql)
+            assert np.array_equal(sort_rows(d.execute(sql)), sort_rows(gpu))
+        finally:
+            del os.environ["GG_NO_PIPELINE_SINKS"]
         d.execute("PRAGMA disable_gpu_graph")
         return sort_rows(cpu), sort_rows(gpu)
 

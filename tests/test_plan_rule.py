@@ -301,6 +301,8 @@ def test_the_build_side_is_planned_as_pipeline_sinks_over_the_references_table_s
         plan = db.explain(keyed)
         if "GG_PATH_EXPAND" in plan:  # (the keyed form needs a declared-unique key: see the fixture)
             assert "GG_VERTEX_SINK" in plan and "GG_EDGE_SINK" in plan
+        plan = db.explain(BFS_TAKEN[0][0])  # the shortest-path rule takes the same route (seeds read once the graph exists)
+        assert "GG_SHORTEST_PATH_BFS" in plan and "GG_EDGE_SINK" in plan and "SEQ_SCAN" in plan and "REC_CTE" not in plan
         db.execute("PRAGMA gg_use_pinned_graphs")
         plan = db.explain(count)
         assert "GG_PATH_COUNT" in plan and "GG_EDGE_SINK" not in plan
@@ -308,6 +310,8 @@ def test_the_build_side_is_planned_as_pipeline_sinks_over_the_references_table_s
         monkeypatch.setenv("GG_NO_PIPELINE_SINKS", "1")
         plan = db.explain(count)
         assert "GG_PATH_COUNT" in plan and "GG_EDGE_SINK" not in plan
+        plan = db.explain(BFS_TAKEN[0][0])
+        assert "GG_SHORTEST_PATH_BFS" in plan and "GG_EDGE_SINK" not in plan
     finally:
         db.execute("PRAGMA gg_ignore_pinned_graphs")
         db.execute("PRAGMA disable_gpu_graph")
