@@ -335,12 +335,6 @@ __host__ __device__ __forceinline__ uint64_t dsum_add(uint64_t a, uint64_t b) {
 __host__ __device__ __forceinline__ uint64_t dsum_sub(uint64_t a, uint64_t b) {
   return (uint64_t)(uint32_t)((uint32_t)a - (uint32_t)b);
 }
-__device__ __forceinline__ uint64_t wave_reduce_dsum(uint64_t v) {
-  uint32_t lo = (uint32_t)v;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lo += __shfl_xor(lo, o, 64);
-  return (uint64_t)lo;
-}
 
 // Inclusive prefix sums (mod 2^32) across the wave's lanes with data-parallel-primitive moves instead of
 // ds_bpermute: four shifts inside each row of 16 lanes, then the totals of rows 0 / 2 into rows 1 / 3 and the total
@@ -361,6 +355,17 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
   v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
   v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
   return v;
+}
+
+// sums over the wave with the DPP scan: the total is the last lane's prefix.  Call with the whole wave active.
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
+}
+__device__ __forceinline__ uint64_t wave_reduce_dsum(uint64_t v) { return (uint64_t)wave_total_u32((uint32_t)v); }
+// a count below 2^50 per lane: two 32-bit totals (24 low bits, the rest)
+__device__ __forceinline__ uint64_t wave_total_u50(uint64_t v) {
+  const uint32_t lo = wave_total_u32((uint32_t)v & 0xFFFFFFu), hi = wave_total_u32((uint32_t)(v >> 24));
+  return ((uint64_t)hi << 24) + lo;
 }
 
 __device__ __forceinline__ uint64_t wave_reduce_add_u64(uint64_t v) {

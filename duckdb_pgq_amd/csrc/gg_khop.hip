@@ -104,7 +104,7 @@ __device__ __forceinline__ void block_store_partials(uint64_t a, uint64_t b, uin
                                                      unsigned long long *__restrict__ partial) {
   a = wave_reduce_dsum(a);
   b = wave_reduce_dsum(b);
-  c = wave_reduce_add_u64(c);
+  c = wave_total_u50(c);  // (a lane's rows: far below 2^50)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     s_red[wave * 3 + 0] = a;
@@ -248,6 +248,9 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced) and every
 // staged state of the run is folded against it (LDS broadcast read + 4 VALU ops per walk).  The kernel
 // is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
+#ifndef GG_MID_PROBE
+#define GG_MID_PROBE 0  // timing probes (wrong digests): 1 states from a scalar counter, no LDS reads; 2 staging only, no fold
+#endif
 #ifndef GG_MID_PIPE
 #define GG_MID_PIPE 2
 #endif
@@ -275,7 +278,14 @@ __device__ __forceinline__ void mid_fold(uint32_t q, const uint32_t (&t)[MID_R],
 template <int NREG>
 __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int ib, const uint32_t (&t)[MID_R],
                                                uint32_t (&acc)[MID_R]) {
-#if GG_MID_PIPE
+#if GG_MID_PROBE == 1  // timing probe (wrong digests): scalar states without any load
+  ia = __builtin_amdgcn_readfirstlane(ia);
+  ib = __builtin_amdgcn_readfirstlane(ib);
+  for (int i = ia; i < ib; i++) {
+#pragma unroll
+    for (int r = 0; r < NREG; r++) asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc[r]) : "s"(i), "v"(t[r]));
+  }
+#elif GG_MID_PIPE
   // the slice bounds are the same in every lane: scalar loop control; states are read four at a time with one
   // 16-byte LDS broadcast read, the next four already in flight while the current ones are folded
   ia = __builtin_amdgcn_readfirstlane(ia);
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
   mid_load_rows(rrow, rnbr, fbase, M, blockIdx.x, rows);
   mid_prepare(off, rows, emit_mid, prep, mid_sum, rows_last);
   const uint32_t nruns = mid_stage(sm, rows, prep, M, blockIdx.x);
-  mid_fold_tile(sm, nruns, nbr, acc, corr);
+  if (GG_MID_PROBE != 2) mid_fold_tile(sm, nruns, nbr, acc, corr);
   uint32_t tsum = 0;
 #pragma unroll
   for (int r = 0; r < MID_R; r++) tsum += acc[r];
