@@ -243,11 +243,11 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // Every 2-hop walk u -> x -> w is one pair (in-edge of x, out-edge of x): the walks through x are the
 // cartesian product in(x) x out(x) — exactly what the reference's second hash join emits when a probe
 // key matches a chain of build rows (join_hashtable.cpp:442-476).  Reading CSR row x once per walk (the
-// frontier formulation above) therefore re-reads it |in(x)| times.  Here a tile of 256 consecutive
+// frontier formulation above) therefore re-reads it |in(x)| times.  Here a tile of MT (768) consecutive
 // REVERSE-CSR entries (= 1-hop rows u->x, grouped by x) is staged in LDS as hash states; for each run
-// of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced) and every
-// staged state of the run is folded against it (LDS broadcast read + 4 VALU ops per walk).  The kernel
-// is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
+// of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced, through a buffer
+// descriptor) and every staged state of the run is folded against it (one 16-byte LDS broadcast read per four
+// states, ONE v_xad_u32 per walk).  The kernel is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
 #ifndef GG_MID_PROBE
 #define GG_MID_PROBE 0  // timing probes (wrong digests): 1 states from a scalar counter, no LDS reads; 2 staging only, no fold
 #endif
