@@ -971,7 +971,7 @@ def test_edge_tables_sorted_by_an_endpoint(gg, orc, order, V, E, rowid):
         g.close()
     finally:
         gg.rank_mode(0)
-        gg.set_edge_rowid(False)
+        gg.set_edge_rowid(True)  # (the session context's default)
 
 
 def test_run_add_ranks_lane_by_lane(tmp_path):
