@@ -804,7 +804,9 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
 
   // status back to the host (the only synchronisation of the build): duplicate check, sentinel
   // vertex, kept-edge count
-  if (!fast)  // (the bucketed build runs no chained scan)
+  // (the bucketed build runs no chained scan; k_gather_rowid still does nothing while the word is set — an earlier
+  // call that failed may have left it — so a build with explicit rowids reports it rather than an unwritten column)
+  if (!fast || csr->eid)
     GG_HIP(hipMemcpyAsync(&st->scan_error, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
   GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, s));
   GG_HIP(hipStreamSynchronize(s));

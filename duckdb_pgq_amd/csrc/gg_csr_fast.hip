@@ -153,11 +153,12 @@ static int lds_order_ok(gg_ctx *ctx, uint32_t *ok) {
     GG_TRY(ctx->dev_alloc((void **)&bad, sizeof(uint32_t)));
     GG_HIP(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(k_lds_order_probe, dim3(256), dim3(512), 0, ctx->stream, 256u, bad);
+    const bool launched = hipGetLastError() == hipSuccess;  // a probe that did not run proves nothing: match masks
     uint32_t h = 1;
     GG_HIP(hipMemcpyAsync(&h, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GG_HIP(hipStreamSynchronize(ctx->stream));
     ctx->dev_free(bad);
-    ctx->rank_mode = h == 0 ? 1 : 2;
+    ctx->rank_mode = launched && h == 0 ? 1 : 2;
   }
   *ok = ctx->rank_mode == 1 ? 1u : 0u;
   return GG_OK;

@@ -161,9 +161,11 @@ struct gg_ctx {
 
   // ---- profiling ----
   bool force_frontier = false;  // gg_debug_force_frontier
+  bool rank_mode_forced = false;  // rank_mode was set by gg_debug_rank_mode, not decided by the probe
   int rank_mode = 0;            // gg_debug_rank_mode: 0 probe the LDS atomic order once, 1 ds_add_rtn ranks, 2 match masks
   bool legacy_build = false;    // gg_debug_force_legacy_build: the multi-pass LSD build (also taken for > 2^22 vertices)
   bool keep_edge_rowid = true;  // gg_ctx_set_edge_rowid
+  uint64_t max_grid_tiles = 0;  // gg_debug_max_grid_tiles: workgroups per expansion launch (0: the hardware bound)
   bool profiling = false;
   std::vector<std::string> prof_names;
   std::vector<uint64_t> prof_launches;

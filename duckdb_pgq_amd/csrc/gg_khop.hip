@@ -26,6 +26,9 @@ using namespace gg;
 namespace gg {
 
 constexpr int XT = 256;  // child positions per tile == threads per workgroup
+// The runtime takes a grid as gridDim.x * blockDim.x threads in 32 bits: at most this many XT-thread workgroups per
+// launch (about 1.3e10 3-hop tile rows; SF100's 12.8 G 2-hop rows are 16.6 M tiles of 768, just below it).
+constexpr uint64_t MAX_GRID_TILES = 0xFFFFFFFFull / XT;
 
 // tile t starts in entry  upper_bound(foff, foff[0] + t*XT) - 1
 template <typename OffT>
@@ -666,14 +669,15 @@ __global__ __launch_bounds__(XT) void k_expand_mid3(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ rnbr, const uint64_t *__restrict__ foff2,
                                                     uint64_t n_entries, uint64_t M2,
                                                     const uint32_t *__restrict__ tile_entry, int emit_mid,
-                                                    unsigned long long *__restrict__ partial) {
+                                                    unsigned long long *__restrict__ partial /* of tile0 */,
+                                                    uint64_t tile0 /* first tile of this launch */) {
   __shared__ MidShared sm;
   __shared__ uint64_t s_foff[MT + 1];
   uint64_t mid_sum = 0, rows_last = 0;
   uint32_t acc[MID_R], corr = 0;
 #pragma unroll
   for (int r = 0; r < MID_R; r++) acc[r] = 0;
-  const uint64_t tile = blockIdx.x, i0 = tile_entry[tile];
+  const uint64_t tile = tile0 + blockIdx.x, i0 = tile_entry[tile];
   for (uint32_t t = threadIdx.x; t <= MT; t += XT) {
     const uint64_t gi = i0 + t;
     s_foff[t] = gi <= n_entries ? foff2[gi] : UINT64_MAX;
@@ -987,8 +991,9 @@ template <typename OffT>
 int make_tiles(gg_ctx *ctx, const OffT *foff, uint64_t n_entries, uint64_t M, uint32_t **tile_entry,
                uint64_t *n_tiles) {
   *n_tiles = (M + XT - 1) / XT;
-  if (*n_tiles > 0x7FFFFFFFull) {
-    set_error("expansion of %llu children exceeds one launch (2^31 tiles)", (unsigned long long)M);
+  if (*n_tiles > MAX_GRID_TILES) {  // (callers hand the runtime n_tiles workgroups of XT threads: see MAX_GRID_TILES)
+    set_error("expansion of %llu children exceeds one launch (%llu tiles)", (unsigned long long)M,
+              (unsigned long long)MAX_GRID_TILES);
     return GG_ERR_TOO_LARGE;
   }
   GG_TRY(ctx->dev_alloc((void **)tile_entry, (*n_tiles ? *n_tiles : 1) * sizeof(uint32_t)));
@@ -1220,8 +1225,8 @@ int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
     partial = nullptr;
     if (M2) {
       const uint64_t n_tiles = (M2 + MT - 1) / MT;
-      if (n_tiles > 0x7FFFFFFFull) {
-        set_error("3-hop expansion over %llu 2-hop rows exceeds one launch (2^31 tiles)", (unsigned long long)M2);
+      if (n_tiles > 0xFFFFFFFFull) {  // tile_entry's tile numbers and the tile-partition grid
+        set_error("3-hop expansion over %llu 2-hop rows exceeds 2^32 tiles", (unsigned long long)M2);
         return GG_ERR_TOO_LARGE;
       }
       uint32_t *tile_entry = nullptr;
@@ -1229,9 +1234,14 @@ int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
       GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
       GG_LAUNCH(ctx, "tile_partition", k_tile_partition_mt, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
                 (const uint64_t *)foff2, E, n_tiles, tile_entry);
-      GG_LAUNCH(ctx, "expand_mid3", k_expand_mid3, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr, csr->roff,
-                csr->rrow, csr->rnbr, (const uint64_t *)foff2, E, M2, (const uint32_t *)tile_entry, (int)(k_min <= 2),
-                partial);
+      const uint64_t per_launch =
+          ctx->max_grid_tiles && ctx->max_grid_tiles < MAX_GRID_TILES ? ctx->max_grid_tiles : MAX_GRID_TILES;
+      for (uint64_t t0 = 0; t0 < n_tiles; t0 += per_launch) {  // (one launch up to 1.3e10 2-hop rows)
+        const uint64_t nt = n_tiles - t0 < per_launch ? n_tiles - t0 : per_launch;
+        GG_LAUNCH(ctx, "expand_mid3", k_expand_mid3, dim3((unsigned)nt), dim3(XT), 0, csr->off, csr->nbr, csr->roff,
+                  csr->rrow, csr->rnbr, (const uint64_t *)foff2, E, M2, (const uint32_t *)tile_entry,
+                  (int)(k_min <= 2), partial + t0 * 4, t0);
+      }
       GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
       GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
       GG_HIP(hipStreamSynchronize(ctx->stream));

@@ -191,6 +191,7 @@ extern "C" int gg_debug_force_frontier(gg_ctx *ctx, int on) {
 extern "C" int gg_debug_rank_mode(gg_ctx *ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) return GG_ERR_INVALID_ARG;
   ctx->rank_mode = mode;
+  ctx->rank_mode_forced = mode != 0;
   return GG_OK;
 }
 
@@ -204,6 +205,29 @@ extern "C" int gg_debug_scan_fault(gg_ctx *ctx, uint32_t spin_limit, uint64_t mu
   if (!ctx) return GG_ERR_INVALID_ARG;
   ctx->scan_spin_limit = spin_limit ? spin_limit : (1u << 24);
   ctx->scan_mute_tile = mute_tile;
+  return GG_OK;
+}
+
+extern "C" int gg_debug_max_grid_tiles(gg_ctx *ctx, uint64_t max_tiles) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  ctx->max_grid_tiles = max_tiles;
+  return GG_OK;
+}
+
+extern "C" int gg_debug_reset(gg_ctx *ctx) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  ctx->force_frontier = false;
+  ctx->legacy_build = false;
+  if (ctx->rank_mode_forced) ctx->rank_mode = 0;  // (a mode the probe decided is kept: it does not change)
+  ctx->rank_mode_forced = false;
+  ctx->scan_spin_limit = 1u << 24;
+  ctx->scan_mute_tile = ~0ull;
+  ctx->max_grid_tiles = 0;
+  ctx->keep_edge_rowid = true;
+  if (ctx->dev_err) {  // a fault-injection test may have left the chained scans' error word set
+    GG_HIP(hipSetDevice(ctx->device));
+    GG_HIP(hipMemsetAsync(ctx->dev_err, 0, sizeof(unsigned long long), ctx->stream));
+  }
   return GG_OK;
 }
 

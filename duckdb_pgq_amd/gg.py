@@ -19,6 +19,7 @@ SYMBOLS = [
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
+    "gg_debug_max_grid_tiles", "gg_debug_reset",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_walk_endpoints", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
@@ -95,6 +96,8 @@ def load_library(path: str | None = None):
     lib.gg_debug_force_legacy_build.argtypes = [P, C.c_int]
     lib.gg_debug_rank_mode.argtypes = [P, C.c_int]
     lib.gg_debug_scan_fault.argtypes = [P, C.c_uint32, u64]
+    lib.gg_debug_max_grid_tiles.argtypes = [P, u64]
+    lib.gg_debug_reset.argtypes = [P]
     lib.gg_result_rows.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_fetch.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
     lib.gg_expand_khop_result.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
@@ -422,6 +425,14 @@ class GG:
 
     def force_legacy_build(self, on: bool):
         self._chk(self.lib.gg_debug_force_legacy_build(self.ctx, int(on)))
+
+    def max_grid_tiles(self, n: int = 0):
+        """Expansion launches of at most n workgroups (0: the hardware bound)."""
+        self._chk(self.lib.gg_debug_max_grid_tiles(self.ctx, int(n)))
+
+    def debug_reset(self):
+        """Every testing knob and the edge-rowid switch back to its default."""
+        self._chk(self.lib.gg_debug_reset(self.ctx))
 
     def khop_partition(self, csr: Csr, n_parts: int):
         b = (C.c_uint64 * (n_parts + 1))()

@@ -88,9 +88,11 @@ struct PhaseTimer {
 //     rules and table functions read the tables, in the statement's own transaction, like the joins they replace;
 //   - a transaction that has changed anything (Transaction::ChangesMade: local appends, updates, deletes)
 //     neither creates nor uses pinned graphs;
-//   - an INSERT, DELETE or UPDATE planned on a pinned table — by any connection of this process, committed or
-//     not — drops the pins on it (gg_plan_hook.c observes the three CreatePlan overloads; without the shim there
-//     are no planner rules either, only the table functions);
+//   - an INSERT, DELETE or UPDATE planned OR executed on a pinned table — by any connection of this process,
+//     committed or not — drops the pins on it (gg_plan_hook.c observes the three CreatePlan overloads, and the
+//     BuildPipelines rule of gg_pipeline.cpp sees every plan the executor is about to run, so a statement
+//     prepared before the pin drops it when it is executed; without the shim there are no planner rules either,
+//     only the table functions);
 //   - a changed row count (appends by other means) drops the pin as well.
 // What remains is the caller's business and is documented in INTEGRATION.md: a graph pinned while another
 // connection holds an uncommitted change does not see that change when it commits — unpin before such work.

@@ -39,6 +39,9 @@
 #undef private
 #include "duckdb/execution/operator/helper/physical_execute.hpp"
 #include "duckdb/execution/operator/join/physical_delim_join.hpp"
+#include "duckdb/execution/operator/persistent/physical_delete.hpp"
+#include "duckdb/execution/operator/persistent/physical_insert.hpp"
+#include "duckdb/execution/operator/persistent/physical_update.hpp"
 
 #include "gg_extension.hpp"
 #include "gg_operators.hpp"
@@ -244,6 +247,9 @@ unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<Log
 // the sinks' pipelines under the pipelines that ended up reading from a graph scan.
 using build_pipelines_fn = void (*)(void *, void *, void *);
 
+//! The graph scans of a plan that is about to be EXECUTED — and, on the way, the tables it is about to write:
+//! every execution passes here (Executor::Initialize), also of statements prepared long ago, which the observers
+//! of the CreatePlan overloads (gg_plan_rule.cpp, WriteObserver) never see again.
 static void CollectGraphScans(PhysicalOperator *op, vector<PhysicalGGGraphScan *> &scans,
                               vector<PhysicalRecursiveCTE *> &ctes) {
 	if (!op) {
@@ -265,6 +271,17 @@ static void CollectGraphScans(PhysicalOperator *op, vector<PhysicalGGGraphScan *
 		break;
 	case PhysicalOperatorType::RECURSIVE_CTE:
 		ctes.push_back((PhysicalRecursiveCTE *)op);
+		break;
+	case PhysicalOperatorType::INSERT:
+		if (((PhysicalInsert &)*op).table) {
+			GGDropPinsOfTable(((PhysicalInsert &)*op).table->oid);
+		}
+		break;
+	case PhysicalOperatorType::DELETE_OPERATOR:
+		GGDropPinsOfTable(((PhysicalDelete &)*op).tableref.oid);
+		break;
+	case PhysicalOperatorType::UPDATE:
+		GGDropPinsOfTable(((PhysicalUpdate &)*op).tableref.oid);
 		break;
 	default:
 		break;
@@ -311,24 +328,55 @@ static int GGBuildPipelinesRule(void *executor_p, void *op_p, void *current_p) {
 	for (auto &entry : executor.child_pipelines) {
 		lists.push_back(&entry.second);
 	}
-	for (auto cte : ctes) {
-		lists.push_back(&cte->pipelines);
-	}
 	for (auto list : lists) {
 		for (auto &pipeline : *list) {
 			all.push_back(pipeline.get());
 		}
 	}
+	// the pipelines of a recursive arm are not part of the main schedule: PhysicalRecursiveCTE resets and re-runs them
+	// per iteration through Executor::ReschedulePipelines, whose event map holds only those pipelines
+	// (executor.cpp:140-170: a dependency on anything else is dereferenced unchecked)
+	vector<std::pair<Pipeline *, PhysicalRecursiveCTE *>> inner;
+	for (auto cte : ctes) {
+		for (auto &pipeline : cte->pipelines) {
+			inner.emplace_back(pipeline.get(), cte);
+		}
+	}
 	vector<shared_ptr<Pipeline>> added;
 	for (auto scan : scans) {
 		vector<Pipeline *> readers;
+		PhysicalRecursiveCTE *inside = nullptr;
 		for (auto pipeline : all) {
 			if (pipeline->source == scan) {
 				readers.push_back(pipeline);
 			}
 		}
-		if (readers.size() != 1) {
+		for (auto &entry : inner) {
+			if (entry.first->source == scan) {
+				readers.push_back(entry.first);
+				inside = entry.second;
+			}
+		}
+		// (a prepared plan that is executed again still carries the recursive arm's pipelines of its earlier
+		// executions — the reference never clears PhysicalRecursiveCTE::pipelines, executor.cpp:470,503 — so several
+		// inner pipelines may name the scan as their source; outside a recursive arm there is exactly one reader)
+		if (readers.empty() || (!inside && readers.size() != 1)) {
 			throw InternalException(scan->GetName() + ": expected one pipeline to read from the scan");
+		}
+		if (inside) {
+			// A scan in the recursive arm: the graph is invariant over the iterations, so its sinks run ONCE, in the main
+			// schedule, before the pipelines that pull from the CTE (the recursion runs inside that source's GetData,
+			// physical_recursive_cte.cpp:48-93); the inner reader gets no dependency and finds the graph kept
+			readers.clear();
+			for (auto pipeline : all) {
+				if (pipeline->source == inside) {
+					readers.push_back(pipeline);
+				}
+			}
+			if (readers.empty()) {
+				throw InternalException(scan->GetName() + ": no pipeline reads from the recursive CTE around the scan");
+			}
+			scan->keep_graph = true;
 		}
 		shared_ptr<Pipeline> previous;
 		for (auto &child : scan->children) {
@@ -338,7 +386,10 @@ static int GGBuildPipelinesRule(void *executor_p, void *op_p, void *current_p) {
 			if (previous) {
 				pipeline->AddDependency(previous);
 			}
-			readers[0]->AddDependency(pipeline);
+			for (auto reader : readers) {
+				reader->AddDependency(pipeline);
+			}
+			// (a sink's child is a table scan: its own traversal never meets the recursive CTE)
 			build(executor_p, child->children[0].get(), pipeline.get());
 			added.push_back(pipeline);
 			previous = pipeline;

@@ -282,6 +282,13 @@ int gg_debug_rank_mode(gg_ctx *ctx, int mode);
  * fail with GG_ERR_HIP instead of returning a wrong result.  spin_limit 0 and mute_tile UINT64_MAX restore
  * normal operation. */
 int gg_debug_scan_fault(gg_ctx *ctx, uint32_t spin_limit, uint64_t mute_tile);
+/* Testing knob: the expansion kernels split their grids into launches of at most `max_tiles` workgroups (the
+ * runtime takes gridDim.x * blockDim.x in 32 bits, so a 3-hop expansion over more than ~1.3e10 2-hop rows runs
+ * as several launches); 0 restores the hardware bound.  Results must not depend on it. */
+int gg_debug_max_grid_tiles(gg_ctx *ctx, uint64_t max_tiles);
+/* Every testing knob above and gg_ctx_set_edge_rowid back to its default (a test suite that shares one context
+ * calls this between tests). */
+int gg_debug_reset(gg_ctx *ctx);
 
 int gg_profile_enable(gg_ctx *ctx, int on);
 /* Time only the kernels named in the comma-separated list (NULL: every kernel).  Two event records per

@@ -20,10 +20,23 @@ def orc():
 
 
 @pytest.fixture(scope="session")
-def gg():
+def _gg_session():
     """One gg_ctx on cuda:0 for the whole GPU session (fails loudly if libgg.so is missing)."""
     import duckdb_pgq_amd as pkg
 
     g = pkg.GG(0)
     yield g
     g.close()
+
+
+@pytest.fixture
+def gg(_gg_session):
+    """The session's context with every knob at its default: whatever a test switched (edge rowids, rank mode,
+    forced builds, scan faults, launch splitting, profiling) and whatever it left staged is undone after it,
+    also when it failed — a test must not depend on the tests that ran before it."""
+    g = _gg_session
+    g.debug_reset()
+    yield g
+    g.debug_reset()
+    g.profile(False)
+    g.staging_clear()

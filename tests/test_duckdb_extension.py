@@ -545,6 +545,19 @@ def test_pinned_graphs_are_opt_in_and_never_outlive_a_write(db):
         d.execute("INSERT INTO other VALUES (2)")
         assert pins() == 1 and np.array_equal(d.execute(sql), keep)
         d.execute("ROLLBACK")
+        # 4b. statements PREPARED before the pin and executed after it never pass the planner again: the pins go when
+        # the executor builds the pipelines of a plan with an INSERT / DELETE / UPDATE operator (gg_pipeline.cpp)
+        d.execute("PREPARE del_pw AS DELETE FROM pw WHERE a = %d" % int(vid[21]))
+        d.execute("PREPARE upd_pw AS UPDATE pw SET b = %d WHERE a = %d" % (int(vid[22]), int(vid[23])))
+        d.execute("PREPARE ins_pw AS INSERT INTO pw VALUES (%d, %d)" % (int(vid[24]), int(vid[25])))
+        for stmt in ("del_pw", "upd_pw", "ins_pw"):
+            d.execute(pin)
+            assert pins() == 1 and np.array_equal(d.execute(sql), cpu()) and pins() == 1
+            d.execute("EXECUTE " + stmt)
+            assert pins() == 0, stmt
+            assert np.array_equal(d.execute(sql), cpu()), stmt
+        for stmt in ("del_pw", "upd_pw", "ins_pw"):
+            d.execute("DEALLOCATE " + stmt)
         # 5. another connection has its own switches: no pragma, no substituted plan
         c = d.connect()
         assert "GG_" not in c.explain(sql)
@@ -654,6 +667,38 @@ def test_pipeline_sinks_inside_a_plan_with_a_recursive_cte(db):
             d.execute("PRAGMA disable_gpu_graph")
         assert "GG_PATH" in plan and "GG_EDGE_SINK" in plan, plan
         assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu) and np.array_equal(cpu, again), sql
+
+
+@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+def test_a_substituted_scan_in_the_recursive_arm_of_a_cte(db):
+    """A count / a join chain taken over INSIDE the recursive arm (a scalar subquery, an IN subquery): the pipelines
+    of that arm are re-run per iteration by Executor::ReschedulePipelines, outside the main schedule, so the graph's
+    sinks must run once before the pipeline that pulls from the CTE — not as dependencies of the inner reader
+    (src/parallel/executor.cpp:140-170 dereferences such a dependency unchecked)."""
+    d, vid = db
+    s = int(vid[3])
+    scalar = ("WITH RECURSIVE up(n) AS (SELECT 1 UNION SELECT n + 1 FROM up WHERE n < 6 AND n < "
+              "(SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id)) "
+              "SELECT count(*), max(n) FROM up")
+    semi = ("WITH RECURSIVE reach(x, hop) AS ("
+            f"SELECT {s}::BIGINT, 0 UNION SELECT k.k_person2id, r.hop + 1 FROM reach r, knows k "
+            "WHERE r.x = k.k_person1id AND r.hop < 3 AND k.k_person2id IN "
+            f"(SELECT k2.k_person2id FROM knows k1, knows k2 WHERE k1.k_person1id = {s} AND k1.k_person2id = k2.k_person1id)) "
+            "SELECT count(*), sum(x % 1000), max(hop) FROM reach")
+    for sql in (scalar, semi):
+        d.execute("PRAGMA disable_gpu_graph")
+        cpu = d.execute(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        try:
+            plan = d.explain(sql)
+            gpu = d.execute(sql)
+            again = d.execute(sql)
+        finally:
+            d.execute("PRAGMA disable_gpu_graph")
+        assert "GG_PATH" in plan and "GG_EDGE_SINK" in plan and "REC_CTE" in plan, plan
+        assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu) and np.array_equal(cpu, again), sql
+    # (no prepared form here: the reference itself crashes on the second EXECUTE of a prepared recursive CTE with a
+    # sink in its recursive arm — PhysicalRecursiveCTE::pipelines keeps the pipelines of the first execution)
 
 
 @pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")

@@ -34,14 +34,26 @@ def test_sf10_two_hop_and_bfs_against_oracle(gg, orc):
     g.close()
 
 
-def test_sf100_size_independent_properties(gg):
-    """configs[3] size (SF100, 12.8 G walks), checked through properties that need no oracle run:
-    product kernel == frontier kernels; ownership shards add up to the whole; rebuilding gives the same bits."""
+def test_sf100_against_the_oracle_and_size_independent_properties(gg, orc):
+    """configs[2] / configs[3] size (SF100, 12.8 G walks): the 2-hop counts, digests and traversed edges and one
+    64-source BFS batch to fixpoint against the C oracle's CSR formulation on the same tables (a few seconds of
+    host time), then properties that need no oracle run: product kernel == frontier kernels; ownership shards
+    add up to the whole; rebuilding gives the same bits."""
     vid, src, dst = datagen.ldbc("sf100")
     stage(gg, vid, src, dst)
     csr = gg.build_csr()
     whole = gg.expand_khop(csr, 1, 2)
     assert whole["rows"][1] == csr.E and whole["traversed_edges"] == whole["rows"][1] + whole["rows"][2]
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0
+    assert whole == g.khop(1, 2)
+    assert whole["rows"][2] > 12 * 10**9
+    batch = datagen.pick_sources(vid, 64, 5)
+    dist, st = gg.bfs64(csr, batch, -1)
+    o_dist, o_st = g.bfs64(g.lookup(batch), -1)
+    assert np.array_equal(dist, o_dist) and st == o_st
+    del dist, o_dist
+    g.close()
     gg.force_frontier(True)
     try:
         assert gg.expand_khop(csr, 1, 2) == whole
@@ -69,6 +81,29 @@ def test_sf100_size_independent_properties(gg):
     dist, st = gg.bfs64(csr2, sources, -1, targets=sources)
     assert np.array_equal(dist, dist.T) and st["levels"] >= 3
     csr2.close()
+
+
+def test_three_hop_product_kernel_against_the_oracle_at_a_million_edges(gg, orc):
+    """k_expand_mid3 against the oracle's streaming depth-first count (orc_khop_csr enumerates the join chain's
+    walks without storing them) where the frontier kernels are not the yardstick: 1.18 M edge rows, 45 G walks,
+    counts, digests and traversed edges of every level for k_min 1..3 — also with the launch split into grids of a
+    few thousand workgroups (gg_debug_max_grid_tiles: what a result beyond 2^32 threads per grid takes)."""
+    vid, src, dst = datagen.ldbc_knows(40_000, 1_200_000, 0x3A0)
+    stage(gg, vid, src, dst)
+    csr = gg.build_csr()
+    rc, g = orc.csr_build(vid, src, dst)
+    assert rc == 0 and csr.E > 1_000_000
+    for kmin in (1, 2, 3):
+        want = g.khop(kmin, 3)
+        assert gg.expand_khop(csr, kmin, 3) == want, kmin
+        gg.max_grid_tiles(4099)
+        try:
+            assert gg.expand_khop(csr, kmin, 3) == want, kmin
+        finally:
+            gg.max_grid_tiles(0)
+    assert want["rows"][3] > 4 * 10**10
+    csr.close()
+    g.close()
 
 
 def test_sf10_three_hop_product_kernel_equals_frontier_kernels(gg):
