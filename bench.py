@@ -129,9 +129,11 @@ def cpu_baseline(vid, src, dst, V, want_seconds=6.0, with_reference=True):
 
         # two calibration points -> fixed cost (hash-table builds over all of knows) + slope
         S1, S2 = max(1, E // 512), max(2, E // 128)
+        cal = None
         if calibrate:
             _, _, ta = run(S1)
             _, _, tb = run(S2)
+            cal = (S1, ta, S2, tb)
             slope = max((tb - ta) / (S2 - S1), 1e-9)
             fixed = max(ta - slope * S1, 0.0)
             S = int(min(E, max(S2, (seconds - fixed) / slope))) if seconds > fixed else S2
@@ -142,12 +144,19 @@ def cpu_baseline(vid, src, dst, V, want_seconds=6.0, with_reference=True):
             c1, c2, tt = run(S)
             times.append(tt)
             counts = (c1, c2)
-        return S, counts, times, fixed, t_load
+        return S, counts, times, fixed, t_load, cal
 
-    S, (c1, c2), times, fixed, t_load = leg(cores, want_seconds)
+    S, (c1, c2), times, fixed, t_load, cal = leg(cores, want_seconds)
     r1, r2 = sample_counts(S)
     hot = statistics.median(times[1:])
-    S1t, (d1, d2), times1, fixed1, _ = leg(1, want_seconds, hot_runs=2, calibrate=False)
+    S1t, (d1, d2), times1, fixed1, _, _ = leg(1, want_seconds, hot_runs=2, calibrate=False)
+    # marginal rate: traversed edges per second of PROBING, from the two calibration samples (their fixed part — the
+    # hash-table builds over all of knows — cancels in the difference), and what the full workload would take at it
+    (Sa, ta, Sb, tb) = cal
+    te_a, te_b = sum(sample_counts(Sa)), sum(sample_counts(Sb))
+    marginal = (te_b - te_a) / max(tb - ta, 1e-9)
+    te_full = int(out["oracle_stats"]["traversed_edges"])
+    full_estimate = fixed + te_full / max(marginal, 1.0)
     db.close()
     q1, q2 = sample_counts(S1t)
     hot1 = statistics.median(times1[1:])
@@ -160,6 +169,11 @@ def cpu_baseline(vid, src, dst, V, want_seconds=6.0, with_reference=True):
                    f"join chains restricted to the first {S} of {E} knows rows as first-hop edges: TE={r1 + r2} per run "
                    f"(its hash-table builds over all knows rows included, ~{fixed:.1f}s; table load {t_load:.1f}s excluded)"),
         "counts_match_oracle": bool(c1 == r1 and c2 == r2),
+        "marginal_value": marginal,
+        "marginal_note": (f"slope between two samples ({Sa} and {Sb} first-hop rows: TE {te_a} in {ta:.2f}s, {te_b} in {tb:.2f}s): "
+                          "traversed edges per second of probing once the hash tables are built"),
+        "full_workload_estimate_s": full_estimate,
+        "full_workload_note": f"fixed {fixed:.1f}s (hash-table builds) + {te_full} traversed edges at the marginal rate; not run",
         "threads_1": {"value": (q1 + q2) / hot1, "unit": "traversed edges/s", "cores": 1, "median_hot_s": hot1,
                       "cold_s": times1[0],
                       "hot_s": times1[1:],
@@ -242,21 +256,16 @@ def extra_materialised(pkg, orc, device):
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": written / (k[1] * 1e-3) / HBM_PEAK,
                            "traffic": None, "avg_launch_ms": k[1] / k[0],
                            "note": "bytes actually written by the kernel (rows x 3 x 8) over its time"}
-    # parity: row count against the oracle's join count; sampled 1024-row slices must be walks of the graph
+    # parity over ALL rows: the digest of what was written (gg_result_digest maps every id of every row back to its
+    # dense index and sums the row hashes) against the count-mode expansion's and the oracle's digest of the same walks
     rc, g = orc.csr_build(vid, src, dst)
     ost = g.khop(2, 2)
-    off, nbr, _, ovid = g.arrays()
-    ok = rows == ost["rows"][2]
-    order = np.argsort(ovid, kind="stable")
-    sv = ovid[order]
-    for o in np.linspace(0, max(rows - 1024, 0), 9).astype(np.int64):
-        sl = res.fetch(2, int(o))
-        d = order[np.searchsorted(sv, sl)]  # dense indices of the three columns
-        for a, b in ((0, 1), (1, 2)):
-            for u, v in zip(d[::97, a], d[::97, b]):
-                ok = ok and bool(np.any(nbr[off[u]:off[u + 1]] == v))
-    out["parity"] = bool(ok)
-    out["parity_note"] = "row count == oracle join count; every 97th row of 9 sampled 1024-row slices is a walk of the oracle's CSR"
+    n_dig, dig = res.digest(csr, 2)
+    counted = gg.expand_khop(csr, 2, 2)
+    out["parity"] = bool(rows == ost["rows"][2] == n_dig == counted["rows"][2] and
+                         dig == ost["digest"][2] == counted["digest"][2])
+    out["parity_note"] = ("rows and digest over all materialised rows (device-side, from the id columns in HBM) == "
+                          "count-mode expansion == oracle")
     res.close()
     g.close()
     csr.close()
@@ -335,7 +344,10 @@ def main():
     device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (WORLD_SIZE is set): the process group exists even for ONE rank, so that a
+    # one-GPU box can run the RCCL calls of the N > 1 path (tests/test_multirank_gpu.py); plain `python bench.py`
+    # — the driver's N = 1 run — has no group and no collective
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -549,7 +561,8 @@ def main():
             "data": "synthetic (seeded LDBC-shaped person/knows, duckdb_pgq_amd/datagen.py)",
             "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build (no edge-rowid payload) + 2-hop expansion (count + digest)",
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
-                       "traversed_edges": int(te_total), "parallelism": f"vertex-ownership shards x{world} (edge table hash-partitioned by endpoint owner, vertex table replicated, CSR + expansion sharded, no data-path collective)"},
+                       "traversed_edges": int(te_total),
+                       "collective_backend": dist.get_backend() if dist is not None else None, "parallelism": f"vertex-ownership shards x{world} (edge table hash-partitioned by endpoint owner, vertex table replicated, CSR + expansion sharded, no data-path collective)"},
             "roofline": roof,
             "roofline_kernels": recs,
             "roofline_phases": phases,

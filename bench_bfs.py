@@ -99,7 +99,8 @@ def graph_sharded(args, pkg, sharding, gg, device, dist, rank, world, vid, src, 
         print(json.dumps({"metric": "64-source bitset BFS, graph-sharded (one BFS over all ranks)", "workload": args.workload,
                           "n_gpus": world, "batches": args.batches, "ms_per_batch": dt / args.batches * 1e3,
                           "levels_per_batch": lv / args.batches, "reached_pairs_per_batch": pairs / args.batches,
-                          "exchange": "all-reduce(SUM) of 8*V bytes per level" if world > 1 else "none",
+                          "exchange": "all-reduce(SUM) of 8*V bytes per level" if dist is not None else "none",
+                          "collective_backend": dist.get_backend() if dist is not None else None,
                           "rows_match_whole_graph_bfs": ok}))
     shard.close()
     gg.close()
@@ -123,19 +124,24 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:  # under torch.distributed.run, also with ONE rank (RCCL on one GPU)
         import torch
         import torch.distributed as dist
 
         # GG_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
         rehearsal = os.environ.get("GG_BENCH_BACKEND", "nccl") != "nccl"
-        torch.cuda.set_device(0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(os.environ.get("GG_BENCH_BACKEND", "nccl"))
+        local_dev = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group(os.environ["GG_BENCH_BACKEND"])
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
 
     vid, src, dst = pkg.datagen.ldbc(args.workload)
     backend = os.environ.get("GG_BENCH_BACKEND", "nccl")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = (local if backend == "nccl" else 0) if world > 1 else 0
+    device = (local if backend == "nccl" else 0) if dist is not None else 0
     gg = pkg.GG(device)
     if args.graph_sharded:
         graph_sharded(args, pkg, sharding, gg, device, dist, rank, world, vid, src, dst)
@@ -177,6 +183,7 @@ def main():
     line = {
         "metric": "traversed edges/sec, 64-source bitset BFS (shortest path)", "workload": args.workload,
         "n_gpus": world, "scaling": "weak", "batches_per_gpu": args.batches, "max_hops": args.max_hops,
+        "collective_backend": dist.get_backend() if dist is not None else None,
         "value": te_job / dt, "unit": "traversed edges/s",
         "ms_per_batch": dt / args.batches * 1e3, "levels_per_batch": lv / args.batches,
         "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -100,8 +100,9 @@ struct FastGeom {
   uint32_t low;       // vertex-in-bucket bits
   uint32_t hb;        // bucket bits (key_bits - low)
   uint32_t pack;      // 1: B's input is one u32 word low(key) << key_bits | payload
-  uint32_t sub;       // low = (sub, leaf): sub-bucket bits (<= 6) ...
+  uint32_t sub;       // low = (sub, leaf): sub-bucket bits (<= FB_MAX_SUB) ...
   uint32_t leaf;      // ... and vertex-in-leaf bits (<= 6)
+  uint32_t ss;        // row stride of the per-chunk / per-bucket sub-bucket offset tables: 65, or 129 with 7 sub bits
   uint32_t part;      // shard builds (gg_csr_build_shard): forward rows of owned sources, reverse rows of owned
   uint32_t n_parts;   // destinations only; 1: whole graph
   uint32_t rank_atomic;  // 1: stable ranks straight from ds_add_rtn (lds_order_ok), 0: from match masks
@@ -166,7 +167,14 @@ static int lds_order_ok(gg_ctx *ctx, uint32_t *ok) {
 
 // ---- D: densify + per-tile bucket histograms of both directions ---------------------------------------------
 // counts[tile * 2 nb + dir * nb + bucket]: tile-major, one contiguous 2 nb row per tile
-template <int MODE>
+// Two-pass form (PASS 1, then PASS 2) for packed dictionaries that do not fit an XCD's 4 MiB L2: random 16-byte
+// probes run at 262 G/s chip-wide while their table stays in L2 and at 120 G/s once it is twice the L2
+// (scripts/ubench_gather.hip, profiles/r03_ubench_gather.txt), so pass 1 resolves only the endpoints whose home
+// pair lies in the LOWER half of the table and marks the others FB_UNRES in the dense pair, and pass 2 resolves
+// those against the upper half — each pass touches half the table — and finishes the rows (drop, ownership marks,
+// histograms).  PASS 0 is the single pass (direct and 16-byte dictionaries, small tables).
+constexpr uint32_t FB_UNRES = 0xFFFFFFFEu;  // endpoint left to pass 2 (dense indices stay below 2^22)
+template <int MODE, int PASS = 0>
 __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                              uint64_t E, uint64_t base, const HtSlot *__restrict__ ht, uint64_t cap,
                                              int64_t min_idx, const uint32_t *__restrict__ dir,
@@ -207,17 +215,34 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
     } else if (MODE == DICT_PACKED8) {
       uint64_t hs[B], hd[B], ts[B], td[B];
       uint4 rs[B], rd[B];
+      bool ns[B], nd[B];  // this pass probes the endpoint
+      u32x2 prev[B];
 #pragma unroll
       for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
+        const uint64_t e = base + (uint64_t)(it0 + j) * FB_THREADS + threadIdx.x;
         pk.locate(ks[j], &hs[j], &ts[j]);
         pk.locate(kd[j], &hd[j], &td[j]);
-        rs[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hs[j]]);
-        rd[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hd[j]]);
+        ns[j] = nd[j] = true;
+        if (PASS == 1) {  // lower half of the table only
+          ns[j] = (hs[j] >> (pk.q - 1)) == 0;
+          nd[j] = (hd[j] >> (pk.q - 1)) == 0;
+        }
+        if (PASS == 2) {  // what pass 1 left
+          prev[j].x = prev[j].y = INVALID_U32;
+          if (e < E) prev[j] = ld_stream(pairs + e);
+          ns[j] = prev[j].x == FB_UNRES;
+          nd[j] = prev[j].y == FB_UNRES;
+        }
+        rs[j] = rd[j] = make_uint4(0, 0, 0, 0);
+        if (ns[j]) rs[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hs[j]]);
+        if (nd[j]) rd[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hd[j]]);
       }
 #pragma unroll
       for (int j = 0; j < B; j++) {
-        us[j] = packed_resolve(tab, pk, ks[j] >= min_id && ks[j] <= max_id, hs[j], ts[j], rs[j]);
-        vs[j] = packed_resolve(tab, pk, kd[j] >= min_id && kd[j] <= max_id, hd[j], td[j], rd[j]);
+        us[j] = PASS == 2 ? prev[j].x : FB_UNRES;
+        vs[j] = PASS == 2 ? prev[j].y : FB_UNRES;
+        if (ns[j]) us[j] = packed_resolve(tab, pk, ks[j] >= min_id && ks[j] <= max_id, hs[j], ts[j], rs[j]);
+        if (nd[j]) vs[j] = packed_resolve(tab, pk, kd[j] >= min_id && kd[j] <= max_id, hd[j], td[j], rd[j]);
       }
     } else {
       uint64_t ss[B], sd[B];
@@ -240,6 +265,13 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
       const uint64_t e = base + (uint64_t)(it0 + j) * FB_THREADS + threadIdx.x;
       if (e >= E) continue;
       uint32_t u = us[j], v = vs[j];
+      if (PASS == 1) {  // half-resolved pair; pass 2 finishes the row
+        u32x2 pr;
+        pr.x = u;
+        pr.y = v;
+        st_stream(pairs + e, pr);
+        continue;
+      }
       if (u == INVALID_U32 || v == INVALID_U32) {
         u = INVALID_U32;  // dropped: an endpoint is not a vertex (inner-join semantics)
         v = INVALID_U32;
@@ -271,7 +303,7 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
 #else
 #define GG_FB_DATTR
 #endif
-template <bool PROBE = false>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
+template <bool PROBE = false, int PASS = 0>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
 __global__ __launch_bounds__(FB_THREADS) GG_FB_DATTR void k_densify_pairs(
     const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
     uint64_t cap, const BuildStatus *__restrict__ st, const uint32_t *__restrict__ dir,
@@ -279,11 +311,20 @@ __global__ __launch_bounds__(FB_THREADS) GG_FB_DATTR void k_densify_pairs(
     FastGeom g, uint64_t nblocks, uint32_t *__restrict__ counts) {
   __shared__ uint32_t hist[2 << FB_MAX_HB];
   const uint32_t nb = 1u << g.hb;
+  const unsigned long long mode = PROBE ? 99ULL : dm->mode;  // uniform over the grid
+  const uint64_t base = (uint64_t)blockIdx.x * FB_TILE;
+  if (PASS == 1) {  // (only a packed table is probed half by half: otherwise pass 2 is the single pass)
+    if (mode == DICT_PACKED8)
+      densify_tile<DICT_PACKED8, 1>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part,
+                                    g.n_parts, hist, hist + nb);
+    return;
+  }
   for (uint32_t i = threadIdx.x; i < 2 * nb; i += FB_THREADS) hist[i] = 0;
   __syncthreads();
-  const uint64_t base = (uint64_t)blockIdx.x * FB_TILE;
-  const unsigned long long mode = PROBE ? 99ULL : dm->mode;  // uniform over the grid
-  if (PROBE)
+  if (PASS == 2 && mode == DICT_PACKED8)
+    densify_tile<DICT_PACKED8, 2>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part,
+                                  g.n_parts, hist, hist + nb);
+  else if (PROBE)
     densify_tile<99>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part, g.n_parts, hist,
                           hist + nb);
   else if (mode == DICT_DIRECT)
@@ -522,8 +563,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
 #define GG_FB_CAPW 1536  // entries of a wave's LDS stage in k_leaf_rows (halved when edge positions ride along)
 #endif
 #ifndef GG_FB_LEAF_TARGET
-#define GG_FB_LEAF_TARGET 2048  // entries per leaf aimed at: between half of this and this
+#define GG_FB_LEAF_TARGET 1024  // entries per leaf aimed at: between half of this and this
 #endif
+#ifndef GG_FB_MAX_SUB
+#define GG_FB_MAX_SUB 7  // sub-bucket bits: up to 128 sub-buckets per bucket (the chunk sort's lanes then own two each)
+#endif
+constexpr int FB_MAX_SUB = GG_FB_MAX_SUB;
+static_assert(FB_MAX_SUB == 6 || FB_MAX_SUB == 7, "one or two sub-buckets per lane of the chunk sort's scan");
 #ifndef GG_FB_LEAF_WAVES
 #define GG_FB_LEAF_WAVES 1  // (4 leaves per workgroup hold their LDS until the largest is done: 366 us against 349 at SF100)
 #endif
@@ -684,17 +730,55 @@ __global__ __launch_bounds__(1024) void k_col_apply(uint32_t *__restrict__ count
   }
 }
 
+// Wave 0 of a chunk sort: per-sub-bucket counts of the waves (hw[wave][NSUBP]) -> staged-slot cursors, the chunk's
+// row of sub-bucket offsets and its entry count.  Lane l owns sub-buckets l * SPL .. l * SPL + SPL - 1 (SPL = 2
+// with 7 sub-bucket bits); sub-buckets the geometry does not use count nothing and come out as the total.
+template <int SPL>
+__device__ __forceinline__ void sub_cursors(uint32_t *hw, uint32_t *dbase, uint32_t *__restrict__ offs_row, int lane,
+                                            uint32_t *s_n) {
+  constexpr int NSUBP = 64 * SPL;
+  uint32_t cw[SPL][FB_WAVES], tot[SPL], mine = 0;
+#pragma unroll
+  for (int j = 0; j < SPL; j++) {
+    tot[j] = 0;
+#pragma unroll
+    for (int q = 0; q < FB_WAVES; q++) {
+      cw[j][q] = hw[q * NSUBP + lane * SPL + j];
+      tot[j] += cw[j][q];
+    }
+    mine += tot[j];
+  }
+  const uint32_t incl = wave_scan_incl(mine);  // (DPP moves, gg_internal.h)
+  uint32_t run = incl - mine;
+#pragma unroll
+  for (int j = 0; j < SPL; j++) {
+    dbase[lane * SPL + j] = run;
+    offs_row[lane * SPL + j] = run;
+#pragma unroll
+    for (int q = 0; q < FB_WAVES; q++) {
+      hw[q * NSUBP + lane * SPL + j] = run;
+      run += cw[j][q];
+    }
+  }
+  if (lane == 63) {
+    dbase[NSUBP] = incl;
+    offs_row[NSUBP] = incl;
+    *s_n = incl;
+  }
+}
+
 // Chunk-local stable sort by sub-bucket, in place.  Element order in a chunk: wave w owns entries
 // [w * FB_WTILE, (w + 1) * FB_WTILE), 64 consecutive entries per step.
-template <bool PACK, bool ROWID, int STOP = 0>  // STOP: timing probes (GG_FB_PROBES)
+template <bool PACK, bool ROWID, int SPL, int STOP = 0>  // STOP: timing probes (GG_FB_PROBES)
 __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
                                                          uint32_t *__restrict__ epos_f,
                                                          const uint32_t *__restrict__ bstart,
                                                          const uint32_t *__restrict__ cstart,
                                                          const uint4 *__restrict__ part_of, FastGeom g,
-                                                         uint32_t *__restrict__ offs /* [chunk][65] */) {
+                                                         uint32_t *__restrict__ offs /* [chunk][g.ss] */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_n;
+  constexpr int NSUBP = 64 * SPL;
   const uint32_t nb = 1u << g.hb;
   const uint32_t p = blockIdx.x;
   const uint4 chunk = part_of[p];  // (both loads in flight: entries past the last chunk are allocated, not meaningful)
@@ -704,13 +788,14 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
   const bool with_pos = ROWID && dir == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lane_lt = (1ULL << lane) - 1ULL;
-  uint32_t *hw = lds;                         // [FB_WAVES][64] per-wave counts -> cursors (staged slot)
-  uint32_t *dbase = hw + FB_WAVES * 64;       // [65] first staged slot of each sub-bucket
-  uint32_t *xw = dbase + 65;                  // staged words (PACK) or low keys
+  uint32_t *hw = lds;                         // [FB_WAVES][NSUBP] per-wave counts -> cursors (staged slot)
+  uint32_t *dbase = hw + FB_WAVES * NSUBP;    // [NSUBP + 1] first staged slot of each sub-bucket
+  uint32_t *xw = dbase + NSUBP + 1;           // staged words (PACK) or low keys
   uint32_t *xp = xw + FB_TILE;                // staged payloads (!PACK)
   uint32_t *xe = PACK ? xp : xp + FB_TILE;    // staged edge positions (ROWID)
-  uint32_t *myh = hw + wave * 64;
-  myh[lane] = 0;
+  uint32_t *myh = hw + wave * NSUBP;
+#pragma unroll
+  for (int j = 0; j < SPL; j++) myh[lane + 64 * j] = 0;
 
   uint32_t k[FB_ITEMS], w[FB_ITEMS], ep[FB_ITEMS];
   const uint32_t wbase = c0 + (uint32_t)wave * FB_WTILE;
@@ -754,28 +839,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
       if (k[it] != INVALID_U32) atomicAdd(&myh[k[it] >> g.leaf], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < 64) {  // <= 64 sub-buckets: wave 0 turns the counts into staged-slot cursors
-    uint32_t tot = 0, cw[FB_WAVES];
-#pragma unroll
-    for (int q = 0; q < FB_WAVES; q++) {
-      cw[q] = hw[q * 64 + lane];
-      tot += cw[q];
-    }
-    const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
-    uint32_t run = incl - tot;
-    dbase[lane] = run;
-    offs[(uint64_t)p * 65 + lane] = run;
-#pragma unroll
-    for (int q = 0; q < FB_WAVES; q++) {
-      hw[q * 64 + lane] = run;
-      run += cw[q];
-    }
-    if (lane == 63) {
-      dbase[64] = incl;
-      offs[(uint64_t)p * 65 + 64] = incl;
-      s_n = incl;
-    }
-  }
+  if (threadIdx.x < 64) sub_cursors<SPL>(hw, dbase, offs + (uint64_t)p * g.ss, lane, &s_n);  // wave 0
   __syncthreads();
   if (STOP == 2) return;  // + counts and the scan
   volatile uint32_t *cur = myh;
@@ -840,22 +904,24 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
 // current one.  One chunk per workgroup spends its life in latencies (probe: the loads alone take 105 of the
 // kernel's 195 us at SF100, a third of the HBM rate): header -> entries -> four barrier-separated phases, and 32
 // resident waves per CU do not cover that.
+template <int SPL>
 __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
                                                               const uint32_t *__restrict__ cstart,
                                                               const uint4 *__restrict__ part_of, FastGeom g,
-                                                              uint32_t *__restrict__ offs /* [chunk][65] */) {
+                                                              uint32_t *__restrict__ offs /* [chunk][g.ss] */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_n;
+  constexpr int NSUBP = 64 * SPL;
   const uint32_t nb = 1u << g.hb, G = gridDim.x;
   uint32_t p = blockIdx.x;
   uint4 chunk = part_of[p];  // (entries past the last chunk are allocated, not meaningful)
   const uint32_t nchunks = cstart[2 * nb];
   if (p >= nchunks) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t *hw = lds;                    // [FB_WAVES][64] per-wave counts -> cursors (staged slot)
-  uint32_t *dbase = hw + FB_WAVES * 64;  // [65] first staged slot of each sub-bucket
-  uint32_t *xw = dbase + 65;             // staged words
-  uint32_t *myh = hw + wave * 64;
+  uint32_t *hw = lds;                       // [FB_WAVES][NSUBP] per-wave counts -> cursors (staged slot)
+  uint32_t *dbase = hw + FB_WAVES * NSUBP;  // [NSUBP + 1] first staged slot of each sub-bucket
+  uint32_t *xw = dbase + NSUBP + 1;         // staged words
+  uint32_t *myh = hw + wave * NSUBP;
   const uint32_t mine = (uint32_t)wave * FB_WTILE + lane;  // this lane's first entry inside a chunk
   uint32_t w[FB_ITEMS], wn[FB_ITEMS];
   {
@@ -877,7 +943,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restri
     }
     uint32_t *__restrict__ buf = (chunk.z / nb ? buf_r : buf_f) + chunk.x;
     const uint32_t len = chunk.y - chunk.x;
-    myh[lane] = 0;
+#pragma unroll
+    for (int j = 0; j < SPL; j++) myh[lane + 64 * j] = 0;
     __builtin_amdgcn_wave_barrier();
     const bool runs = wave_has_runs(w[0] >> (g.key_bits + g.leaf), mine < len, lane);  // (see k_partition_dual)
     if (runs) {
@@ -890,28 +957,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restri
         if (mine + it * 64 < len) atomicAdd(&myh[w[it] >> (g.key_bits + g.leaf)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {  // <= 64 sub-buckets: wave 0 turns the counts into staged-slot cursors
-      uint32_t tot = 0, cw[FB_WAVES];
-#pragma unroll
-      for (int q = 0; q < FB_WAVES; q++) {
-        cw[q] = hw[q * 64 + lane];
-        tot += cw[q];
-      }
-      const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
-      uint32_t run = incl - tot;
-      dbase[lane] = run;
-      offs[(uint64_t)p * 65 + lane] = run;
-#pragma unroll
-      for (int q = 0; q < FB_WAVES; q++) {
-        hw[q * 64 + lane] = run;
-        run += cw[q];
-      }
-      if (lane == 63) {
-        dbase[64] = incl;
-        offs[(uint64_t)p * 65 + 64] = incl;
-        s_n = incl;
-      }
-    }
+    if (threadIdx.x < 64) sub_cursors<SPL>(hw, dbase, offs + (uint64_t)p * g.ss, lane, &s_n);  // wave 0
     __syncthreads();
     if (runs) {
 #pragma unroll
@@ -946,7 +992,8 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort_pipe(uint32_t *__restri
   }
 }
 
-// substart[i * 65 + s] = first final position of leaf (bucket i, sub s); [i * 65 + 64] = end of the bucket
+// substart[i * g.ss + s] = first final position of leaf (bucket i, sub s); [i * g.ss + 64 SPL] = end of the bucket
+template <int SPL>
 __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ offs,
                                                    const uint32_t *__restrict__ bstart,
                                                    const uint32_t *__restrict__ cstart, FastGeom g, uint64_t V,
@@ -955,15 +1002,42 @@ __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ 
   const uint32_t nb = 1u << g.hb, i = blockIdx.x, dir = i / nb, j = i % nb;
   const int lane = threadIdx.x;
   const uint32_t p0 = cstart[i], p1 = cstart[i + 1];
-  uint32_t tot = 0;
-  for (uint32_t p = p0; p < p1; p++) tot += offs[(uint64_t)p * 65 + lane + 1] - offs[(uint64_t)p * 65 + lane];
-  const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
+  uint32_t tot[SPL], mine = 0;
+#pragma unroll
+  for (int q = 0; q < SPL; q++) tot[q] = 0;
+  for (uint32_t p = p0; p < p1; p++) {
+    const uint32_t *row = offs + (uint64_t)p * g.ss + lane * SPL;
+#pragma unroll
+    for (int q = 0; q < SPL; q++) tot[q] += row[q + 1] - row[q];
+  }
+#pragma unroll
+  for (int q = 0; q < SPL; q++) mine += tot[q];
+  const uint32_t incl = wave_scan_incl(mine);  // (DPP moves, gg_internal.h)
   const uint32_t b0 = bstart[dir * (nb + 1) + j];
-  substart[(uint64_t)i * 65 + lane] = b0 + incl - tot;
-  if (lane == 63) substart[(uint64_t)i * 65 + 64] = b0 + incl;
+  uint32_t run = b0 + incl - mine;
+#pragma unroll
+  for (int q = 0; q < SPL; q++) {
+    substart[(uint64_t)i * g.ss + lane * SPL + q] = run;
+    run += tot[q];
+  }
+  if (lane == 63) substart[(uint64_t)i * g.ss + 64 * SPL] = b0 + incl;
   // no leaf holds vertex V when V is a multiple of the bucket width: the last bucket closes the offsets
   if (lane == 0 && j == nb - 1 && ((uint64_t)nb << g.low) == V) (dir ? roff : off)[V] = bstart[dir * (nb + 1) + nb];
 }
+
+#ifdef GG_FB_LEAF_STAMPS  // diagnostic build: shader-clock stamps of a leaf's phases (scripts/leaf_stamps.py)
+#define GG_STAMP(k)                                                                        \
+  do {                                                                                     \
+    unsigned long long t_;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if (gg_leaf_stamps && (threadIdx.x & 63) == 0) gg_leaf_stamps[(uint64_t)unit * 8 + (k)] = t_; \
+  } while (0)
+__device__ unsigned long long *gg_leaf_stamps = nullptr;
+#else
+#define GG_STAMP(k)
+#endif
 
 template <bool PACK, bool ROWID>
 __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const uint32_t *__restrict__ buf_f,
@@ -987,12 +1061,13 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
   const uint64_t lane_lt = (1ULL << lane) - 1ULL;
   const uint32_t leaf_mask = leafW - 1u;
   const uint32_t pay_mask = g.key_bits >= 32 ? 0xFFFFFFFFu : (1u << g.key_bits) - 1u;
-  const uint32_t t0 = substart[(uint64_t)i * 65 + s], t1 = substart[(uint64_t)i * 65 + s + 1], n = t1 - t0;
+  const uint32_t t0 = substart[(uint64_t)i * g.ss + s], t1 = substart[(uint64_t)i * g.ss + s + 1], n = t1 - t0;
   const uint32_t b0 = bstart[dir * (nb + 1) + j];
   const uint32_t p0 = cstart[i], nch = cstart[i + 1] - p0;
   const uint64_t vfirst = ((uint64_t)j << g.low) + ((uint64_t)s << g.leaf);  // first vertex of the leaf
   lc[lane] = 0;
   const bool staged = n <= CAPW;  // wave-uniform
+  GG_STAMP(0);  // header loaded
 
   // The leaf's entries: run `s` of every chunk of the bucket, chunk after chunk.  Chunks are taken 64 at a time
   // (lane c holds chunk c's run); a run is walked in 64-entry steps.  pass 0 counts, pass 1 places; when the
@@ -1008,8 +1083,8 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
       const uint32_t c = cg + lane;
       uint32_t so = 0, len = 0;
       if (c < nch) {
-        so = offs[(uint64_t)(p0 + c) * 65 + s];
-        len = offs[(uint64_t)(p0 + c) * 65 + s + 1] - so;
+        so = offs[(uint64_t)(p0 + c) * g.ss + s];
+        len = offs[(uint64_t)(p0 + c) * g.ss + s + 1] - so;
       }
       const uint32_t src = b0 + c * FB_TILE + so;  // position of the run's first entry
       const uint32_t st_c = (len + 63) / 64;       // steps of this run
@@ -1017,6 +1092,7 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
       const uint32_t sexcl = sincl - st_c;
       const uint32_t T = __shfl(sincl, 63, 64);  // steps in this group of chunks
       if (pass == 0) single = nch <= 64 && T <= LEAF_MAXS;
+      if (cg == 0) GG_STAMP(pass == 0 ? 1 : 4);  // run table loaded
       for (uint32_t r = 0; r < T; r += LEAF_MAXS) {
         if (pass == 0 || !single) {
           have = 0;
@@ -1062,6 +1138,7 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
             }
           }
         }
+        if (cg == 0 && r == 0) GG_STAMP(pass == 0 ? 2 : 5);  // first round of entries loaded
         if (pass == 0) {
           if (cg == 0 && r == 0)
             runs = wave_has_runs((PACK ? kw[0] >> g.key_bits : kw[0]) & leaf_mask, have & 1u, lane);
@@ -1130,8 +1207,10 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
       lc[lane] = incl - cnt;
       __builtin_amdgcn_wave_barrier();
       incl_keep = incl;  // (single: the entries are still in registers, pass 1 skips its loads)
+      GG_STAMP(3);  // counted, row offsets written
     }
   }
+  GG_STAMP(6);  // ranked (and staged or written)
   if (staged) {
     // the vertex of staged slot x is the number of runs that end at or before x
     for (uint32_t x0 = 0; x0 < n; x0 += 64) {
@@ -1148,6 +1227,7 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
       }
     }
   }
+  GG_STAMP(7);  // rows written
 }
 
 // One wave per leaf (bucket i, sub-bucket s); LEAF_WAVES leaves per workgroup.
@@ -1179,14 +1259,14 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   int kb = bits_of(V - 1);
   if (kb < 1) kb = 1;
   // Geometry: key = (bucket: hb bits)(sub-bucket: sub bits)(leaf vertex: leaf bits).  A leaf is finished by one
-  // wave, so it should hold about a thousand entries: 2^(hb + sub) ~ entries / 1024..2048, where a shard expects about
-  // half of its local rows per direction.  leaf <= 6 bits (one lane per vertex), sub <= 6, hb <= FB_MAX_HB.
+  // wave, so it should hold some hundreds of entries: 2^(hb + sub) ~ entries / 512..1024, where a shard expects about
+  // half of its local rows per direction.  leaf <= 6 bits (one lane per vertex), sub <= FB_MAX_SUB, hb <= FB_MAX_HB.
   const uint64_t expect = csr->n_parts > 1 ? E / 2 : E;
   int lb = bits_of(expect / GG_FB_LEAF_TARGET);               // log2 of the number of leaves wanted (600-1200 entries each)
   if (lb < kb - 6) lb = kb - 6;                  // leaf <= 6 bits
   if (lb > kb) lb = kb;                          // at most one leaf per vertex
   if (lb < 0) lb = 0;
-  int sub = lb < 6 ? lb : 6;
+  int sub = lb < FB_MAX_SUB ? lb : FB_MAX_SUB;
   int hb = lb - sub;
   if (hb > FB_MAX_HB) return GG_OK;              // more than 2^22 vertices: the multi-pass build
   const int low = kb - hb;
@@ -1196,6 +1276,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   g.pack = (low + kb <= 32) ? 1u : 0u;
   g.sub = (uint32_t)sub;
   g.leaf = (uint32_t)(low - sub);
+  g.ss = sub > 6 ? 129u : 65u;
   g.part = (uint32_t)csr->part;
   g.n_parts = (uint32_t)csr->n_parts;
   GG_TRY(lds_order_ok(ctx, &g.rank_atomic));
@@ -1254,16 +1335,30 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
             ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
             (const DirectMap *)dm, pairs, g, nblocks64, counts);
 #endif
-  GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev, ctx->c_dst.dev, E,
-            csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab, (const DirectMap *)dm,
-            pairs, g, nblocks64, counts);
+#ifndef GG_FB_TWOPASS
+#define GG_FB_TWOPASS 2  // 0: one densification pass; 1: always two; 2: two when the packed table exceeds an XCD's L2
+#endif
+  const bool two_pass = GG_FB_TWOPASS == 1 || (GG_FB_TWOPASS == 2 && 2 * npairs * sizeof(unsigned long long) > (4u << 20) &&
+                                               E >= (1u << 22));
+  if (two_pass) {
+    GG_LAUNCH(ctx, "densify_half", (k_densify_pairs<false, 1>), dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
+              ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
+              (const DirectMap *)dm, pairs, g, nblocks64, counts);
+    GG_LAUNCH(ctx, "densify_pairs", (k_densify_pairs<false, 2>), dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
+              ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
+              (const DirectMap *)dm, pairs, g, nblocks64, counts);
+  } else {
+    GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
+              ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
+              (const DirectMap *)dm, pairs, g, nblocks64, counts);
+  }
   const uint64_t pmax = 2 * (nblocks64 + nb);  // chunks: every bucket may end in a partial one
   uint4 *part_of = nullptr;
   uint32_t *cstart = nullptr, *offs = nullptr, *substart = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&cstart, (2 * nb + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint4)));
-  GG_TRY(ctx->dev_alloc((void **)&offs, pmax * 65 * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * 65 * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&offs, pmax * g.ss * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * g.ss * sizeof(uint32_t)));
   GG_LAUNCH(ctx, "col_partial", k_col_partial, dim3(ngroups), dim3(1024), 0, (const uint32_t *)counts, nblocks64, ncol, gsz,
             partial, coltot);
   GG_LAUNCH(ctx, "col_scan", k_col_scan, dim3(1), dim3(1024), 0, coltot, nb, bstart, cstart, part_of, st);
@@ -1324,26 +1419,34 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
 #undef GG_FB_LAUNCH_A
 
   // ---- B ----------------------------------------------------------------------------------------------------
-  const size_t lds_s = (size_t)(FB_WAVES * 64 + 65 + FB_TILE * (words + (rowid ? 1 : 0))) * sizeof(uint32_t);
+  const size_t lds_s = (size_t)((FB_WAVES + 1) * (g.ss - 1) + 1 + FB_TILE * (words + (rowid ? 1 : 0))) * sizeof(uint32_t);
   const size_t lds_l = (size_t)LEAF_WAVES * (64 + GG_FB_CAPW) * sizeof(uint32_t);
   const unsigned grid_l = (unsigned)((2ull * nb * (1u << g.sub) + LEAF_WAVES - 1) / LEAF_WAVES);
-#define GG_FB_LAUNCH_B(P, R)                                                                                          \
-  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<P, R>),                                         \
+#define GG_FB_LAUNCH_B(P, R, SPL)                                                                                     \
+  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<P, R, SPL>),                                    \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
-  GG_LAUNCH(ctx, "sub_sort", (k_sub_sort<P, R>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, epos_f, \
-            (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);                    \
-  GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,                         \
+  GG_LAUNCH(ctx, "sub_sort", (k_sub_sort<P, R, SPL>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r,    \
+            epos_f, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);               \
+  GG_LAUNCH(ctx, "sub_totals", k_sub_totals<SPL>, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,                    \
             (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);                   \
   GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<P, R>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,                          \
             (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,     \
             (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,     \
             csr->epos, csr->roff, csr->rnbr, csr->rrow)
+#define GG_FB_LAUNCH_B2(P, R)      \
+  do {                             \
+    if (g.sub > 6) {               \
+      GG_FB_LAUNCH_B(P, R, 2);     \
+    } else {                       \
+      GG_FB_LAUNCH_B(P, R, 1);     \
+    }                              \
+  } while (0)
 #ifdef GG_FB_PROBES
-  if (g.pack && !rowid) {
+  if (g.pack && !rowid && g.sub <= 6) {
 #define GG_FB_PROBE_S(N, NAME)                                                                                         \
-  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<true, false, N>),                             \
+  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<true, false, 1, N>),                          \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                 \
-  GG_LAUNCH(ctx, NAME, (k_sub_sort<true, false, N>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r,    \
+  GG_LAUNCH(ctx, NAME, (k_sub_sort<true, false, 1, N>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, \
             epos_f, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint4 *)part_of, g, offs)
     GG_FB_PROBE_S(1, "probe_S_loads");
     GG_FB_PROBE_S(2, "probe_S_counts");
@@ -1352,29 +1455,58 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   }
 #endif
   if (g.pack && rowid) {
-    GG_FB_LAUNCH_B(true, true);
+    GG_FB_LAUNCH_B2(true, true);
   } else if (g.pack && g.rank_atomic && GG_FB_SUBPIPE) {
     const uint64_t resident = (uint64_t)ctx->num_cus * GG_FB_SUBPIPE;
     const unsigned grid_p = (unsigned)(pmax < resident ? pmax : resident);
-    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort_pipe),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    GG_LAUNCH(ctx, "sub_sort", k_sub_sort_pipe, dim3(grid_p), dim3(FB_THREADS), lds_s, part_f, part_r,
-              (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);
-    GG_LAUNCH(ctx, "sub_totals", k_sub_totals, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,
-              (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);
+    if (g.sub > 6) {
+      GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort_pipe<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      GG_LAUNCH(ctx, "sub_sort", k_sub_sort_pipe<2>, dim3(grid_p), dim3(FB_THREADS), lds_s, part_f, part_r,
+                (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);
+      GG_LAUNCH(ctx, "sub_totals", k_sub_totals<2>, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,
+                (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);
+    } else {
+      GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort_pipe<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      GG_LAUNCH(ctx, "sub_sort", k_sub_sort_pipe<1>, dim3(grid_p), dim3(FB_THREADS), lds_s, part_f, part_r,
+                (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);
+      GG_LAUNCH(ctx, "sub_totals", k_sub_totals<1>, dim3(2 * nb), dim3(64), 0, (const uint32_t *)offs,
+                (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, substart, csr->off, csr->roff);
+    }
     GG_LAUNCH(ctx, "leaf_rows", (k_leaf_rows<true, false>), dim3(grid_l), dim3(LEAF_WAVES * 64), lds_l,
               (const uint32_t *)part_f, (const uint32_t *)part_r, (const uint32_t *)epos_f, (const uint32_t *)bstart,
               (const uint32_t *)cstart, (const uint32_t *)offs, (const uint32_t *)substart, g, V, csr->off, csr->nbr,
               csr->epos, csr->roff, csr->rnbr, csr->rrow);
   } else if (g.pack) {
-    GG_FB_LAUNCH_B(true, false);
+    GG_FB_LAUNCH_B2(true, false);
   } else if (rowid) {
-    GG_FB_LAUNCH_B(false, true);
+    GG_FB_LAUNCH_B2(false, true);
   } else {
-    GG_FB_LAUNCH_B(false, false);
+    GG_FB_LAUNCH_B2(false, false);
   }
+#undef GG_FB_LAUNCH_B2
 #undef GG_FB_LAUNCH_B
 
+#ifdef GG_FB_LEAF_STAMPS
+  if (const char *path = getenv("GG_LEAF_STAMPS_FILE")) {  // (the stamps of the build that just ran are of its LAST leaf launch)
+    static unsigned long long *dev = nullptr;
+    const size_t n = (size_t)grid_l * LEAF_WAVES * 8;
+    if (!dev) {
+      GG_HIP(hipMalloc((void **)&dev, n * sizeof(unsigned long long)));
+      GG_HIP(hipMemset(dev, 0, n * sizeof(unsigned long long)));
+      GG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gg_leaf_stamps), &dev, sizeof(dev)));
+    } else {
+      std::vector<unsigned long long> host(n);
+      GG_HIP(hipStreamSynchronize(s));
+      GG_HIP(hipMemcpy(host.data(), dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(path, "wb")) {
+        fwrite(host.data(), sizeof(unsigned long long), n, f);
+        fclose(f);
+      }
+    }
+  }
+#endif
   for (void *p : {(void *)dir, (void *)tab, (void *)pairs, (void *)counts, (void *)bstart, (void *)total,
                   (void *)part_f, (void *)part_r, (void *)epos_f, (void *)cstart, (void *)part_of, (void *)offs,
                   (void *)substart, (void *)partial})

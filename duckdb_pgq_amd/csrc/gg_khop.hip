@@ -1628,6 +1628,74 @@ extern "C" int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, 
   return GG_OK;
 }
 
+// ---- digest of materialised rows ------------------------------------------------------------------------------------
+// Reads the id columns a materialising expansion left in HBM, maps every id back to its dense index through the
+// CSR's id table and sums the low halves of the row hashes (DESIGN.md "Row digest"): the checksum a count-mode
+// expansion of the same walks reports, taken from what was actually WRITTEN.
+__global__ __launch_bounds__(256) void k_result_digest(const int64_t *__restrict__ c0, const int64_t *__restrict__ c1,
+                                                       const int64_t *__restrict__ c2, const int64_t *__restrict__ c3,
+                                                       const int64_t *__restrict__ c4, int hops, uint64_t n,
+                                                       const HtSlot *__restrict__ ht, uint64_t cap, int64_t min_idx,
+                                                       unsigned long long *__restrict__ out /* [2]: digest, bad ids */) {
+  const int64_t *cols[5] = {c0, c1, c2, c3, c4};
+  uint32_t sum = 0, bad = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t P = 0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      if (j <= hops) {
+        const uint32_t d = ht_lookup(ht, cap, min_idx, cols[j][r]);
+        ok = ok && d != INVALID_U32;
+        P = j == 0 ? (uint64_t)d : dig_leaf(dig_q(P, j - 1), d);
+      }
+    }
+    if (ok)
+      sum += (uint32_t)P;
+    else
+      bad++;
+  }
+  sum = wave_total_u32(sum);
+  bad = wave_total_u32(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (sum) atomicAdd(reinterpret_cast<unsigned int *>(&out[0]), sum);  // (mod 2^32: the high half stays zero)
+    if (bad) atomicAdd(&out[1], (unsigned long long)bad);
+  }
+}
+
+extern "C" int gg_result_digest(gg_ctx *ctx, const gg_csr *csr, const gg_result *res, int hops, uint64_t *n_rows,
+                                uint64_t *digest) {
+  if (!ctx || !csr || !res || !digest || res->ctx != ctx || csr->ctx != ctx) return GG_ERR_INVALID_ARG;
+  if (hops < res->k_min || hops > res->k_max || hops < 1 || hops > 4) {
+    set_error("gg_result_digest: hops %d outside the result's range or above 4", hops);
+    return GG_ERR_INVALID_ARG;
+  }
+  ApiScope scope(ctx);
+  GG_HIP(hipSetDevice(ctx->device));
+  GG_TRY(ensure_ht(ctx, const_cast<gg_csr *>(csr)));
+  const uint64_t n = res->rows[hops];
+  unsigned long long *out = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&out, 2 * sizeof(unsigned long long)));
+  GG_HIP(hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  if (n) {
+    const uint64_t want = (n + 255) / 256, cap = (uint64_t)ctx->num_cus * 32;
+    GG_LAUNCH(ctx, "result_digest", k_result_digest, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0,
+              (const int64_t *)res->cols[hops][0], (const int64_t *)res->cols[hops][1],
+              (const int64_t *)res->cols[hops][2], (const int64_t *)res->cols[hops][3],
+              (const int64_t *)res->cols[hops][4], hops, n, (const HtSlot *)csr->ht, csr->ht_cap, csr->ht_min_idx, out);
+  }
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, out, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->dev_free(out);
+  if (ctx->pin_scratch[1]) {
+    set_error("gg_result_digest: %llu rows hold an id that is not a vertex", (unsigned long long)ctx->pin_scratch[1]);
+    return GG_ERR_STATE;
+  }
+  if (n_rows) *n_rows = n;
+  *digest = ctx->pin_scratch[0];
+  return GG_OK;
+}
+
 extern "C" void gg_result_destroy(gg_result *res) {
   if (!res) return;
   gg_ctx *ctx = res->ctx;

@@ -20,7 +20,7 @@ SYMBOLS = [
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_debug_max_grid_tiles", "gg_debug_reset",
-    "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result",
+    "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_walk_endpoints", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
     "gg_bfs_sharded_begin", "gg_bfs_sharded_expand", "gg_bfs_sharded_words", "gg_bfs_sharded_commit",
@@ -106,6 +106,7 @@ def load_library(path: str | None = None):
     lib.gg_vertices_from_edges.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
+    lib.gg_result_digest.argtypes = [P, P, P, C.c_int, C.POINTER(u64), C.POINTER(u64)]
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
     lib.gg_host_alloc.argtypes = [P, u64, C.POINTER(C.c_void_p)]
     lib.gg_host_free.argtypes = [P, C.c_void_p]
@@ -207,6 +208,12 @@ class KhopResult:
         n = C.c_uint64()
         self.gg._chk(self.gg.lib.gg_result_rows(self.handle, h, C.byref(n)))
         return int(n.value)
+
+    def digest(self, csr, h: int):
+        """(rows, digest) of the h-hop rows as they stand in HBM — the figures a count-mode expansion reports."""
+        n, d = C.c_uint64(), C.c_uint64()
+        self.gg._chk(self.gg.lib.gg_result_digest(self.gg.ctx, csr.handle, self.handle, h, C.byref(n), C.byref(d)))
+        return int(n.value), int(d.value)
 
     def fetch(self, h: int, offset: int, max_rows: int = GG_CHUNK_ROWS) -> np.ndarray:
         bufs = [np.empty(GG_CHUNK_ROWS, np.int64) for _ in range(h + 1)]

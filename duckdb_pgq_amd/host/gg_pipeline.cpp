@@ -31,12 +31,16 @@
 #include "duckdb/catalog/catalog_entry/table_catalog_entry.hpp"
 #include "duckdb/storage/data_table.hpp"
 // Executor::BuildPipelines and the pipeline lists it fills are private; the rule below is the body of a case the
-// reference's own member function would hold.  Nothing else in this file touches non-public members.
+// reference's own member function would hold.  Nothing else in this file touches non-public members — and with
+// -DGG_REFERENCE_CALLOUTS (an extension built only for a reference that carries oracle/callout.patch, where that
+// case is the executor's own code) neither the rule nor this access is compiled at all.
+#ifndef GG_REFERENCE_CALLOUTS
 #define private public
 #include "duckdb/execution/executor.hpp"
 #include "duckdb/parallel/pipeline.hpp"
 #include "duckdb/execution/operator/set/physical_recursive_cte.hpp"
 #undef private
+#endif
 #include "duckdb/execution/operator/helper/physical_execute.hpp"
 #include "duckdb/execution/operator/join/physical_delim_join.hpp"
 #include "duckdb/execution/operator/persistent/physical_delete.hpp"
@@ -234,6 +238,7 @@ unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<Log
 	return move(scan);
 }
 
+#ifndef GG_REFERENCE_CALLOUTS
 //===--------------------------------------------------------------------===//
 // The BuildPipelines case
 //===--------------------------------------------------------------------===//
@@ -401,15 +406,33 @@ static int GGBuildPipelinesRule(void *executor_p, void *op_p, void *current_p) {
 	return 1;
 }
 
+#endif // GG_REFERENCE_CALLOUTS
+
 static bool g_pipeline_rule = false;
 
+void GGPipelineSinksNative() {
+	g_pipeline_rule = true;
+}
+
+void GGKeepGraphs(PhysicalOperator &plan) {
+	if (auto scan = dynamic_cast<PhysicalGGGraphScan *>(&plan)) {
+		scan->keep_graph = true;
+		return;
+	}
+	for (auto &child : plan.children) {
+		GGKeepGraphs(*child);
+	}
+}
+
 void GGRegisterPipelineRule() {
+#ifndef GG_REFERENCE_CALLOUTS
 	auto reg = (int (*)(int, gg_plan_rule_fn))dlsym(RTLD_DEFAULT, "gg_plan_hook_register");
 	auto kinds = (int (*)())dlsym(RTLD_DEFAULT, "gg_plan_hook_kinds");
 	if (!reg || !kinds || kinds() <= GG_PLAN_HOOK_PIPELINES || !dlsym(RTLD_DEFAULT, "gg_plan_hook_original")) {
 		return; // no shim, or one built before it knew this hook
 	}
 	g_pipeline_rule = reg(GG_PLAN_HOOK_PIPELINES, GGBuildPipelinesRule) == 0;
+#endif
 }
 
 } // namespace duckdb

@@ -83,6 +83,10 @@ unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<Log
                                              string description, bool parallel_result,
                                              PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality);
 void GGRegisterPipelineRule();
+//! the hosting reference has the BuildPipelines case itself (oracle/callout.patch): pipeline sinks without a rule
+void GGPipelineSinksNative();
+//! every graph scan below `plan` keeps its graph for as long as the plan lives (plans with a recursive CTE)
+void GGKeepGraphs(PhysicalOperator &plan);
 
 } // namespace duckdb
 

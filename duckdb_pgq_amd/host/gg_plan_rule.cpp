@@ -92,6 +92,7 @@
 namespace duckdb {
 
 static std::atomic<uint64_t> g_rules_fired {0};
+static bool g_callouts_registered = false; // rules registered with a patched reference's call-outs (no shim)
 
 namespace {
 
@@ -2135,8 +2136,28 @@ int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 	for (auto table : g_plan_tables) {
 		((PhysicalPlanGenerator *)generator)->dependencies.insert(table);
 	}
+	// planned inside a statement with a recursive CTE (the generator registers the working table before it plans the
+	// CTE's arms, plan_recursive_cte.cpp:14-21): the pipelines of a recursive arm are reset and re-run per iteration,
+	// so a graph scan in there keeps its graph across its source states
+	if (!((PhysicalPlanGenerator *)generator)->rec_ctes.empty()) {
+		GGKeepGraphs(*plan);
+	}
 	new (ret_slot) unique_ptr<PhysicalOperator>(move(plan));
 	return 1;
+}
+
+//! The same rules behind the call-outs of a patched reference (oracle/callout.patch):
+//! unique_ptr<PhysicalOperator> (*)(PhysicalPlanGenerator &, LogicalOperator &), null = not taken over
+template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
+unique_ptr<PhysicalOperator> CalloutEntry(PhysicalPlanGenerator &generator, LogicalOperator &op) {
+	typename std::aligned_storage<sizeof(unique_ptr<PhysicalOperator>), alignof(unique_ptr<PhysicalOperator>)>::type slot;
+	if (!RuleEntry<OP, RULE>(&slot, &generator, &op)) {
+		return nullptr;
+	}
+	auto made = reinterpret_cast<unique_ptr<PhysicalOperator> *>(&slot);
+	auto plan = move(*made);
+	made->~unique_ptr<PhysicalOperator>();
+	return plan;
 }
 
 void PragmaEnableGpuGraph(ClientContext &context, const FunctionParameters &parameters) {
@@ -2188,7 +2209,21 @@ void GGRegisterPlanRules(ClientContext &context) {
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &use_pins);
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &no_pins);
 
-	// the shim is optional: without it the extension only offers its table functions
+	// A reference built with oracle/callout.patch exports the registration of its call-outs: the maintainers' route —
+	// no interposition, no access to private members (the BuildPipelines case and the write observation are then the
+	// executor's own code, src/parallel/executor.cpp as patched)
+	using plan_fn = unique_ptr<PhysicalOperator> (*)(PhysicalPlanGenerator &, LogicalOperator &);
+	using write_fn = void (*)(idx_t);
+	auto callouts = (void (*)(plan_fn, plan_fn, plan_fn, write_fn))dlsym(RTLD_DEFAULT, "duckdb_register_plan_callouts");
+	if (callouts) {
+		callouts(CalloutEntry<LogicalComparisonJoin, PlanJoinChain>, CalloutEntry<LogicalAggregate, PlanAggregate>,
+		         CalloutEntry<LogicalDistinct, PlanDistinctUnion>, GGDropPinsOfTable);
+		g_callouts_registered = true;
+		GGPipelineSinksNative();
+		return;
+	}
+	// otherwise the interposition shim, if it was loaded before libduckdb; without either the extension only offers
+	// its table functions
 	auto reg = (int (*)(int, gg_plan_rule_fn))dlsym(RTLD_DEFAULT, "gg_plan_hook_register");
 	if (!reg) {
 		return;
@@ -2206,10 +2241,17 @@ void GGRegisterPlanRules(ClientContext &context) {
 } // namespace duckdb
 
 extern "C" {
-//! 1 when the shim is loaded and the rules are registered with it
+//! 1 when the rules are registered: with the call-outs of a patched reference, or with the loaded shim
 int gg_plan_rules_available() {
+	if (duckdb::g_callouts_registered) {
+		return 1;
+	}
 	auto probe = (int (*)(int))dlsym(RTLD_DEFAULT, "gg_plan_hook_registered");
 	return probe && probe(GG_PLAN_HOOK_JOIN) ? 1 : 0;
+}
+//! 1 when they are registered through the call-outs of a patched reference (no interposition)
+int gg_plan_rules_by_callout() {
+	return duckdb::g_callouts_registered ? 1 : 0;
 }
 //! number of plans a rule took over since load
 uint64_t gg_plan_rules_fired() {

@@ -53,8 +53,9 @@ def join_halves(parts) -> list:
 
 def combine(vec, dist=None, device=None) -> list:
     """All-reduce one query's per-rank result vector (SUM over ranks)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return [int(x) for x in vec]
+    # (a group of one rank still makes the call: that is how a one-GPU box exercises the RCCL path)
     import torch
 
     t = torch.tensor(split_halves(vec), dtype=torch.int64, device=device or "cpu")

@@ -172,6 +172,12 @@ int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows);
 /* Copy rows [offset, offset+max_rows) of the h-hop table into cols[0..h] (host arrays of >= max_rows). */
 int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *cols,
                     uint32_t *n_out);
+/* Checksum of the `hops`-hop rows (1 <= hops <= 4) as they stand in HBM: every id of every row is mapped back to its
+ * dense index and the rows' hashes are summed exactly as gg_khop_stats.digest[hops] sums them, so a materialising
+ * expansion can be compared with the count-only expansion (and with the oracle) over ALL its rows without fetching
+ * them.  Fails with GG_ERR_STATE if a row holds an id that is not a vertex of `csr`. */
+int gg_result_digest(gg_ctx *ctx, const gg_csr *csr, const gg_result *res, int hops, uint64_t *n_rows,
+                     uint64_t *digest);
 void gg_result_destroy(gg_result *res);
 /* gg_expand_khop with the result left on the device for further operators (same arguments; only the
  * handle is returned, nothing is copied to the host). */

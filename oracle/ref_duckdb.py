@@ -17,13 +17,26 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 # GG_REF_VARIANT=hoisted: the reference with oracle/hoisted_build.patch (hash tables of a recursive CTE's invariant
 # builds kept across iterations: the "best CPU" baseline).  One variant per process: both export the same symbols.
+# GG_REF_VARIANT=patched: the reference with oracle/callout.patch (planner call-outs and the BuildPipelines case the
+# product's operators need, as the maintainers would add them): the extension registers its rules there, the
+# interposition shim is NOT loaded, and the extension is the build without access to private members.
 VARIANT = os.environ.get("GG_REF_VARIANT", "")
-_DIR = "_ref_hoisted" if VARIANT == "hoisted" else "_ref"
+_DIR = {"hoisted": "_ref_hoisted", "patched": "_ref_patched"}.get(VARIANT, "_ref")
 LIBDUCKDB = os.path.join(HERE, _DIR, "libduckdb.so")
 LIBGGREF = os.path.join(HERE, _DIR, "libggref.so")
+_PKG = os.path.join(os.path.dirname(HERE), "duckdb_pgq_amd")
 # interposition shim of the product's planner rules (duckdb_pgq_amd/host/gg_plan_hook.c): a pass-through
 # until the extension registers its rules, but it has to be in the global scope BEFORE libduckdb
-PLAN_HOOK = os.path.join(os.path.dirname(HERE), "duckdb_pgq_amd", "libgg_plan_hook.so")
+PLAN_HOOK = os.path.join(_PKG, "libgg_plan_hook.so")
+# the loadable extension that goes with this variant of the reference
+EXTENSION = os.path.join(_PKG, "callouts" if VARIANT == "patched" else "", "gg_duckdb.duckdb_extension")
+
+
+def rules_route() -> str:
+    """How the planner rules reach this reference: "callouts" (patched reference), "shim", or "" (table functions only)."""
+    if VARIANT == "patched":
+        return "callouts"
+    return "shim" if os.path.exists(PLAN_HOOK) else ""
 
 
 def available() -> bool:
@@ -44,7 +57,7 @@ class RefDuckDB:
     def __init__(self, threads: int | None = None):
         if not available():
             raise RuntimeError("oracle/_ref is not built (make -C oracle ref, needs /root/reference)")
-        self.hook = C.CDLL(PLAN_HOOK, mode=C.RTLD_GLOBAL) if os.path.exists(PLAN_HOOK) else None
+        self.hook = C.CDLL(PLAN_HOOK, mode=C.RTLD_GLOBAL) if rules_route() == "shim" else None
         self.L = C.CDLL(LIBDUCKDB, mode=C.RTLD_GLOBAL)
         self.G = C.CDLL(LIBGGREF)
         self.L.duckdb_value_int64.restype = C.c_int64

@@ -12,7 +12,7 @@ from oracle import ref_duckdb as R
 from tests.oracle_lib import sort_rows
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXT = os.path.join(ROOT, "duckdb_pgq_amd", "gg_duckdb.duckdb_extension")
+EXT = R.EXTENSION  # (the build that goes with the reference variant under test: oracle/ref_duckdb.py)
 
 pytestmark = [
     pytest.mark.gpu,
@@ -131,7 +131,7 @@ def _chain(h, select):
     return f"SELECT {select} FROM {frm} WHERE {cond}"
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_plan_rule_join_chains_give_the_reference_result(db):
     d, vid = db
     # a keyed copy of the vertex table: the vertex-validated rule needs a declared-unique key
@@ -176,7 +176,7 @@ def test_plan_rule_join_chains_give_the_reference_result(db):
     assert np.array_equal(cpu, gpu)
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_plan_rule_sees_table_changes_between_executions(db):
     """The scan opens at execution time: a second run of the same SQL reflects rows inserted meanwhile."""
     d, _ = db
@@ -192,7 +192,7 @@ def test_plan_rule_sees_table_changes_between_executions(db):
     assert int(d.execute(sql)[0, 0]) == 3
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_plan_rule_friends_cte_gives_the_reference_result(db):
     """bi-10's friends / friends_shortest (recursive CTE + min) with the rules off (PhysicalRecursiveCTE +
     hash aggregate) and on (64-lane BFS): same relation."""
@@ -249,7 +249,7 @@ def test_plan_rule_friends_cte_gives_the_reference_result(db):
     assert cpu.shape[0] > vid.size and np.array_equal(cpu, gpu)
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_plan_rule_connectedsegments_query_text():
     """BASELINE.json configs[4]: the reference's own ConnectedSegments text (11 hash joins), planned by the
     reference and by the same-neighbour rule (one GPU operator): both give the golden rows at SF1 and the
@@ -292,7 +292,7 @@ def test_plan_rule_connectedsegments_query_text():
         d.close()
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_plan_rule_prepared_statements_and_concurrent_connections(db):
     import threading
 
@@ -357,7 +357,7 @@ def test_oversized_results_are_produced_part_by_part(db, monkeypatch):
     assert np.array_equal(sort_rows(parts), sort_rows(whole))
     assert np.array_equal(sort_rows(mixed[mixed[:, 0] == 2][:, 1:]), sort_rows(whole))
     assert np.array_equal(sort_rows(mixed[mixed[:, 0] == 1][:, 1:3]), sort_rows(d.execute(R.sql_khop_rows(1))))
-    if os.path.exists(R.PLAN_HOOK):  # the substituted join takes the same route
+    if bool(R.rules_route()):  # the substituted join takes the same route
         sql = "SELECT k1.k_person1id, k2.k_person1id, k2.k_person2id FROM knows k1, knows k2 " \
               "WHERE k1.k_person2id = k2.k_person1id"
         cpu = d.execute(sql)
@@ -369,7 +369,7 @@ def test_oversized_results_are_produced_part_by_part(db, monkeypatch):
         assert np.array_equal(sort_rows(cpu), sort_rows(gpu))
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_plan_rule_predicates_on_walk_positions(db):
     """Predicates on key columns other than the pinned source stay as a filter above the GPU scan — the
     friends-of-friends branch of interactive-complex-3.sql:9-11 (`k1.src = C ... AND k2.dst <> X`), ranges,
@@ -420,7 +420,7 @@ def test_table_functions_accept_views_and_reject_unknown_names(db):
     assert int(d.execute("SELECT rows FROM gg_khop_count('person', 'p_personid', 'knows', 'k_person1id', 'k_person2id', 1, 1)")[0, 0]) > 0
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_pinned_graphs_are_reused_and_dropped_when_rows_are_appended(db):
     """gg_graph_pin builds a graph once and keeps it on the device; statements that need exactly that graph
     skip ingest and build.  It is a snapshot: appending rows makes the row count differ, the pin is dropped
@@ -480,7 +480,7 @@ def test_pinned_graphs_are_reused_and_dropped_when_rows_are_appended(db):
     assert with_pin < 1.0
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_pinned_graphs_are_opt_in_and_never_outlive_a_write(db):
     """A pinned graph is a snapshot.  Nothing uses one unless the connection said PRAGMA gg_use_pinned_graphs; an
     INSERT, UPDATE or DELETE planned on a pinned table drops the pin (also when the transaction rolls back); a
@@ -572,7 +572,7 @@ def test_pinned_graphs_are_opt_in_and_never_outlive_a_write(db):
         d.execute("PRAGMA disable_gpu_graph")
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_statements_shaped_like_the_ldbc_friends_queries_give_the_reference_result():
     """Five statements with the shape of the reference's interactive-complex-3/5/6/9/11 (tests/ldbc_shapes.py:
     friends UNION friends-of-friends of one person, joined with person / place / message / forum / organisation /
@@ -610,7 +610,7 @@ def test_statements_shaped_like_the_ldbc_friends_queries_give_the_reference_resu
         d.close()
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_sinks_run_as_pipelines_of_the_references_executor(db, monkeypatch):
     """The tables of a substituted plan flow into the device graph through pipeline sinks that the reference's
     executor schedules (Executor::BuildPipelines case in gg_pipeline.cpp): its profiler reports the sink and the
@@ -641,7 +641,7 @@ def test_sinks_run_as_pipelines_of_the_references_executor(db, monkeypatch):
         d.execute("PRAGMA disable_gpu_graph")
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_pipeline_sinks_inside_a_plan_with_a_recursive_cte(db):
     """A join chain taken over by the join rule inside a statement that also runs a recursive CTE: the chain's
     sinks get their pipelines next to the CTE's own (which the executor resets and re-runs per iteration), and the
@@ -669,7 +669,7 @@ def test_pipeline_sinks_inside_a_plan_with_a_recursive_cte(db):
         assert cpu.shape[0] > 0 and np.array_equal(cpu, gpu) and np.array_equal(cpu, again), sql
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_a_substituted_scan_in_the_recursive_arm_of_a_cte(db):
     """A count / a join chain taken over INSIDE the recursive arm (a scalar subquery, an IN subquery): the pipelines
     of that arm are re-run per iteration by Executor::ReschedulePipelines, outside the main schedule, so the graph's
@@ -701,7 +701,7 @@ def test_a_substituted_scan_in_the_recursive_arm_of_a_cte(db):
     # sink in its recursive arm — PhysicalRecursiveCTE::pipelines keeps the pipelines of the first execution)
 
 
-@pytest.mark.skipif(not os.path.exists(R.PLAN_HOOK), reason="plan hook shim not built")
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_several_substituted_scans_in_one_plan(db):
     """Two (three) GPU scans in one statement, each with its own sink pipelines: under UNION ALL (the second scan
     is the source of a union pipeline), on both sides of a join, and under a UNION that is deduped."""

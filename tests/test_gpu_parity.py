@@ -156,6 +156,28 @@ def test_khop_materialised_rows_equal_join_formulation(gg, orc):
     g.close()
 
 
+def test_digest_of_materialised_rows_equals_the_count_mode_digest(gg, orc):
+    """gg_result_digest reads the id columns a materialising expansion left in HBM, maps every id back to its dense
+    index and sums the row hashes: rows and digest must be the count-only expansion's and the oracle's for the same
+    walks (1..4 hops, all sources and a source list; dangling rows and duplicate edges in the table)."""
+    vid, src, dst = datagen.small_graph(300, 2500, 41, dangling=9, dup_edges=30)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = np.concatenate([datagen.pick_sources(vid, 40, 2), vid[:3], np.array([-9], np.int64)])
+    dense = g.lookup(sources)
+    dense = dense[dense >= 0].astype(np.uint32)
+    for k in (1, 2, 3, 4):
+        for srcs, sd in ((None, None), (sources, dense)):
+            res = gg.expand_khop_result(csr, k, sources=srcs)
+            want = g.khop(k, k, sources_dense=sd)
+            counted = gg.expand_khop(csr, k, k, sources=srcs)
+            n, dig = res.digest(csr, k)
+            assert n == res.rows(k) == want["rows"][k] == counted["rows"][k], (k, srcs is None)
+            assert dig == want["digest"][k] == counted["digest"][k], (k, srcs is None)
+            res.close()
+    csr.close()
+    g.close()
+
+
 def test_khop_source_list(gg, orc):
     vid, src, dst = datagen.ldbc_knows(2000, 60_000, 5)
     csr, g = build_both(gg, orc, vid, src, dst)

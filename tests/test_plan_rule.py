@@ -10,10 +10,10 @@ import pytest
 from oracle import ref_duckdb as R
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXT = os.path.join(ROOT, "duckdb_pgq_amd", "gg_duckdb.duckdb_extension")
+EXT = R.EXTENSION  # (the build that goes with the reference variant under test: oracle/ref_duckdb.py)
 
 pytestmark = pytest.mark.skipif(
-    not (R.available() and os.path.exists(EXT) and os.path.exists(R.PLAN_HOOK)),
+    not (R.available() and os.path.exists(EXT) and bool(R.rules_route())),
     reason="reference build / extension / plan hook not present")
 
 
