@@ -167,14 +167,7 @@ static int lds_order_ok(gg_ctx *ctx, uint32_t *ok) {
 
 // ---- D: densify + per-tile bucket histograms of both directions ---------------------------------------------
 // counts[tile * 2 nb + dir * nb + bucket]: tile-major, one contiguous 2 nb row per tile
-// Two-pass form (PASS 1, then PASS 2) for packed dictionaries that do not fit an XCD's 4 MiB L2: random 16-byte
-// probes run at 262 G/s chip-wide while their table stays in L2 and at 120 G/s once it is twice the L2
-// (scripts/ubench_gather.hip, profiles/r03_ubench_gather.txt), so pass 1 resolves only the endpoints whose home
-// pair lies in the LOWER half of the table and marks the others FB_UNRES in the dense pair, and pass 2 resolves
-// those against the upper half — each pass touches half the table — and finishes the rows (drop, ownership marks,
-// histograms).  PASS 0 is the single pass (direct and 16-byte dictionaries, small tables).
-constexpr uint32_t FB_UNRES = 0xFFFFFFFEu;  // endpoint left to pass 2 (dense indices stay below 2^22)
-template <int MODE, int PASS = 0>
+template <int MODE>
 __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
                                              uint64_t E, uint64_t base, const HtSlot *__restrict__ ht, uint64_t cap,
                                              int64_t min_idx, const uint32_t *__restrict__ dir,
@@ -215,34 +208,17 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
     } else if (MODE == DICT_PACKED8) {
       uint64_t hs[B], hd[B], ts[B], td[B];
       uint4 rs[B], rd[B];
-      bool ns[B], nd[B];  // this pass probes the endpoint
-      u32x2 prev[B];
 #pragma unroll
       for (int j = 0; j < B; j++) {  // first probes of the whole batch issue back to back
-        const uint64_t e = base + (uint64_t)(it0 + j) * FB_THREADS + threadIdx.x;
         pk.locate(ks[j], &hs[j], &ts[j]);
         pk.locate(kd[j], &hd[j], &td[j]);
-        ns[j] = nd[j] = true;
-        if (PASS == 1) {  // lower half of the table only
-          ns[j] = (hs[j] >> (pk.q - 1)) == 0;
-          nd[j] = (hd[j] >> (pk.q - 1)) == 0;
-        }
-        if (PASS == 2) {  // what pass 1 left
-          prev[j].x = prev[j].y = INVALID_U32;
-          if (e < E) prev[j] = ld_stream(pairs + e);
-          ns[j] = prev[j].x == FB_UNRES;
-          nd[j] = prev[j].y == FB_UNRES;
-        }
-        rs[j] = rd[j] = make_uint4(0, 0, 0, 0);
-        if (ns[j]) rs[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hs[j]]);
-        if (nd[j]) rd[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hd[j]]);
+        rs[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hs[j]]);
+        rd[j] = *reinterpret_cast<const uint4 *>(&tab[2 * hd[j]]);
       }
 #pragma unroll
       for (int j = 0; j < B; j++) {
-        us[j] = PASS == 2 ? prev[j].x : FB_UNRES;
-        vs[j] = PASS == 2 ? prev[j].y : FB_UNRES;
-        if (ns[j]) us[j] = packed_resolve(tab, pk, ks[j] >= min_id && ks[j] <= max_id, hs[j], ts[j], rs[j]);
-        if (nd[j]) vs[j] = packed_resolve(tab, pk, kd[j] >= min_id && kd[j] <= max_id, hd[j], td[j], rd[j]);
+        us[j] = packed_resolve(tab, pk, ks[j] >= min_id && ks[j] <= max_id, hs[j], ts[j], rs[j]);
+        vs[j] = packed_resolve(tab, pk, kd[j] >= min_id && kd[j] <= max_id, hd[j], td[j], rd[j]);
       }
     } else {
       uint64_t ss[B], sd[B];
@@ -265,13 +241,6 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
       const uint64_t e = base + (uint64_t)(it0 + j) * FB_THREADS + threadIdx.x;
       if (e >= E) continue;
       uint32_t u = us[j], v = vs[j];
-      if (PASS == 1) {  // half-resolved pair; pass 2 finishes the row
-        u32x2 pr;
-        pr.x = u;
-        pr.y = v;
-        st_stream(pairs + e, pr);
-        continue;
-      }
       if (u == INVALID_U32 || v == INVALID_U32) {
         u = INVALID_U32;  // dropped: an endpoint is not a vertex (inner-join semantics)
         v = INVALID_U32;
@@ -303,7 +272,7 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
 #else
 #define GG_FB_DATTR
 #endif
-template <bool PROBE = false, int PASS = 0>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
+template <bool PROBE = false>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
 __global__ __launch_bounds__(FB_THREADS) GG_FB_DATTR void k_densify_pairs(
     const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
     uint64_t cap, const BuildStatus *__restrict__ st, const uint32_t *__restrict__ dir,
@@ -311,20 +280,11 @@ __global__ __launch_bounds__(FB_THREADS) GG_FB_DATTR void k_densify_pairs(
     FastGeom g, uint64_t nblocks, uint32_t *__restrict__ counts) {
   __shared__ uint32_t hist[2 << FB_MAX_HB];
   const uint32_t nb = 1u << g.hb;
-  const unsigned long long mode = PROBE ? 99ULL : dm->mode;  // uniform over the grid
-  const uint64_t base = (uint64_t)blockIdx.x * FB_TILE;
-  if (PASS == 1) {  // (only a packed table is probed half by half: otherwise pass 2 is the single pass)
-    if (mode == DICT_PACKED8)
-      densify_tile<DICT_PACKED8, 1>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part,
-                                    g.n_parts, hist, hist + nb);
-    return;
-  }
   for (uint32_t i = threadIdx.x; i < 2 * nb; i += FB_THREADS) hist[i] = 0;
   __syncthreads();
-  if (PASS == 2 && mode == DICT_PACKED8)
-    densify_tile<DICT_PACKED8, 2>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part,
-                                  g.n_parts, hist, hist + nb);
-  else if (PROBE)
+  const uint64_t base = (uint64_t)blockIdx.x * FB_TILE;
+  const unsigned long long mode = PROBE ? 99ULL : dm->mode;  // uniform over the grid
+  if (PROBE)
     densify_tile<99>(src, dst, E, base, ht, cap, st->min_idx, dir, tab, dm, pairs, g.low, g.part, g.n_parts, hist,
                           hist + nb);
   else if (mode == DICT_DIRECT)
@@ -1335,23 +1295,9 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
             ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
             (const DirectMap *)dm, pairs, g, nblocks64, counts);
 #endif
-#ifndef GG_FB_TWOPASS
-#define GG_FB_TWOPASS 2  // 0: one densification pass; 1: always two; 2: two when the packed table exceeds an XCD's L2
-#endif
-  const bool two_pass = GG_FB_TWOPASS == 1 || (GG_FB_TWOPASS == 2 && 2 * npairs * sizeof(unsigned long long) > (4u << 20) &&
-                                               E >= (1u << 22));
-  if (two_pass) {
-    GG_LAUNCH(ctx, "densify_half", (k_densify_pairs<false, 1>), dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
-              (const DirectMap *)dm, pairs, g, nblocks64, counts);
-    GG_LAUNCH(ctx, "densify_pairs", (k_densify_pairs<false, 2>), dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
-              (const DirectMap *)dm, pairs, g, nblocks64, counts);
-  } else {
-    GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
-              ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
-              (const DirectMap *)dm, pairs, g, nblocks64, counts);
-  }
+  GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev, ctx->c_dst.dev, E,
+            csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab, (const DirectMap *)dm,
+            pairs, g, nblocks64, counts);
   const uint64_t pmax = 2 * (nblocks64 + nb);  // chunks: every bucket may end in a partial one
   uint4 *part_of = nullptr;
   uint32_t *cstart = nullptr, *offs = nullptr, *substart = nullptr;
