@@ -1205,6 +1205,315 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
                          rnbr, rrow);
 }
 
+// ---- B, second form: chunks sorted by VERTEX, rows by address arithmetic -------------------------------------------
+// For graphs of up to 2^20 vertices a bucket holds at most 2^10 = 1024 vertices, and a wave's row of LDS cursors can
+// have one cursor per vertex: the chunk sort then orders a chunk by the whole bucket-local vertex number (not by a
+// 6- or 7-bit sub-bucket), its offset row says where every vertex's entries start inside the chunk, and nothing is
+// left to rank afterwards.  The rows step k_vrows therefore has no counting pass and no LDS atomics: an entry's
+// final position is  off[v] + (entries of v in the chunks before) + (its index inside the chunk's segment of v),
+// all of it known from the offset rows; one pass, one LDS read per entry for the per-(chunk, vertex) term.
+//   k_vsort_pipe  persistent workgroups, next chunk's loads in flight (as k_sub_sort_pipe); cursors of up to 1024
+//                 keys: every thread owns keys t and t + 512, two scans over the workgroup
+//   k_vtotals     per bucket: degree of every vertex (sum over the chunks' rows) -> the CSR's row offsets
+//   k_vrows       one wave per group of VG consecutive vertices: copies the group's run of every chunk to its rows
+// Measured at SF100 against the sub-bucket form (k_sub_sort_pipe + k_sub_totals + k_leaf_rows): DESIGN.md §4.1.
+#ifndef GG_FB_VLOW
+#define GG_FB_VLOW 10  // vertices per bucket (log2) in this form: a wave's cursor row is 4 << GG_FB_VLOW bytes of LDS
+#endif
+constexpr int FB_VLOW = GG_FB_VLOW;
+#ifndef GG_FB_VG
+#define GG_FB_VG 16    // vertices per wave of k_vrows (<= 32)
+#endif
+constexpr int FB_VG = GG_FB_VG;
+#ifndef GG_FB_VCG
+#define GG_FB_VCG 32
+#endif
+constexpr int FB_VCG = GG_FB_VCG;  // chunks a wave of k_vrows takes at a time (lane c holds chunk c's run; a multiple of 8)
+#ifndef GG_FB_VSTEPS
+#define GG_FB_VSTEPS 16  // 64-entry loads a wave of k_vrows keeps in flight
+#endif
+constexpr int FB_VSTEPS = GG_FB_VSTEPS;
+
+__global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
+                                                           const uint32_t *__restrict__ cstart,
+                                                           const uint4 *__restrict__ part_of, FastGeom g,
+                                                           uint32_t *__restrict__ offs /* [chunk][nk + 1] */) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t s_n, s_w[2][FB_WAVES];
+  const uint32_t nb = 1u << g.hb, nk = 1u << g.low, G = gridDim.x;
+  uint32_t p = blockIdx.x;
+  uint4 chunk = part_of[p];  // (entries past the last chunk are allocated, not meaningful)
+  const uint32_t nchunks = cstart[2 * nb];
+  if (p >= nchunks) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *hw = lds;                  // [FB_WAVES][nk] per-wave counts -> cursors (staged slot)
+  uint32_t *xw = hw + FB_WAVES * nk;   // staged words
+  uint32_t *myh = hw + wave * nk;
+  const uint32_t mine = (uint32_t)wave * FB_WTILE + lane;  // this lane's first entry inside a chunk
+  uint32_t w[FB_ITEMS], wn[FB_ITEMS];
+  {
+    const uint32_t *__restrict__ src = (chunk.z / nb ? buf_r : buf_f) + chunk.x;
+    const uint32_t len = chunk.y - chunk.x;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) w[it] = mine + it * 64 < len ? ld_stream(src + mine + it * 64) : 0u;
+  }
+  uint4 chunk_n = p + G < nchunks ? part_of[p + G] : make_uint4(0, 0, 0, 0);
+  for (;;) {
+    const bool has_next = p + G < nchunks;  // uniform
+    uint4 chunk_nn = make_uint4(0, 0, 0, 0);
+    if (has_next) {
+      const uint32_t *__restrict__ src = (chunk_n.z / nb ? buf_r : buf_f) + chunk_n.x;
+      const uint32_t len = chunk_n.y - chunk_n.x;
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) wn[it] = mine + it * 64 < len ? ld_stream(src + mine + it * 64) : 0u;
+      if (p + 2 * G < nchunks) chunk_nn = part_of[p + 2 * G];
+    }
+    uint32_t *__restrict__ buf = (chunk.z / nb ? buf_r : buf_f) + chunk.x;
+    const uint32_t len = chunk.y - chunk.x;
+    for (uint32_t k = lane; k < nk; k += 64) myh[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const bool runs = wave_has_runs(w[0] >> g.key_bits, mine < len, lane);  // (see k_partition_dual)
+    if (runs) {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) run_add<false>(myh, w[it] >> g.key_bits, mine + it * 64 < len, lane);
+    } else {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++)
+        if (mine + it * 64 < len) atomicAdd(&myh[w[it] >> g.key_bits], 1u);
+    }
+    __syncthreads();
+    {
+      // cursors: thread t owns keys t and t + FB_THREADS (bank-conflict-free columns of hw); positions are prefix sums
+      // in key order, so two scans over the workgroup: keys [0, 512), then [512, 1024) on top of the first total
+      uint32_t cw[2][FB_WAVES], tot[2] = {0, 0}, incl[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t k = (uint32_t)h * FB_THREADS + threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < FB_WAVES; q++) {
+          cw[h][q] = k < nk ? hw[q * nk + k] : 0u;
+          tot[h] += cw[h][q];
+        }
+        incl[h] = wave_scan_incl(tot[h]);  // (DPP moves, gg_internal.h)
+        if (lane == 63) s_w[h][wave] = incl[h];
+      }
+      __syncthreads();
+      uint32_t before[2] = {0, 0}, all[2] = {0, 0};
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int q = 0; q < FB_WAVES; q++) {
+          const uint32_t sv = s_w[h][q];
+          if (q < wave) before[h] += sv;
+          all[h] += sv;
+        }
+      uint32_t *__restrict__ row = offs + (uint64_t)p * g.ss;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t k = (uint32_t)h * FB_THREADS + threadIdx.x;
+        uint32_t run = (h ? all[0] : 0u) + before[h] + incl[h] - tot[h];
+        if (k < nk) {
+          row[k] = run;
+#pragma unroll
+          for (int q = 0; q < FB_WAVES; q++) {
+            hw[q * nk + k] = run;
+            run += cw[h][q];
+          }
+        }
+      }
+      if (threadIdx.x == 0) {
+        row[nk] = all[0] + all[1];
+        s_n = all[0] + all[1];
+      }
+    }
+    __syncthreads();
+    if (runs) {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) {
+        const bool valid = mine + it * 64 < len;
+        const uint32_t pos = run_add<true>(myh, w[it] >> g.key_bits, valid, lane);
+        if (valid) xw[pos] = w[it];
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < FB_ITEMS; it++) {  // ranks straight from the wave's cursors (lane-ordered ds_add_rtn)
+        if (mine + it * 64 < len) {
+          const uint32_t pos = atomicAdd(&myh[w[it] >> g.key_bits], 1u);
+          xw[pos] = w[it];
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) {
+      const uint32_t sidx = (uint32_t)it * FB_THREADS + threadIdx.x;
+      if (sidx < n) buf[sidx] = xw[sidx];
+    }
+    if (!has_next) break;
+    __syncthreads();  // the stage and the cursors are reused
+#pragma unroll
+    for (int it = 0; it < FB_ITEMS; it++) w[it] = wn[it];
+    chunk = chunk_n;
+    chunk_n = chunk_nn;
+    p += G;
+  }
+}
+
+// row offsets: one workgroup per bucket, thread k = vertex k of the bucket
+__global__ __launch_bounds__(1024) void k_vtotals(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ bstart,
+                                                  const uint32_t *__restrict__ cstart, FastGeom g, uint64_t V,
+                                                  uint32_t *__restrict__ off, uint32_t *__restrict__ roff) {
+  __shared__ uint32_t s_w[16];
+  const uint32_t nb = 1u << g.hb, nk = 1u << g.low, i = blockIdx.x, dir = i / nb, j = i % nb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t k = threadIdx.x, p0 = cstart[i], p1 = cstart[i + 1];
+  uint32_t deg = 0;
+  if (k < nk)
+    for (uint32_t p = p0; p < p1; p++) deg += offs[(uint64_t)p * g.ss + k + 1] - offs[(uint64_t)p * g.ss + k];
+  const uint32_t incl = wave_scan_incl(deg);  // (DPP moves, gg_internal.h)
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int q = 0; q < wave; q++) before += s_w[q];
+  const uint64_t v = ((uint64_t)j << g.low) + k;
+  uint32_t *__restrict__ out = dir ? roff : off;
+  if (k < nk && v <= V) out[v] = bstart[dir * (nb + 1) + j] + before + incl - deg;  // v == V: the closing offset
+  // no thread holds vertex V when V is a multiple of the bucket width: the last bucket closes the offsets
+  if (k == 0 && j == nb - 1 && ((uint64_t)nb << g.low) == V) out[V] = bstart[dir * (nb + 1) + nb];
+}
+
+// One wave per (direction, bucket, group of VG vertices).  Chunks are taken FB_VCG at a time: for chunk c the lanes
+// d <= VG read the chunk's offsets of the group's vertices (one coalesced load), lane d keeps the running row
+// position of vertex d, and LDS gets   delta[c][d] = (row position of d's first entry in chunk c) - (index of that
+// entry inside the group's run of chunk c),   so an entry at index x of the run goes to delta[c][d] + x.
+// The group's rows are one contiguous piece of the output: when it fits the wave's LDS stage the entries are placed
+// there (plain LDS stores: scattered 4-byte GLOBAL stores cost a memory-pipeline slot per lane) and written out as
+// whole lines; larger groups store straight to their rows.  (Measured at SF100, 240 us as it stands: reading the runs
+// of a large group once per stage-sized window instead of storing directly 307 us; four entries per lane and step
+// with 16-byte loads — runs start at any 4-byte boundary — 358 us.)
+#ifndef GG_FB_VCAP
+#define GG_FB_VCAP 1536  // entries of a wave's stage in k_vrows
+#endif
+__global__ __launch_bounds__(64) void k_vrows(const uint32_t *__restrict__ buf_f, const uint32_t *__restrict__ buf_r,
+                                              const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart,
+                                              const uint32_t *__restrict__ offs, FastGeom g, uint64_t V,
+                                              const uint32_t *__restrict__ off, uint32_t *__restrict__ nbr,
+                                              const uint32_t *__restrict__ roff, uint32_t *__restrict__ rnbr,
+                                              uint32_t *__restrict__ rrow) {
+  __shared__ uint32_t s_delta[FB_VCG * FB_VG];
+  __shared__ uint32_t s_run[2 * FB_VCG];  // [c]: first entry of the run inside chunk c, [FB_VCG + c]: its length
+  __shared__ uint32_t s_stage[GG_FB_VCAP];
+  const uint32_t nb = 1u << g.hb, nk = 1u << g.low;
+  const uint32_t vg = nk < (uint32_t)FB_VG ? nk : (uint32_t)FB_VG, groups = nk / vg;  // (powers of two)
+  const uint32_t unit = blockIdx.x, i = unit / groups, k0 = (unit % groups) * vg, dir = i / nb, j = i % nb;
+  const int lane = threadIdx.x;
+  const uint32_t *__restrict__ buf = dir ? buf_r : buf_f;
+  uint32_t *__restrict__ o_nbr = dir ? rnbr : nbr;
+  const uint64_t v0 = ((uint64_t)j << g.low) + k0;  // first vertex of the group
+  if (v0 >= V) return;                              // (the table ends before this group: uniform)
+  const uint32_t b0 = bstart[dir * (nb + 1) + j], p0 = cstart[i], nch = cstart[i + 1] - p0;
+  const uint32_t pay_mask = (1u << g.key_bits) - 1u;  // (this form packs: key_bits + low <= 32)
+  const uint32_t keep_mask = (vg << g.key_bits) - 1u;   // payload and the vertex inside the group
+  uint32_t base = 0;  // lane d < vg: row position of vertex d's next entry
+  {
+    const uint64_t vv = v0 + (uint32_t)lane;
+    if ((uint32_t)lane <= vg) base = (dir ? roff : off)[vv < V ? vv : V];
+  }
+  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)vg) - t0;  // entries of the group
+  const bool staged = n <= (uint32_t)GG_FB_VCAP;  // uniform
+  if (staged) base -= t0;                         // positions inside the stage
+  for (uint32_t cg = 0; cg < nch; cg += FB_VCG) {
+    const uint32_t ncg = nch - cg < (uint32_t)FB_VCG ? nch - cg : (uint32_t)FB_VCG;
+    // offset rows of the chunks of this round, eight loads in flight
+    for (uint32_t c0 = 0; c0 < ncg; c0 += 8) {
+      uint32_t sv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        sv[q] = 0;
+        if (c0 + q < ncg && (uint32_t)lane <= vg) sv[q] = offs[(uint64_t)(p0 + cg + c0 + q) * g.ss + k0 + lane];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (c0 + q >= ncg) continue;  // uniform
+        const uint32_t c = c0 + q;
+        const uint32_t nxt = (uint32_t)__shfl_down((int)sv[q], 1, 64);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)sv[q], 0);
+        if ((uint32_t)lane < vg) {
+          s_delta[c * vg + lane] = base - (sv[q] - first);
+          base += nxt - sv[q];
+        }
+        if (lane == 0) {
+          s_run[c] = first;
+          s_run[FB_VCG + c] = (uint32_t)__builtin_amdgcn_readlane((int)sv[q], (int)vg) - first;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane c holds chunk c's run; a run is walked in 64-entry steps
+    uint32_t so = 0, len = 0;
+    if ((uint32_t)lane < ncg) {
+      so = s_run[lane];
+      len = s_run[FB_VCG + lane];
+    }
+    const uint32_t src = b0 + (cg + lane) * FB_TILE + so;  // position of the run's first entry
+    const uint32_t st_c = (len + 63) / 64;
+    const uint32_t sincl = wave_scan_incl(st_c);  // (DPP moves, gg_internal.h)
+    const uint32_t sexcl = sincl - st_c;
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+    for (uint32_t r = 0; r < T; r += FB_VSTEPS) {
+      uint32_t kw[FB_VSTEPS], kx[FB_VSTEPS];
+      uint32_t have = 0;
+#pragma unroll
+      for (int q = 0; q < FB_VSTEPS; q++) {  // all loads of the round issue back to back
+        const uint32_t t = r + q;
+        kw[q] = 0;
+        kx[q] = 0;
+        if (t < T) {  // uniform
+          const int cc = __popcll(__ballot(sincl <= t));  // the run this step belongs to (< 64: t < T)
+          const uint32_t kidx = (t - (uint32_t)__builtin_amdgcn_readlane((int)sexcl, cc)) * 64 + lane;
+          const uint32_t run_src = (uint32_t)__builtin_amdgcn_readlane((int)src, cc);
+          const uint32_t run_len = (uint32_t)__builtin_amdgcn_readlane((int)len, cc);
+          if (kidx < run_len) {
+            have |= 1u << q;
+            kw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(buf + run_src), 0, (int)(run_len * 4u),
+                                                  0x00020000),
+                kidx * 4u, 0, 0);
+            kx[q] = kidx | ((uint32_t)cc << 24);  // index inside the run (< 8192), run number
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < FB_VSTEPS; q++) {
+        if (r + q >= T) continue;  // uniform
+        if ((have >> q) & 1u) {
+          const uint32_t d = (kw[q] >> g.key_bits) & (vg - 1u);
+          const uint32_t pos = s_delta[(kx[q] >> 24) * vg + d] + (kx[q] & 0xFFFFFFu);
+          if (staged) {
+            s_stage[pos] = kw[q] & keep_mask;
+          } else {
+            o_nbr[pos] = kw[q] & pay_mask;
+            if (dir) rrow[pos] = (uint32_t)v0 + d;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the tables are rewritten by the next round of chunks
+  }
+  if (staged) {
+    for (uint32_t x0 = 0; x0 < n; x0 += 64) {
+      const uint32_t x = x0 + lane;
+      if (x < n) {
+        const uint32_t sw = s_stage[x];
+        o_nbr[t0 + x] = sw & pay_mask;
+        if (dir) rrow[t0 + x] = (uint32_t)v0 + (sw >> g.key_bits);
+      }
+    }
+  }
+}
+
 static int bits_of(uint64_t v) {  // bits needed for values 0..v
   int b = 0;
   while (b < 64 && (v >> b)) b++;
@@ -1229,17 +1538,29 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   int sub = lb < FB_MAX_SUB ? lb : FB_MAX_SUB;
   int hb = lb - sub;
   if (hb > FB_MAX_HB) return GG_OK;              // more than 2^22 vertices: the multi-pass build
-  const int low = kb - hb;
+  int low = kb - hb;
+  GG_TRY(lds_order_ok(ctx, &g.rank_atomic));
+  // up to 2^(FB_MAX_HB + FB_VLOW) vertices, packed words, no edge positions, cursor ranks: the chunks are sorted by
+  // vertex and the rows step only copies (k_vsort_pipe / k_vtotals / k_vrows)
+#ifndef GG_FB_VSORT
+#define GG_FB_VSORT 1
+#endif
+  const bool want_rowid = ctx->keep_edge_rowid && csr->n_parts <= 1;
+  const bool vsort = GG_FB_VSORT && g.rank_atomic && !want_rowid && kb <= FB_MAX_HB + FB_VLOW && kb <= 20;
+  if (vsort) {
+    low = kb < FB_VLOW ? kb : FB_VLOW;
+    hb = kb - low;
+    sub = low;
+  }
   g.key_bits = (uint32_t)kb;
   g.low = (uint32_t)low;
   g.hb = (uint32_t)hb;
   g.pack = (low + kb <= 32) ? 1u : 0u;
   g.sub = (uint32_t)sub;
   g.leaf = (uint32_t)(low - sub);
-  g.ss = sub > 6 ? 129u : 65u;
+  g.ss = vsort ? (1u << low) + 1u : sub > 6 ? 129u : 65u;
   g.part = (uint32_t)csr->part;
   g.n_parts = (uint32_t)csr->n_parts;
-  GG_TRY(lds_order_ok(ctx, &g.rank_atomic));
   *taken = 1;
   const uint32_t nb = 1u << hb;
   const bool rowid = ctx->keep_edge_rowid && csr->n_parts <= 1;  // a shard only serves 2-hop counting and BFS: no rowids
@@ -1400,7 +1721,21 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
 #undef GG_FB_PROBE_S
   }
 #endif
-  if (g.pack && rowid) {
+  if (vsort) {
+    const size_t lds_v = ((size_t)FB_WAVES * (1u << low) + FB_TILE) * sizeof(uint32_t);
+    const uint64_t resident = (uint64_t)ctx->num_cus * 2;
+    const unsigned grid_p = (unsigned)(pmax < resident ? pmax : resident);
+    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vsort_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds_v));
+    GG_LAUNCH(ctx, "sub_sort", k_vsort_pipe, dim3(grid_p), dim3(FB_THREADS), lds_v, part_f, part_r,
+              (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);
+    GG_LAUNCH(ctx, "sub_totals", k_vtotals, dim3(2 * nb), dim3(1024), 0, (const uint32_t *)offs,
+              (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, csr->off, csr->roff);
+    const uint32_t nk = 1u << low, vg = nk < (uint32_t)FB_VG ? nk : (uint32_t)FB_VG;
+    GG_LAUNCH(ctx, "leaf_rows", k_vrows, dim3((unsigned)(2ull * nb * (nk / vg))), dim3(64), 0, (const uint32_t *)part_f,
+              (const uint32_t *)part_r, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint32_t *)offs, g, V,
+              (const uint32_t *)csr->off, csr->nbr, (const uint32_t *)csr->roff, csr->rnbr, csr->rrow);
+  } else if (g.pack && rowid) {
     GG_FB_LAUNCH_B2(true, true);
   } else if (g.pack && g.rank_atomic && GG_FB_SUBPIPE) {
     const uint64_t resident = (uint64_t)ctx->num_cus * GG_FB_SUBPIPE;
