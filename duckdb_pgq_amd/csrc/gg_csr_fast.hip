@@ -1214,8 +1214,9 @@ __global__ __launch_bounds__(LEAF_WAVES * 64) void k_leaf_rows(
 // all of it known from the offset rows; one pass, one LDS read per entry for the per-(chunk, vertex) term.
 //   k_vsort_pipe  persistent workgroups, next chunk's loads in flight (as k_sub_sort_pipe); cursors of up to 1024
 //                 keys: every thread owns keys t and t + 512, two scans over the workgroup
-//   k_vtotals     per bucket: degree of every vertex (sum over the chunks' rows) -> the CSR's row offsets
-//   k_vrows       one wave per group of VG consecutive vertices: copies the group's run of every chunk to its rows
+//   k_vgroups     per bucket: where the rows of every group of VG vertices start (sums over the chunks' rows)
+//   k_vrows       one wave per group of VG consecutive vertices: the group's row offsets (its piece of the CSR's
+//                 offset array), then the group's run of every chunk copied to its rows
 // Measured at SF100 against the sub-bucket form (k_sub_sort_pipe + k_sub_totals + k_leaf_rows): DESIGN.md §4.1.
 #ifndef GG_FB_VLOW
 #define GG_FB_VLOW 10  // vertices per bucket (log2) in this form: a wave's cursor row is 4 << GG_FB_VLOW bytes of LDS
@@ -1226,7 +1227,7 @@ constexpr int FB_VLOW = GG_FB_VLOW;
 #endif
 constexpr int FB_VG = GG_FB_VG;
 #ifndef GG_FB_VCG
-#define GG_FB_VCG 32
+#define GG_FB_VCG 16
 #endif
 constexpr int FB_VCG = GG_FB_VCG;  // chunks a wave of k_vrows takes at a time (lane c holds chunk c's run; a multiple of 8)
 #ifndef GG_FB_VSTEPS
@@ -1237,7 +1238,7 @@ constexpr int FB_VSTEPS = GG_FB_VSTEPS;
 __global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
                                                            const uint32_t *__restrict__ cstart,
                                                            const uint4 *__restrict__ part_of, FastGeom g,
-                                                           uint32_t *__restrict__ offs /* [chunk][nk + 1] */) {
+                                                           uint16_t *__restrict__ offs /* [chunk][nk + 1], <= 8192 */) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t s_n, s_w[2][FB_WAVES];
   const uint32_t nb = 1u << g.hb, nk = 1u << g.low, G = gridDim.x;
@@ -1307,13 +1308,13 @@ __global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict_
           if (q < wave) before[h] += sv;
           all[h] += sv;
         }
-      uint32_t *__restrict__ row = offs + (uint64_t)p * g.ss;
+      uint16_t *__restrict__ row = offs + (uint64_t)p * g.ss;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const uint32_t k = (uint32_t)h * FB_THREADS + threadIdx.x;
         uint32_t run = (h ? all[0] : 0u) + before[h] + incl[h] - tot[h];
         if (k < nk) {
-          row[k] = run;
+          row[k] = (uint16_t)run;
 #pragma unroll
           for (int q = 0; q < FB_WAVES; q++) {
             hw[q * nk + k] = run;
@@ -1322,7 +1323,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict_
         }
       }
       if (threadIdx.x == 0) {
-        row[nk] = all[0] + all[1];
+        row[nk] = (uint16_t)(all[0] + all[1]);
         s_n = all[0] + all[1];
       }
     }
@@ -1360,27 +1361,19 @@ __global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict_
   }
 }
 
-// row offsets: one workgroup per bucket, thread k = vertex k of the bucket
-__global__ __launch_bounds__(1024) void k_vtotals(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ bstart,
-                                                  const uint32_t *__restrict__ cstart, FastGeom g, uint64_t V,
-                                                  uint32_t *__restrict__ off, uint32_t *__restrict__ roff) {
-  __shared__ uint32_t s_w[16];
+// where the rows of every group of VG vertices start: one wave per bucket, lane = group (at most 64 groups)
+__global__ __launch_bounds__(64) void k_vgroups(const uint16_t *__restrict__ offs, const uint32_t *__restrict__ bstart,
+                                                const uint32_t *__restrict__ cstart, FastGeom g,
+                                                uint32_t *__restrict__ gstart /* [2 nb][64] */) {
   const uint32_t nb = 1u << g.hb, nk = 1u << g.low, i = blockIdx.x, dir = i / nb, j = i % nb;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t k = threadIdx.x, p0 = cstart[i], p1 = cstart[i + 1];
-  uint32_t deg = 0;
-  if (k < nk)
-    for (uint32_t p = p0; p < p1; p++) deg += offs[(uint64_t)p * g.ss + k + 1] - offs[(uint64_t)p * g.ss + k];
-  const uint32_t incl = wave_scan_incl(deg);  // (DPP moves, gg_internal.h)
-  if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
-  uint32_t before = 0;
-  for (int q = 0; q < wave; q++) before += s_w[q];
-  const uint64_t v = ((uint64_t)j << g.low) + k;
-  uint32_t *__restrict__ out = dir ? roff : off;
-  if (k < nk && v <= V) out[v] = bstart[dir * (nb + 1) + j] + before + incl - deg;  // v == V: the closing offset
-  // no thread holds vertex V when V is a multiple of the bucket width: the last bucket closes the offsets
-  if (k == 0 && j == nb - 1 && ((uint64_t)nb << g.low) == V) out[V] = bstart[dir * (nb + 1) + nb];
+  const uint32_t vg = nk < (uint32_t)FB_VG ? nk : (uint32_t)FB_VG, groups = nk / vg;
+  const int lane = threadIdx.x;
+  const uint32_t p0 = cstart[i], p1 = cstart[i + 1], k0 = (uint32_t)lane * vg;
+  uint32_t tot = 0;
+  if ((uint32_t)lane < groups)
+    for (uint32_t p = p0; p < p1; p++) tot += (uint32_t)offs[(uint64_t)p * g.ss + k0 + vg] - offs[(uint64_t)p * g.ss + k0];
+  const uint32_t incl = wave_scan_incl(tot);  // (DPP moves, gg_internal.h)
+  gstart[(uint64_t)i * 64 + lane] = bstart[dir * (nb + 1) + j] + incl - tot;
 }
 
 // One wave per (direction, bucket, group of VG vertices).  Chunks are taken FB_VCG at a time: for chunk c the lanes
@@ -1397,57 +1390,85 @@ __global__ __launch_bounds__(1024) void k_vtotals(const uint32_t *__restrict__ o
 #endif
 __global__ __launch_bounds__(64) void k_vrows(const uint32_t *__restrict__ buf_f, const uint32_t *__restrict__ buf_r,
                                               const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ cstart,
-                                              const uint32_t *__restrict__ offs, FastGeom g, uint64_t V,
-                                              const uint32_t *__restrict__ off, uint32_t *__restrict__ nbr,
-                                              const uint32_t *__restrict__ roff, uint32_t *__restrict__ rnbr,
-                                              uint32_t *__restrict__ rrow) {
+                                              const uint16_t *__restrict__ offs, const uint32_t *__restrict__ gstart,
+                                              FastGeom g, uint64_t V, uint32_t *__restrict__ off,
+                                              uint32_t *__restrict__ nbr, uint32_t *__restrict__ roff,
+                                              uint32_t *__restrict__ rnbr, uint32_t *__restrict__ rrow) {
   __shared__ uint32_t s_delta[FB_VCG * FB_VG];
   __shared__ uint32_t s_run[2 * FB_VCG];  // [c]: first entry of the run inside chunk c, [FB_VCG + c]: its length
   __shared__ uint32_t s_stage[GG_FB_VCAP];
   const uint32_t nb = 1u << g.hb, nk = 1u << g.low;
   const uint32_t vg = nk < (uint32_t)FB_VG ? nk : (uint32_t)FB_VG, groups = nk / vg;  // (powers of two)
-  const uint32_t unit = blockIdx.x, i = unit / groups, k0 = (unit % groups) * vg, dir = i / nb, j = i % nb;
+  const uint32_t unit = blockIdx.x, i = unit / groups, gi = unit % groups, k0 = gi * vg, dir = i / nb, j = i % nb;
   const int lane = threadIdx.x;
   const uint32_t *__restrict__ buf = dir ? buf_r : buf_f;
   uint32_t *__restrict__ o_nbr = dir ? rnbr : nbr;
   const uint64_t v0 = ((uint64_t)j << g.low) + k0;  // first vertex of the group
   if (v0 >= V) return;                              // (the table ends before this group: uniform)
   const uint32_t b0 = bstart[dir * (nb + 1) + j], p0 = cstart[i], nch = cstart[i + 1] - p0;
+  const uint32_t gs = gstart[(uint64_t)i * 64 + gi];
   const uint32_t pay_mask = (1u << g.key_bits) - 1u;  // (this form packs: key_bits + low <= 32)
   const uint32_t keep_mask = (vg << g.key_bits) - 1u;   // payload and the vertex inside the group
-  uint32_t base = 0;  // lane d < vg: row position of vertex d's next entry
+  // Pass over the offset rows of ALL the bucket's chunks: the vertices' degrees (sum over the chunks), and with them the
+  // row offsets — this wave's piece of the CSR's offset array.  The rows of the first FB_VCG chunks (normally all
+  // of them) are parked in the LDS tables as they stand, so the placing pass below does not load them again.
+  uint32_t deg = 0;
+#pragma unroll 1
+  for (uint32_t c0 = 0; c0 < nch; c0 += 8) {
+    uint32_t sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {  // eight loads in flight
+      sv[q] = 0;
+      if (c0 + q < nch && (uint32_t)lane <= vg) sv[q] = offs[(uint64_t)(p0 + c0 + q) * g.ss + k0 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t c = c0 + q;
+      if (c >= nch) continue;  // uniform
+      const uint32_t nxt = (uint32_t)__shfl_down((int)sv[q], 1, 64);  // (by the whole wave: lane vg feeds lane vg - 1)
+      if ((uint32_t)lane < vg) deg += nxt - sv[q];
+      if (c < (uint32_t)FB_VCG) {
+        if ((uint32_t)lane < vg) s_delta[c * vg + lane] = sv[q];
+        if (lane == 0) s_run[c] = sv[q];
+        if ((uint32_t)lane == vg) s_run[FB_VCG + c] = sv[q];  // (the END of the run for now)
+      }
+    }
+  }
+  const uint32_t dincl = wave_scan_incl(deg);  // (DPP moves, gg_internal.h)
+  uint32_t base = gs + dincl - deg;            // lane d < vg: row position of vertex d's next entry; lane vg: the end
   {
     const uint64_t vv = v0 + (uint32_t)lane;
-    if ((uint32_t)lane <= vg) base = (dir ? roff : off)[vv < V ? vv : V];
-  }
-  const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
-  const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)vg) - t0;  // entries of the group
+    if ((uint32_t)lane <= vg && vv <= V) (dir ? roff : off)[vv] = base;  // (lane vg of a group writes the next group's
+  }                                                                       // first offset too: the same value)
+  const uint32_t t0 = gs;
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)dincl, 63);  // entries of the group
   const bool staged = n <= (uint32_t)GG_FB_VCAP;  // uniform
   if (staged) base -= t0;                         // positions inside the stage
+#pragma unroll 1
   for (uint32_t cg = 0; cg < nch; cg += FB_VCG) {
     const uint32_t ncg = nch - cg < (uint32_t)FB_VCG ? nch - cg : (uint32_t)FB_VCG;
-    // offset rows of the chunks of this round, eight loads in flight
-    for (uint32_t c0 = 0; c0 < ncg; c0 += 8) {
-      uint32_t sv[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        sv[q] = 0;
-        if (c0 + q < ncg && (uint32_t)lane <= vg) sv[q] = offs[(uint64_t)(p0 + cg + c0 + q) * g.ss + k0 + lane];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (uint32_t c = 0; c < ncg; c++) {  // chunk c of the round, lane d < vg: where vertex d starts in it
+      uint32_t sv = 0, first, end;
+      if (cg == 0) {  // parked above
+        if ((uint32_t)lane < vg) sv = s_delta[c * vg + lane];
+        first = s_run[c];
+        end = s_run[FB_VCG + c];
+      } else {
+        if ((uint32_t)lane <= vg) sv = offs[(uint64_t)(p0 + cg + c) * g.ss + k0 + lane];
+        first = (uint32_t)__builtin_amdgcn_readlane((int)sv, 0);
+        end = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)vg);
       }
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        if (c0 + q >= ncg) continue;  // uniform
-        const uint32_t c = c0 + q;
-        const uint32_t nxt = (uint32_t)__shfl_down((int)sv[q], 1, 64);
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)sv[q], 0);
-        if ((uint32_t)lane < vg) {
-          s_delta[c * vg + lane] = base - (sv[q] - first);
-          base += nxt - sv[q];
-        }
-        if (lane == 0) {
-          s_run[c] = first;
-          s_run[FB_VCG + c] = (uint32_t)__builtin_amdgcn_readlane((int)sv[q], (int)vg) - first;
-        }
+      uint32_t nxt = (uint32_t)__shfl_down((int)sv, 1, 64);
+      if ((uint32_t)lane + 1 == vg) nxt = end;
+      if ((uint32_t)lane < vg) {
+        s_delta[c * vg + lane] = base - (sv - first);
+        base += nxt - sv;
+      }
+      if (lane == 0) {
+        s_run[c] = first;
+        s_run[FB_VCG + c] = end - first;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1462,6 +1483,7 @@ __global__ __launch_bounds__(64) void k_vrows(const uint32_t *__restrict__ buf_f
     const uint32_t sincl = wave_scan_incl(st_c);  // (DPP moves, gg_internal.h)
     const uint32_t sexcl = sincl - st_c;
     const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+#pragma unroll 1
     for (uint32_t r = 0; r < T; r += FB_VSTEPS) {
       uint32_t kw[FB_VSTEPS], kx[FB_VSTEPS];
       uint32_t have = 0;
@@ -1625,7 +1647,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_TRY(ctx->dev_alloc((void **)&cstart, (2 * nb + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&part_of, pmax * sizeof(uint4)));
   GG_TRY(ctx->dev_alloc((void **)&offs, pmax * g.ss * sizeof(uint32_t)));
-  GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * g.ss * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&substart, (uint64_t)2 * nb * (g.ss < 64 ? 64 : g.ss) * sizeof(uint32_t)));
   GG_LAUNCH(ctx, "col_partial", k_col_partial, dim3(ngroups), dim3(1024), 0, (const uint32_t *)counts, nblocks64, ncol, gsz,
             partial, coltot);
   GG_LAUNCH(ctx, "col_scan", k_col_scan, dim3(1), dim3(1024), 0, coltot, nb, bstart, cstart, part_of, st);
@@ -1727,14 +1749,16 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
     const unsigned grid_p = (unsigned)(pmax < resident ? pmax : resident);
     GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vsort_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds_v));
+    uint16_t *offs16 = reinterpret_cast<uint16_t *>(offs);  // (rows of nk + 1 16-bit offsets inside the same block)
+    uint32_t *gstart = substart;                            // [2 nb][64]
     GG_LAUNCH(ctx, "sub_sort", k_vsort_pipe, dim3(grid_p), dim3(FB_THREADS), lds_v, part_f, part_r,
-              (const uint32_t *)cstart, (const uint4 *)part_of, g, offs);
-    GG_LAUNCH(ctx, "sub_totals", k_vtotals, dim3(2 * nb), dim3(1024), 0, (const uint32_t *)offs,
-              (const uint32_t *)bstart, (const uint32_t *)cstart, g, V, csr->off, csr->roff);
+              (const uint32_t *)cstart, (const uint4 *)part_of, g, offs16);
+    GG_LAUNCH(ctx, "sub_totals", k_vgroups, dim3(2 * nb), dim3(64), 0, (const uint16_t *)offs16,
+              (const uint32_t *)bstart, (const uint32_t *)cstart, g, gstart);
     const uint32_t nk = 1u << low, vg = nk < (uint32_t)FB_VG ? nk : (uint32_t)FB_VG;
     GG_LAUNCH(ctx, "leaf_rows", k_vrows, dim3((unsigned)(2ull * nb * (nk / vg))), dim3(64), 0, (const uint32_t *)part_f,
-              (const uint32_t *)part_r, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint32_t *)offs, g, V,
-              (const uint32_t *)csr->off, csr->nbr, (const uint32_t *)csr->roff, csr->rnbr, csr->rrow);
+              (const uint32_t *)part_r, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint16_t *)offs16,
+              (const uint32_t *)gstart, g, V, csr->off, csr->nbr, csr->roff, csr->rnbr, csr->rrow);
   } else if (g.pack && rowid) {
     GG_FB_LAUNCH_B2(true, true);
   } else if (g.pack && g.rank_atomic && GG_FB_SUBPIPE) {
