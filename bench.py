@@ -43,9 +43,14 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
-# v_xad_u32 (xor + add, one per walk in k_expand_mid2) issues once per 4.9 cycles per wave on gfx950
-# (scripts/ubench_valu.hip): 256 CUs x 4 SIMDs x 64 lanes x 2.4e9 / 4.9 lane-ops per second
-VALU_XAD_PEAK = 256 * 4 * 64 * 2.4e9 / 4.9
+# v_xad_u32 (xor + add, one per walk in k_expand_mid2): measured issue rate on this part, the counted loop holding
+# nothing but the instruction (scripts/ubench_valu.hip -> profiles/r03_ubench_valu.txt): 4.38 cycles per wave-instruction
+# and SIMD with 8 waves per SIMD (8.9 with one wave), the same with the state in a scalar register (4.28) — every
+# three-source VOP3 runs at that rate (v_add3_u32 4.24), two-source VOP2 instructions at 2.3-2.4 (v_add_u32, v_xor_b32,
+# v_fma_f32: the guide's 2-cycle row), so xor + add as two instructions costs 2 x 2.48 = 4.96: the fused form is the
+# cheapest way to take one walk.  Peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4e9 / 4.38 = 35.9 T lane-ops/s.
+VALU_XAD_CYCLES = 4.38
+VALU_XAD_PEAK = 256 * 4 * 64 * 2.4e9 / VALU_XAD_CYCLES
 MASK64 = (1 << 64) - 1
 PROFILE_TAG = "r02"
 
@@ -246,13 +251,14 @@ def extra_materialised(pkg, orc, device):
     prof = gg.profile_get()
     rows = res.rows(2)
     written = rows * 24
-    k = prof.get("mat_last", (0, 0.0))
+    kname = "mat_mid2" if prof.get("mat_mid2", (0, 0.0))[0] else "mat_last"
+    k = prof.get(kname, (0, 0.0))
     out = {"workload": "LDBC SNB SF10 Person-KNOWS-Person-KNOWS-Person, all persons as sources, rows materialised in HBM "
                        "(3 int64 id columns)",
            "rows": rows, "bytes_written": written, "wall_ms": dt * 1e3,
            "kernels_ms": {n: v[1] for n, v in prof.items() if v[1] > 0.02}}
     if k[0]:
-        out["roofline"] = {"bound": "hbm", "kernel": "mat_last", "achieved": written / (k[1] * 1e-3) / 1e9,
+        out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": written / (k[1] * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": written / (k[1] * 1e-3) / HBM_PEAK,
                            "traffic": None, "avg_launch_ms": k[1] / k[0],
                            "note": "bytes actually written by the kernel (rows x 3 x 8) over its time"}
@@ -270,6 +276,50 @@ def extra_materialised(pkg, orc, device):
     g.close()
     csr.close()
     gg.close()
+    return out
+
+
+def extra_materialised_parts(gg, csr, counted, budget_gb=16.0):
+    """SF100 2-hop MATCH with the rows written to HBM: 12.8 G rows x 3 int64 columns = 306 GB do not fit 288 GB, so
+    the result is produced part by part — middle-vertex ranges of near-equal work (gg_khop_partition_mid), each
+    through the product kernel (gg_expand_khop_mid_result), handed over and freed — the way the substituted join
+    streams it (host/gg_operators.cpp).  Timed: expansion calls only (count + materialise per part); the digest of
+    every part's rows (gg_result_digest, all rows, device-side) is taken outside the timed region and must add up to
+    the count-mode expansion's."""
+    total_rows = counted["rows"][2]
+    n_parts = max(1, int(np.ceil(total_rows * 24 / (budget_gb * 2**30))))
+    bounds = gg.khop_partition_mid(csr, n_parts)
+    gg.profile_reset()
+    gg.profile_select(["mat_mid2"])
+    gg.profile(True)
+    rows = dig = 0
+    t_total = 0.0
+    import torch
+
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = gg.expand_khop_mid_result(csr, lo, hi, k_min=2)
+        torch.cuda.synchronize()  # (the materialising kernel is launched asynchronously)
+        t_total += time.perf_counter() - t0
+        n, d = res.digest(csr, 2)
+        rows += n
+        dig = (dig + d) & 0xFFFFFFFF
+        res.close()
+    gg.profile(False)
+    prof = gg.profile_get()
+    k = prof.get("mat_mid2", (0, 0.0))
+    out = {"workload": "LDBC SNB SF100 Person-KNOWS-Person-KNOWS-Person, all persons as sources, rows materialised in HBM "
+                       f"in {n_parts} middle-vertex parts of <= {budget_gb:.0f} GiB (3 int64 id columns each)",
+           "parts": n_parts, "rows": rows, "bytes_written": rows * 24, "wall_s": t_total,
+           "rows_per_s": rows / t_total, "bytes_per_s": rows * 24 / t_total,
+           "parity": bool(rows == total_rows and dig == counted["digest"][2]),
+           "parity_note": "sum over the parts of rows and of the device-side digests of all materialised rows == count-mode expansion"}
+    if k[0]:
+        out["roofline"] = {"bound": "hbm", "kernel": "mat_mid2", "achieved": rows * 24 / (k[1] * 1e-3) / 1e9,
+                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": rows * 24 / (k[1] * 1e-3) / HBM_PEAK,
+                           "traffic": None, "avg_launch_ms": k[1] / k[0], "launches": k[0],
+                           "note": "bytes written by the kernel (rows x 3 x 8) over its time, all parts"}
     return out
 
 
@@ -534,6 +584,7 @@ def main():
                 if args.workload == "sf100":
                     c = gg.build_csr()
                     extra["bfs64"] = extra_bfs64(pkg, gg, c, vid, oracle_graph)
+                    extra["materialised_sf100_parts"] = extra_materialised_parts(gg, c, gg.expand_khop(c, 2, 2))
                     c.close()
                 if oracle_graph is not None:
                     oracle_graph.close()

@@ -1269,6 +1269,164 @@ int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
   return GG_OK;
 }
 
+// ---- 2-hop rows as a join product, materialised ----------------------------------------------------------------
+// The materialising counterpart of k_expand_mid2 for walks from EVERY vertex: the rows u -> x -> w through a middle
+// vertex x are in(x) x out(x), and the reverse CSR lists the 1-hop rows u -> x grouped by x.  k_mat_last, one parent
+// row at a time in source order, translates every child to its id — a random 8-byte gather per OUTPUT row (1.06 G at
+// SF10, more time than the stores).  Here the ids of out(x) are gathered once per run of equal x (E gathers in all),
+// kept in registers, and every reverse entry of the run writes them behind its own (u, x) — stores only.  Row order
+// of a materialised result is unspecified (gg.h), so grouping the rows by middle vertex is the caller's right.
+// A tile is 256 consecutive reverse entries; the four waves share every run (entry i of a run goes to wave i mod 4).
+// Stores are 16 bytes per lane (two rows of one column); a row block that starts at an odd row writes its first row
+// singly and pairs up from the second (the same ids, paired the other way: both pairings are kept in registers).
+__global__ __launch_bounds__(256) void k_mat_mid2_prepare(const uint32_t *__restrict__ off, const uint32_t *__restrict__ rrow,
+                                                          uint64_t e0, uint64_t n, uint64_t *__restrict__ foff) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t x = rrow[e0 + i];
+    foff[i] = (uint64_t)(off[x + 1] - off[x]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                  const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
+                                                  const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
+                                                  uint64_t e0, uint64_t n, int64_t *__restrict__ c0,
+                                                  int64_t *__restrict__ c1, int64_t *__restrict__ c2) {
+  typedef long long ll2 __attribute__((ext_vector_type(2)));
+  __shared__ int64_t s_uid[256];
+  __shared__ uint64_t s_base[256];
+  __shared__ uint32_t s_x[256], s_run[257], s_wcnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < n;
+  uint32_t x = INVALID_U32;
+  if (valid) {
+    x = rrow[e0 + p];
+    s_uid[threadIdx.x] = vid[rnbr[e0 + p]];
+    s_base[threadIdx.x] = foff[p];
+  }
+  s_x[threadIdx.x] = x;
+  __syncthreads();
+  const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
+  const uint64_t hm = __ballot(head);
+  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
+  __syncthreads();
+  uint32_t before = 0, nruns = 0;
+  for (int q = 0; q < 4; q++) {
+    if (q < wave) before += s_wcnt[q];
+    nruns += s_wcnt[q];
+  }
+  if (head) s_run[before + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
+  if (threadIdx.x == 0) {
+    const uint64_t left = n - (uint64_t)blockIdx.x * 256;
+    s_run[nruns] = left < 256 ? (uint32_t)left : 256u;
+  }
+  __syncthreads();
+  for (uint32_t r = 0; r < nruns; r++) {
+    const uint32_t i0 = s_run[r], i1 = s_run[r + 1];
+    const uint32_t xr = s_x[i0], st = off[xr], dout = off[xr + 1] - st;
+    if (dout == 0 || i0 + wave >= i1) continue;  // (uniform per wave)
+    const long long xid = vid[xr];
+    // (several entries side by side in one store instruction for short out-rows — 64 / ppe entries of (dout + 1) / 2
+    // lane pairs each — was slower: 7.7 against 6.6 ms at SF10; the per-lane entry look-ups cost more than the
+    // half-empty stores)
+    for (uint32_t jb = 0; jb < dout; jb += 128) {
+      // leaves jb + 2 lane .. + 2 of the out-row, as ids: (e0, e1) is the pair of an even row block, (e1, o1) of an odd
+      const uint32_t k = jb + 2 * (uint32_t)lane;
+      const long long e0v = k < dout ? vid[nbr[st + k]] : 0;
+      const long long e1v = k + 1 < dout ? vid[nbr[st + k + 1]] : 0;
+      const long long o1v = k + 2 < dout ? vid[nbr[st + k + 2]] : 0;
+      for (uint32_t i = i0 + wave; i < i1; i += 4) {
+        const uint64_t B = s_base[i];  // first output row of this entry's block (uniform)
+        const long long uid = s_uid[i];
+        ll2 uu, xx;
+        uu.x = uu.y = uid;
+        xx.x = xx.y = xid;
+        if ((B & 1) == 0) {  // rows B + k, B + k + 1: aligned pair
+          const uint64_t o = B + k;
+          if (k + 1 < dout) {
+            ll2 w;
+            w.x = e0v;
+            w.y = e1v;
+            __builtin_nontemporal_store(w, reinterpret_cast<ll2 *>(c2 + o));
+            __builtin_nontemporal_store(uu, reinterpret_cast<ll2 *>(c0 + o));
+            __builtin_nontemporal_store(xx, reinterpret_cast<ll2 *>(c1 + o));
+          } else if (k < dout) {  // odd last row
+            c2[o] = e0v;
+            c0[o] = uid;
+            c1[o] = xid;
+          }
+        } else {  // the block starts at an odd row: rows B + k + 1, B + k + 2 pair up
+          const uint64_t o = B + k + 1;
+          if (k + 2 < dout) {
+            ll2 w;
+            w.x = e1v;
+            w.y = o1v;
+            __builtin_nontemporal_store(w, reinterpret_cast<ll2 *>(c2 + o));
+            __builtin_nontemporal_store(uu, reinterpret_cast<ll2 *>(c0 + o));
+            __builtin_nontemporal_store(xx, reinterpret_cast<ll2 *>(c1 + o));
+          } else if (k + 1 < dout) {  // last row, alone
+            c2[o] = e1v;
+            c0[o] = uid;
+            c1[o] = xid;
+          }
+          if (jb == 0 && lane == 0) {  // first row of the block, alone (later J-blocks: the pair before covers it)
+            c2[B] = e0v;
+            c0[B] = uid;
+            c1[B] = xid;
+          }
+        }
+      }
+    }
+  }
+}
+
+// 2-hop rows (and, with k_min == 1, the 1-hop rows) whose MIDDLE vertex lies in [mid_lo, mid_hi), through
+// k_mat_mid2; the whole graph for [0, V).  The 1-hop table of a middle range holds the edges INTO the range.
+int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, gg_result *res) {
+  GG_TRY(ensure_reverse(ctx, csr));
+  uint64_t e0 = 0, n = csr->E_rev;
+  if (!(mid_lo == 0 && mid_hi == csr->V)) {
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, csr->roff + mid_lo, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch + 1, csr->roff + mid_hi, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t ends[2];
+    memcpy(&ends[0], ctx->pin_scratch, sizeof(uint32_t));
+    memcpy(&ends[1], ctx->pin_scratch + 1, sizeof(uint32_t));
+    e0 = ends[0];
+    n = (uint64_t)ends[1] - ends[0];
+  }
+  uint64_t *foff = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&foff, (n + 1) * sizeof(uint64_t)));
+  if (n)
+    GG_LAUNCH(ctx, "mat_mid2_prepare", k_mat_mid2_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, csr->off,
+              csr->rrow, e0, n, foff);
+  uint64_t M2 = 0;
+  GG_TRY(offsets_from_deg(ctx, foff, n, &M2));
+  res->rows[2] = M2;
+  for (int c = 0; c <= 2; c++) {
+    GG_TRY(ctx->dev_alloc((void **)&res->cols[2][c], (M2 ? M2 : 1) * sizeof(int64_t)));
+    ctx->keep(res->cols[2][c]);
+  }
+  if (M2)
+    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
+              csr->rnbr, csr->vid, (const uint64_t *)foff, e0, n, res->cols[2][0], res->cols[2][1], res->cols[2][2]);
+  if (k_min <= 1) {
+    res->rows[1] = n;
+    for (int c = 0; c <= 1; c++) {
+      GG_TRY(ctx->dev_alloc((void **)&res->cols[1][c], (n ? n : 1) * sizeof(int64_t)));
+      ctx->keep(res->cols[1][c]);
+      if (n)
+        GG_LAUNCH(ctx, "gather_ids", k_gather_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                  (c ? csr->rrow : csr->rnbr) + e0, csr->vid, n, res->cols[1][c]);
+    }
+  }
+  ctx->dev_free(foff);
+  return GG_OK;
+}
+
 // materialise walks as int64 id columns (correctness config; level-by-level)
 int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64_t n0, int k_min, int k_max,
                      gg_result *res) {
@@ -1431,13 +1589,19 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
     res->k_max = k_max;
     uint32_t *fv = nullptr;
     uint64_t *fdeg = nullptr;
-    int rc = ctx->dev_alloc((void **)&fv, (n0 ? n0 : 1) * sizeof(uint32_t));
-    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&fdeg, (n0 ? n0 : 1) * sizeof(uint64_t));
-    if (rc == GG_OK && n0) {
-      hipLaunchKernelGGL(k_iota_deg, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)src_lo,
-                         n0, csr->off, fv, fdeg);
+    int rc = GG_OK;
+    if (k_max == 2 && src_lo == 0 && src_hi == csr->V && !ctx->force_frontier) {
+      // every vertex is a source: the rows are the per-vertex products in(x) x out(x), grouped by x (k_mat_mid2)
+      rc = khop_materialise_mid2(ctx, const_cast<gg_csr *>(csr), 0, csr->V, k_min, res);
+    } else {
+      rc = ctx->dev_alloc((void **)&fv, (n0 ? n0 : 1) * sizeof(uint32_t));
+      if (rc == GG_OK) rc = ctx->dev_alloc((void **)&fdeg, (n0 ? n0 : 1) * sizeof(uint64_t));
+      if (rc == GG_OK && n0) {
+        hipLaunchKernelGGL(k_iota_deg, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)src_lo,
+                           n0, csr->off, fv, fdeg);
+      }
+      if (rc == GG_OK) rc = khop_materialise(ctx, csr, fv, n0, k_min, k_max, res);
     }
-    if (rc == GG_OK) rc = khop_materialise(ctx, csr, fv, n0, k_min, k_max, res);
     ctx->dev_free(fv);
     ctx->dev_free(fdeg);
     if (rc != GG_OK) {
@@ -1562,6 +1726,29 @@ extern "C" int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uin
   if (mid_lo > mid_hi) mid_lo = mid_hi;
   GG_HIP(hipSetDevice(ctx->device));
   return khop_count_mid(ctx, csr, mid_lo, mid_hi, k_min, stats);
+}
+
+extern "C" int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min,
+                                         gg_khop_stats *stats, gg_result **out_result) {
+  ApiScope scope(ctx);
+  GG_TRY(check_args(ctx, csr, k_min, 2, stats));
+  if (!out_result || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
+  *out_result = nullptr;
+  if (mid_hi > csr->V) mid_hi = csr->V;
+  if (mid_lo > mid_hi) mid_lo = mid_hi;
+  GG_HIP(hipSetDevice(ctx->device));
+  GG_TRY(khop_count_mid(ctx, csr, mid_lo, mid_hi, k_min, stats));
+  gg_result *res = new gg_result();
+  res->ctx = ctx;
+  res->k_min = k_min;
+  res->k_max = 2;
+  const int rc = khop_materialise_mid2(ctx, csr, mid_lo, mid_hi, k_min, res);
+  if (rc != GG_OK) {
+    gg_result_destroy(res);
+    return rc;
+  }
+  *out_result = res;
+  return GG_OK;
 }
 
 extern "C" int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds) {

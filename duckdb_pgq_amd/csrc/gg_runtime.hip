@@ -43,6 +43,13 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
   std::lock_guard<std::mutex> lk(pool_mu);
   if (bytes == 0) bytes = 256;
   bytes = (bytes + 255) & ~size_t(255);
+  if (bytes >= (size_t(64) << 20)) {
+    // large blocks in steps of an eighth of their power of two: results produced part by part (near-equal parts of
+    // several GB each) then recycle one set of blocks instead of growing the pool by a slightly larger set per part
+    size_t step = size_t(1) << 26;
+    while ((step << 4) <= bytes) step <<= 1;
+    bytes = (bytes + step - 1) / step * step;
+  }
   int best = -1;
   for (size_t i = 0; i < blocks.size(); i++) {
     if (!blocks[i].in_use && blocks[i].size >= bytes && blocks[i].size <= bytes * 2 + (1u << 20)) {

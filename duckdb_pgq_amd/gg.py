@@ -17,7 +17,7 @@ SYMBOLS = [
     "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
-    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid",
+    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_debug_max_grid_tiles", "gg_debug_reset",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
@@ -92,6 +92,7 @@ def load_library(path: str | None = None):
     lib.gg_khop_partition.argtypes = [P, P, C.c_int, C.POINTER(u64)]
     lib.gg_expand_khop_mid.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.POINTER(KhopStats)]
     lib.gg_khop_partition_mid.argtypes = [P, P, C.c_int, C.POINTER(u64)]
+    lib.gg_expand_khop_mid_result.argtypes = [P, P, u64, u64, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_debug_force_frontier.argtypes = [P, C.c_int]
     lib.gg_debug_force_legacy_build.argtypes = [P, C.c_int]
     lib.gg_debug_rank_mode.argtypes = [P, C.c_int]
@@ -414,6 +415,13 @@ class GG:
         st = KhopStats()
         self._chk(self.lib.gg_expand_khop_mid(self.ctx, csr.handle, lo, hi, k_min, k_max, C.byref(st)))
         return self._stats_dict(st)
+
+    def expand_khop_mid_result(self, csr: Csr, lo: int, hi: int, k_min: int = 2) -> "KhopResult":
+        """The 2-hop rows (k_min == 1: also the 1-hop rows) with the middle vertex in [lo, hi), materialised in HBM."""
+        st = KhopStats()
+        res = C.c_void_p()
+        self._chk(self.lib.gg_expand_khop_mid_result(self.ctx, csr.handle, lo, hi, k_min, C.byref(st), C.byref(res)))
+        return KhopResult(self, res, self._stats_dict(st))
 
     def khop_partition_mid(self, csr: Csr, n_parts: int):
         b = (C.c_uint64 * (n_parts + 1))()

@@ -165,6 +165,12 @@ int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bou
  * multi-GPU sharding entry point of the 2-hop product kernel (reads each CSR row once per shard). */
 int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, int k_max,
                        gg_khop_stats *stats);
+/* The same rows MATERIALISED (int64 id columns in HBM, fetched with gg_result_fetch): the 2-hop rows u -> x -> w of
+ * all sources with x in [mid_lo, mid_hi) and, if k_min == 1, the 1-hop rows u -> x into the range.  Disjoint ranges
+ * partition the materialised result of gg_expand_khop(all sources, k_min..2) — how a result larger than device
+ * memory (SF100: 12.8 G rows, 306 GB) is produced part by part, each part through the product kernel. */
+int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min,
+                              gg_khop_stats *stats, gg_result **out_result);
 /* Split [0,V) into n_parts contiguous middle-vertex ranges of near-equal product work. */
 int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds);
 

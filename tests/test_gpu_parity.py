@@ -178,6 +178,51 @@ def test_digest_of_materialised_rows_equals_the_count_mode_digest(gg, orc):
     g.close()
 
 
+def test_two_hop_rows_by_middle_vertex_ranges_partition_the_materialised_result(gg, orc):
+    """The product form of the materialising expansion (k_mat_mid2: rows grouped by middle vertex, the ids of out(x)
+    gathered once per run): the whole result equals the join formulation's rows as a sorted multiset; middle-vertex
+    ranges partition it (rows and digests add up, the 1-hop tables are the edges into each range); odd and even row
+    blocks, out-rows longer than one 128-leaf block, vertices without out- or in-edges."""
+    rng = np.random.default_rng(5)
+    V, E = 700, 9000
+    vid = np.arange(V, dtype=np.int64) * 7 + 11
+    s, d = rng.integers(0, V - 50, E), rng.integers(0, V - 50, E)  # the last 50 vertices stay isolated
+    s[:600] = 3   # a hub with an out-row of ~600 leaves (five 128-leaf blocks)
+    d[600:1100] = 5  # and one with ~500 in-edges
+    for vtx, deg, at in ((40, 127, 1200), (41, 128, 1400), (42, 129, 1600), (43, 1, 1800), (44, 2, 1810)):
+        s[at:at + deg] = vtx  # out-rows right at the boundary between the two store forms (one lane pair .. 128 leaves)
+    keep = ~np.isin(s, (40, 41, 42, 43, 44))
+    keep[1200:1327] = keep[1400:1528] = keep[1600:1729] = keep[1800:1801] = keep[1810:1812] = True
+    s, d = s[keep], d[keep]
+    d[:5] = (40, 41, 42, 43, 44)  # every one of them has an in-edge, so their products are not empty
+    src, dst = vid[s], vid[d]
+    csr, g = build_both(gg, orc, vid, src, dst)
+    ref = orc.khop_join(vid, src, dst, 1, 2)
+    whole = gg.expand_khop(csr, 1, 2, materialise=True)
+    for h in (1, 2):
+        assert np.array_equal(sort_rows(whole["tables"][h]), sort_rows(vid[ref[h]]))
+    counted = gg.expand_khop(csr, 1, 2)
+    bounds = [0, 4, 5, 6, 300, 301, V]
+    rows = {1: [], 2: []}
+    dig = {1: 0, 2: 0}
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        res = gg.expand_khop_mid_result(csr, lo, hi, k_min=1)
+        for h in (1, 2):
+            n, dgst = res.digest(csr, h)
+            assert n == res.rows(h) == res.stats["rows"][h] and dgst == res.stats["digest"][h]
+            dig[h] = (dig[h] + dgst) & 0xFFFFFFFF
+            got = [res.fetch(h, o) for o in range(0, n, 1024)]
+            if got:
+                rows[h].append(np.concatenate(got))
+        res.close()
+    for h in (1, 2):
+        allrows = np.concatenate(rows[h])
+        assert np.array_equal(sort_rows(allrows), sort_rows(vid[ref[h]]))
+        assert dig[h] == counted["digest"][h]
+    csr.close()
+    g.close()
+
+
 def test_khop_source_list(gg, orc):
     vid, src, dst = datagen.ldbc_knows(2000, 60_000, 5)
     csr, g = build_both(gg, orc, vid, src, dst)
