@@ -45,39 +45,19 @@ constexpr int FB_MAX_HB = 10;                    // bucket bits
 #ifndef GG_FB_LOAD_PCT
 #define GG_FB_LOAD_PCT 50                        // load factor of the packed dictionary, percent
 #endif
-#ifndef GG_FB_NT
-#define GG_FB_NT 1                               // streamed columns bypass the caches' retention (nt loads/stores)
-#endif
-#ifndef GG_FB_SUBNT
-#define GG_FB_SUBNT 0
-#endif
 #ifndef GG_FB_SUBPIPE
 #define GG_FB_SUBPIPE 2  // workgroups per CU of the pipelined k_sub_sort_pipe: its resident set (0: k_sub_sort, one chunk per workgroup)
-#endif
-#ifndef GG_FB_XCD
-#define GG_FB_XCD 1                              // A: consecutive tiles on one XCD (short runs merge in its L2)
 #endif
 
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T *p) {
-#if GG_FB_NT
   return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void st_stream(T *p, T v) {
-#if GG_FB_NT
   __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
 }
 
-#ifndef GG_FB_MATCH_OR
-#define GG_FB_MATCH_OR 0
-#endif
 // Match mask: which lanes of the wave hold the same small value d as this lane.  Every lane ORs its bit
 // into the wave's private 64-bit LDS word of d and reads the word back (LDS executes a wave's instructions in
 // order, and OR commutes, so the mask is exact whatever order the lanes of one instruction are served in);
@@ -264,14 +244,7 @@ __device__ __forceinline__ void densify_tile(const int64_t *__restrict__ src, co
   }
 }
 
-#ifndef GG_FB_DWAVES
-#define GG_FB_DWAVES 0
-#endif
-#if GG_FB_DWAVES
-#define GG_FB_DATTR __attribute__((amdgpu_waves_per_eu(GG_FB_DWAVES, GG_FB_DWAVES)))
-#else
 #define GG_FB_DATTR
-#endif
 template <bool PROBE = false>  // PROBE: timing probe without dictionary lookups (its output is overwritten)
 __global__ __launch_bounds__(FB_THREADS) GG_FB_DATTR void k_densify_pairs(
     const int64_t *__restrict__ src, const int64_t *__restrict__ dst, uint64_t E, const HtSlot *__restrict__ ht,
@@ -319,22 +292,12 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
   uint32_t *gb = dbase + nb;                            // [nb] global position of the bucket's staged slot 0, minus dbase
   uint32_t *misc = gb + nb;                             // [FB_WAVES + 2]
   uint16_t *xd = reinterpret_cast<uint16_t *>(misc + FB_WAVES + 2);  // staged bucket numbers
-#if GG_FB_MATCH_OR
-  unsigned long long *mm_all = reinterpret_cast<unsigned long long *>(
-      lds + (((size_t)(misc + FB_WAVES + 2 - lds) + FB_TILE / 2 + 1) & ~(size_t)1));  // [FB_WAVES][nb], 8-byte aligned
-  unsigned long long *mm = mm_all + (size_t)(threadIdx.x >> 6) * nb;
-  for (uint32_t i = threadIdx.x; i < FB_WAVES * nb; i += FB_THREADS) mm_all[i] = 0ULL;
-#endif
 
-#if GG_FB_XCD
   // blocks b and b + 8 share an XCD (speed only): give each XCD a contiguous range of tiles, so the short
   // runs that neighbouring tiles append to one bucket meet in one L2 before they are written back
   const uint64_t chunk = (nblocks + 7) / 8;
   const uint64_t tile = (uint64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tile >= nblocks) return;
-#else
-  const uint64_t tile = blockIdx.x;
-#endif
   const uint64_t tile_base = tile * FB_TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t low_mask = (1u << g.low) - 1u;
@@ -465,14 +428,10 @@ __global__ __launch_bounds__(FB_THREADS) void k_partition_dual(
             counted = true;
           }
         } else {
-#if GG_FB_MATCH_OR
-          m = match_or(mm, d, valid, lane);
-#else
           for (uint32_t bit = 0; bit < g.hb; bit++) {  // match mask: same bucket within the wave
             const uint64_t bb = __ballot((d >> bit) & 1u);
             m &= ((d >> bit) & 1u) ? bb : ~bb;
           }
-#endif
         }
         if (valid) {
           if (!counted) pos = cur[d] + __popcll(m & lane_lt);
@@ -534,9 +493,6 @@ static_assert(FB_MAX_SUB == 6 || FB_MAX_SUB == 7, "one or two sub-buckets per la
 #define GG_FB_LEAF_WAVES 1  // (4 leaves per workgroup hold their LDS until the largest is done: 366 us against 349 at SF100)
 #endif
 constexpr int LEAF_WAVES = GG_FB_LEAF_WAVES;  // waves (= leaves) per workgroup of k_leaf_rows
-#ifndef GG_FB_LEAF_READLANE
-#define GG_FB_LEAF_READLANE 1
-#endif
 #ifndef GG_FB_LEAF_MAXS
 #define GG_FB_LEAF_MAXS 24
 #endif
@@ -767,11 +723,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_sub_sort(uint32_t *__restrict__ 
     ep[it] = 0;
     if (e < c1) {
       if (PACK) {
-#if GG_FB_SUBNT
-        w[it] = ld_stream(buf + e);
-#else
         w[it] = buf[e];
-#endif
         k[it] = w[it] >> g.key_bits;
       } else {
         const uint2 x = reinterpret_cast<const uint2 *>(buf)[e];
@@ -985,19 +937,7 @@ __global__ __launch_bounds__(64) void k_sub_totals(const uint32_t *__restrict__ 
   if (lane == 0 && j == nb - 1 && ((uint64_t)nb << g.low) == V) (dir ? roff : off)[V] = bstart[dir * (nb + 1) + nb];
 }
 
-#ifdef GG_FB_LEAF_STAMPS  // diagnostic build: shader-clock stamps of a leaf's phases (scripts/leaf_stamps.py)
-#define GG_STAMP(k)                                                                        \
-  do {                                                                                     \
-    unsigned long long t_;                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (gg_leaf_stamps && (threadIdx.x & 63) == 0) gg_leaf_stamps[(uint64_t)unit * 8 + (k)] = t_; \
-  } while (0)
-__device__ unsigned long long *gg_leaf_stamps = nullptr;
-#else
 #define GG_STAMP(k)
-#endif
 
 template <bool PACK, bool ROWID>
 __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const uint32_t *__restrict__ buf_f,
@@ -1064,30 +1004,20 @@ __device__ __forceinline__ void leaf_unit(uint32_t unit, uint32_t *lds, const ui
             if (ROWID) ew[ROWID ? q : 0] = 0;
             if (t < T) {  // uniform
               const int cc = __popcll(__ballot(sincl <= t));  // the run this step belongs to (< 64: t < T)
-#if GG_FB_LEAF_READLANE
               // (the run is the same for every lane: v_readlane into scalar registers, no ds_bpermute before the load)
               const uint32_t kidx = (t - (uint32_t)__builtin_amdgcn_readlane((int)sexcl, cc)) * 64 + lane;
               const uint32_t run_src = (uint32_t)__builtin_amdgcn_readlane((int)src, cc);
               const uint32_t run_len = (uint32_t)__builtin_amdgcn_readlane((int)len, cc);
               const uint32_t e = run_src + kidx;
               if (kidx < run_len) {
-#else
-              const uint32_t kidx = (t - (uint32_t)__shfl(sexcl, cc, 64)) * 64 + lane;
-              const uint32_t e = (uint32_t)__shfl(src, cc, 64) + kidx;
-              if (kidx < (uint32_t)__shfl(len, cc, 64)) {
-#endif
                 have |= 1u << q;
                 if (PACK) {
-#if GG_FB_LEAF_READLANE
                   // the run as a buffer of its own (scalar 64-bit base: partitions of more than 2^30 entries are
                   // fine, the vector offset stays inside one chunk)
                   kw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
                       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(buf + run_src), 0, (int)(run_len * 4u),
                                                         0x00020000),
                       kidx * 4u, 0, 0);
-#else
-                  kw[q] = buf[e];
-#endif
                 } else {
                   const uint2 x = reinterpret_cast<const uint2 *>(buf)[e];
                   kw[q] = x.x;
@@ -1564,11 +1494,8 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_TRY(lds_order_ok(ctx, &g.rank_atomic));
   // up to 2^(FB_MAX_HB + FB_VLOW) vertices, packed words, no edge positions, cursor ranks: the chunks are sorted by
   // vertex and the rows step only copies (k_vsort_pipe / k_vtotals / k_vrows)
-#ifndef GG_FB_VSORT
-#define GG_FB_VSORT 1
-#endif
   const bool want_rowid = ctx->keep_edge_rowid && csr->n_parts <= 1;
-  const bool vsort = GG_FB_VSORT && g.rank_atomic && !want_rowid && kb <= FB_MAX_HB + FB_VLOW && kb <= 20;
+  const bool vsort = 1 && g.rank_atomic && !want_rowid && kb <= FB_MAX_HB + FB_VLOW && kb <= 20;
   if (vsort) {
     low = kb < FB_VLOW ? kb : FB_VLOW;
     hb = kb - low;
@@ -1586,7 +1513,6 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   *taken = 1;
   const uint32_t nb = 1u << hb;
   const bool rowid = ctx->keep_edge_rowid && csr->n_parts <= 1;  // a shard only serves 2-hop counting and BFS: no rowids
-  hipStream_t s = ctx->stream;
   const uint64_t nblocks64 = (E + FB_TILE - 1) / FB_TILE;
   const unsigned nblocks = (unsigned)nblocks64;
 
@@ -1633,11 +1559,6 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_TRY(ctx->dev_alloc((void **)&counts, ncount * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&bstart, 2 * (nb + 1) * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&total, sizeof(uint64_t)));
-#ifdef GG_FB_PROBES
-  GG_LAUNCH(ctx, "probe_densify_streams", k_densify_pairs<true>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev,
-            ctx->c_dst.dev, E, csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab,
-            (const DirectMap *)dm, pairs, g, nblocks64, counts);
-#endif
   GG_LAUNCH(ctx, "densify_pairs", k_densify_pairs<false>, dim3(nblocks), dim3(FB_THREADS), 0, ctx->c_src.dev, ctx->c_dst.dev, E,
             csr->ht, csr->ht_cap, st, (const uint32_t *)dir, (const unsigned long long *)tab, (const DirectMap *)dm,
             pairs, g, nblocks64, counts);
@@ -1665,37 +1586,14 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   GG_TRY(ctx->dev_alloc((void **)&csr->rrow, E * sizeof(uint32_t)));
   const size_t lds_a = ((size_t)FB_TILE * (words + (rowid ? 1 : 0)) + (size_t)(FB_WAVES + 2) * nb + FB_WAVES + 2) *
                            sizeof(uint32_t) +
-                       (size_t)FB_TILE * sizeof(uint16_t) + 16 + (GG_FB_MATCH_OR ? (size_t)FB_WAVES * nb * 8 : 0);
-#if GG_FB_XCD
+                       (size_t)FB_TILE * sizeof(uint16_t) + 16 + (0 ? (size_t)FB_WAVES * nb * 8 : 0);
   const unsigned grid_a = (unsigned)(((nblocks64 + 7) / 8) * 8);
-#else
-  const unsigned grid_a = nblocks;
-#endif
 #define GG_FB_LAUNCH_A(P, R)                                                                                        \
   GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<P, R>),                                 \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));                                \
   GG_LAUNCH(ctx, "partition_dual", (k_partition_dual<P, R>), dim3(grid_a), dim3(FB_THREADS), lds_a,                  \
             (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r, \
             epos_f)
-#ifdef GG_FB_PROBES
-  if (g.pack && !rowid) {
-    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-    GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_partition_dual<true, false, 3>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-    GG_LAUNCH(ctx, "probe_A_loads", (k_partition_dual<true, false, 1>), dim3(grid_a), dim3(FB_THREADS), lds_a,
-              (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f);
-    GG_LAUNCH(ctx, "probe_A_counts", (k_partition_dual<true, false, 2>), dim3(grid_a), dim3(FB_THREADS), lds_a,
-              (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f);
-    GG_LAUNCH(ctx, "probe_A_rank", (k_partition_dual<true, false, 3>), dim3(grid_a), dim3(FB_THREADS), lds_a,
-              (const u32x2 *)pairs, E, g, nblocks64, (const uint32_t *)counts, (const BuildStatus *)st, part_f, part_r,
-              epos_f);
-  }
-#endif
   if (g.pack && rowid) {
     GG_FB_LAUNCH_A(true, true);
   } else if (g.pack) {
@@ -1730,19 +1628,6 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
       GG_FB_LAUNCH_B(P, R, 1);     \
     }                              \
   } while (0)
-#ifdef GG_FB_PROBES
-  if (g.pack && !rowid && g.sub <= 6) {
-#define GG_FB_PROBE_S(N, NAME)                                                                                         \
-  GG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sub_sort<true, false, 1, N>),                          \
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                 \
-  GG_LAUNCH(ctx, NAME, (k_sub_sort<true, false, 1, N>), dim3((unsigned)pmax), dim3(FB_THREADS), lds_s, part_f, part_r, \
-            epos_f, (const uint32_t *)bstart, (const uint32_t *)cstart, (const uint4 *)part_of, g, offs)
-    GG_FB_PROBE_S(1, "probe_S_loads");
-    GG_FB_PROBE_S(2, "probe_S_counts");
-    GG_FB_PROBE_S(3, "probe_S_rank");
-#undef GG_FB_PROBE_S
-  }
-#endif
   if (vsort) {
     const size_t lds_v = ((size_t)FB_WAVES * (1u << low) + FB_TILE) * sizeof(uint32_t);
     const uint64_t resident = (uint64_t)ctx->num_cus * 2;
@@ -1793,25 +1678,6 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
 #undef GG_FB_LAUNCH_B2
 #undef GG_FB_LAUNCH_B
 
-#ifdef GG_FB_LEAF_STAMPS
-  if (const char *path = getenv("GG_LEAF_STAMPS_FILE")) {  // (the stamps of the build that just ran are of its LAST leaf launch)
-    static unsigned long long *dev = nullptr;
-    const size_t n = (size_t)grid_l * LEAF_WAVES * 8;
-    if (!dev) {
-      GG_HIP(hipMalloc((void **)&dev, n * sizeof(unsigned long long)));
-      GG_HIP(hipMemset(dev, 0, n * sizeof(unsigned long long)));
-      GG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gg_leaf_stamps), &dev, sizeof(dev)));
-    } else {
-      std::vector<unsigned long long> host(n);
-      GG_HIP(hipStreamSynchronize(s));
-      GG_HIP(hipMemcpy(host.data(), dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      if (FILE *f = fopen(path, "wb")) {
-        fwrite(host.data(), sizeof(unsigned long long), n, f);
-        fclose(f);
-      }
-    }
-  }
-#endif
   for (void *p : {(void *)dir, (void *)tab, (void *)pairs, (void *)counts, (void *)bstart, (void *)total,
                   (void *)part_f, (void *)part_r, (void *)epos_f, (void *)cstart, (void *)part_of, (void *)offs,
                   (void *)substart, (void *)partial})

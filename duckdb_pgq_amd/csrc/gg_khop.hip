@@ -251,18 +251,6 @@ __global__ __launch_bounds__(XT) void k_expand_last1(const uint32_t *__restrict_
 // of equal x the out-row is loaded ONCE into registers (64 lanes x MID_R values, coalesced, through a buffer
 // descriptor) and every staged state of the run is folded against it (one 16-byte LDS broadcast read per four
 // states, ONE v_xad_u32 per walk).  The kernel is VALU-bound; HBM/L2 traffic drops to one pass over both CSRs.
-#ifndef GG_MID_PROBE
-#define GG_MID_PROBE 0  // timing probes (wrong digests): 1 states from a scalar counter, no LDS reads; 2 staging only, no fold
-#endif
-#ifndef GG_MID_PIPE
-#define GG_MID_PIPE 2
-#endif
-#ifndef GG_MID_BUFFER
-#define GG_MID_BUFFER 1
-#endif
-#ifndef GG_MID_RUNLANES
-#define GG_MID_RUNLANES 1
-#endif
 #ifndef GG_MID_ISPLIT
 #define GG_MID_ISPLIT 128  // runs of at least this many states are split over the workgroup's waves
 #endif
@@ -281,14 +269,6 @@ __device__ __forceinline__ void mid_fold(uint32_t q, const uint32_t (&t)[MID_R],
 template <int NREG>
 __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int ib, const uint32_t (&t)[MID_R],
                                                uint32_t (&acc)[MID_R]) {
-#if GG_MID_PROBE == 1  // timing probe (wrong digests): scalar states without any load
-  ia = __builtin_amdgcn_readfirstlane(ia);
-  ib = __builtin_amdgcn_readfirstlane(ib);
-  for (int i = ia; i < ib; i++) {
-#pragma unroll
-    for (int r = 0; r < NREG; r++) asm("v_xad_u32 %0, %1, %2, %0" : "+v"(acc[r]) : "s"(i), "v"(t[r]));
-  }
-#elif GG_MID_PIPE
   // the slice bounds are the same in every lane: scalar loop control; states are read four at a time with one
   // 16-byte LDS broadcast read, the next four already in flight while the current ones are folded
   ia = __builtin_amdgcn_readfirstlane(ia);
@@ -296,7 +276,6 @@ __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int 
   int i = ia;
   for (; i < ib && (i & 3); i++) mid_fold<NREG>(s_q[i], t, acc);
   if (i + 4 <= ib) {
-#if GG_MID_PIPE == 2
     // two groups of four per trip with fixed roles (no register copies between trips)
     uint4 c0 = *reinterpret_cast<const uint4 *>(s_q + i);
     for (; i + 12 <= ib; i += 8) {
@@ -325,35 +304,8 @@ __device__ __forceinline__ void mid_accumulate(const uint32_t *s_q, int ia, int 
     mid_fold<NREG>(c0.z, t, acc);
     mid_fold<NREG>(c0.w, t, acc);
     i += 4;
-#else
-    uint4 cur = *reinterpret_cast<const uint4 *>(s_q + i);
-    for (; i + 8 <= ib; i += 4) {
-      const uint4 nxt = *reinterpret_cast<const uint4 *>(s_q + i + 4);
-      mid_fold<NREG>(cur.x, t, acc);
-      mid_fold<NREG>(cur.y, t, acc);
-      mid_fold<NREG>(cur.z, t, acc);
-      mid_fold<NREG>(cur.w, t, acc);
-      cur = nxt;
-    }
-    mid_fold<NREG>(cur.x, t, acc);
-    mid_fold<NREG>(cur.y, t, acc);
-    mid_fold<NREG>(cur.z, t, acc);
-    mid_fold<NREG>(cur.w, t, acc);
-    i += 4;
-#endif
   }
   for (; i < ib; i++) mid_fold<NREG>(s_q[i], t, acc);
-#else
-  int i = ia;
-  for (; i + 4 <= ib; i += 4) {  // 4 states per trip: their LDS broadcast reads issue back to back
-    const uint32_t q0 = s_q[i], q1 = s_q[i + 1], q2 = s_q[i + 2], q3 = s_q[i + 3];
-    mid_fold<NREG>(q0, t, acc);
-    mid_fold<NREG>(q1, t, acc);
-    mid_fold<NREG>(q2, t, acc);
-    mid_fold<NREG>(q3, t, acc);
-  }
-  for (; i < ib; i++) mid_fold<NREG>(s_q[i], t, acc);
-#endif
 }
 
 #ifndef GG_MID_EPT
@@ -485,7 +437,6 @@ __device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *_
                                           uint32_t &corr) {
   uint32_t t[MID_R];
   uint32_t ninv = 0;
-#if GG_MID_BUFFER
   // the out-row as a buffer of dout words (descriptor in scalar registers, the run is the same in every lane): a
   // lane past the row's end reads 0 without a compare or a clamped index, the NREG offsets are immediates
   const __amdgpu_buffer_rsrc_t rsrc =
@@ -496,16 +447,6 @@ __device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *_
     t[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + r * 256u, 0, 0) * DIG_K32;
   const uint32_t left = dout > j0 ? (dout - j0 + 63u) >> 6 : 0u;  // registers of this lane that hold a leaf
   ninv = NREG - (left < (uint32_t)NREG ? left : (uint32_t)NREG);
-#else
-#pragma unroll
-  for (int r = 0; r < NREG; r++) {
-    const uint32_t j = j0 + r * 64;
-    const bool ok = j < dout;
-    const uint32_t w = row[ok ? j : dout - 1];
-    t[r] = ok ? w * DIG_K32 : 0u;  // low half of the leaf term (w * K mod 2^32: a bijection of w)
-    ninv += ok ? 0u : 1u;
-  }
-#endif
   mid_accumulate<NREG>(s_q, ia, ib, t, acc);
   corr += ninv * sq;
 }
@@ -514,7 +455,6 @@ __device__ __forceinline__ void mid_block(const uint32_t *s_q, const uint32_t *_
 __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nruns, const uint32_t *__restrict__ nbr,
                                               uint32_t (&acc)[MID_R], uint32_t &corr) {
   const int lane = threadIdx.x & 63;
-#if GG_MID_RUNLANES
   // Run descriptors 64 at a time, one per lane; the wave then walks only the runs it owns (ballot), with the
   // descriptor in scalar registers.  (Every wave stepping through every run, three quarters of them only to skip
   // them, was a seventh of the kernel's VALU instructions.)
@@ -563,41 +503,6 @@ __device__ __forceinline__ void mid_fold_tile(const MidShared &sm, uint32_t nrun
       }
     }
   }
-#else
-  const int wave = threadIdx.x >> 6;
-  for (uint32_t rr = 0; rr < nruns; rr++) {
-    const int a = (int)sm.run[rr], b = (int)sm.run[rr + 1];
-    const int len = b - a;
-    // long runs: every wave takes a slice of the run (i-split) and walks all J-blocks;
-    // short runs: the whole run belongs to ONE wave (dealt round-robin), the others skip it at once
-    const bool isplit = len >= GG_MID_ISPLIT;
-    if (!isplit && (rr & (XT / 64 - 1)) != (uint32_t)wave) continue;
-    const uint32_t dout = sm.rdout[rr];
-    if (dout == 0) continue;
-    const uint32_t *__restrict__ row = nbr + sm.rst[rr];
-    const int ia = isplit ? a + (len * wave) / (XT / 64) : a;
-    const int ib = isplit ? a + (len * (wave + 1)) / (XT / 64) : b;
-    if (ia >= ib) continue;
-    const uint32_t sq = sm.pq[ib] - sm.pq[ia];  // sum of the slice's hash states
-    // J-blocks of equal size (multiple of 64 leaves, at most 64*MID_R): avoids a nearly empty tail block
-    const uint32_t nJ = (dout + 64 * MID_R - 1) / (64 * MID_R);
-    const uint32_t jsz = nJ == 1 ? (dout + 63) & ~63u : (((dout + nJ - 1) / nJ) + 63) & ~63u;  // (no division for <= 512)
-    const int nreg = (int)(jsz >> 6);
-    for (uint32_t jb = 0; jb < nJ; jb++) {
-      const uint32_t base = jb * jsz + (uint32_t)lane;
-      switch (nreg) {
-      case 1: mid_block<1>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      case 2: mid_block<2>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      case 3: mid_block<3>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      case 4: mid_block<4>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      case 5: mid_block<5>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      case 6: mid_block<6>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      case 7: mid_block<7>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      default: mid_block<8>(sm.q, row, base, dout, ia, ib, sq, acc, corr); break;
-      }
-    }
-  }
-#endif
 }
 
 // One tile per workgroup.
@@ -618,7 +523,7 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
   mid_load_rows(rrow, rnbr, fbase, M, blockIdx.x, rows);
   mid_prepare(off, rows, emit_mid, prep, mid_sum, rows_last);
   const uint32_t nruns = mid_stage(sm, rows, prep, M, blockIdx.x);
-  if (GG_MID_PROBE != 2) mid_fold_tile(sm, nruns, nbr, acc, corr);
+  mid_fold_tile(sm, nruns, nbr, acc, corr);
   uint32_t tsum = 0;
 #pragma unroll
   for (int r = 0; r < MID_R; r++) tsum += acc[r];
@@ -1326,8 +1231,24 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
   for (uint32_t r = 0; r < nruns; r++) {
     const uint32_t i0 = s_run[r], i1 = s_run[r + 1];
     const uint32_t xr = s_x[i0], st = off[xr], dout = off[xr + 1] - st;
-    if (dout == 0 || i0 + wave >= i1) continue;  // (uniform per wave)
+    if (dout == 0) continue;  // (uniform)
     const long long xid = vid[xr];
+    {
+      // the middle column is ONE value over the whole piece of the run (rows of entries i0 .. i1 - 1 are contiguous):
+      // written as a plain fill, 1 KB per store instruction, a quarter of the piece per wave
+      const uint64_t Bs = s_base[i0], Be = s_base[i1 - 1] + dout;
+      ll2 xx;
+      xx.x = xx.y = xid;
+      const uint64_t a0 = (Bs + 1) & ~1ULL, npair = (Be - a0) >> 1;  // aligned pairs [a0, a0 + 2 npair)
+      const uint64_t per = (npair + 3) / 4, q0 = per * (uint64_t)wave, q1 = q0 + per < npair ? q0 + per : npair;
+      for (uint64_t q = q0 + (uint32_t)lane; q < q1; q += 64)
+        __builtin_nontemporal_store(xx, reinterpret_cast<ll2 *>(c1 + a0 + 2 * q));
+      if (wave == 0 && lane == 0) {
+        if (Bs & 1) c1[Bs] = xid;
+        if ((Be - a0) & 1) c1[Be - 1] = xid;
+      }
+    }
+    if (i0 + wave >= i1) continue;  // (uniform per wave)
     // (several entries side by side in one store instruction for short out-rows — 64 / ppe entries of (dout + 1) / 2
     // lane pairs each — was slower: 7.7 against 6.6 ms at SF10; the per-lane entry look-ups cost more than the
     // half-empty stores)
@@ -1340,9 +1261,8 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
       for (uint32_t i = i0 + wave; i < i1; i += 4) {
         const uint64_t B = s_base[i];  // first output row of this entry's block (uniform)
         const long long uid = s_uid[i];
-        ll2 uu, xx;
+        ll2 uu;
         uu.x = uu.y = uid;
-        xx.x = xx.y = xid;
         if ((B & 1) == 0) {  // rows B + k, B + k + 1: aligned pair
           const uint64_t o = B + k;
           if (k + 1 < dout) {
@@ -1351,11 +1271,9 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
             w.y = e1v;
             __builtin_nontemporal_store(w, reinterpret_cast<ll2 *>(c2 + o));
             __builtin_nontemporal_store(uu, reinterpret_cast<ll2 *>(c0 + o));
-            __builtin_nontemporal_store(xx, reinterpret_cast<ll2 *>(c1 + o));
           } else if (k < dout) {  // odd last row
             c2[o] = e0v;
             c0[o] = uid;
-            c1[o] = xid;
           }
         } else {  // the block starts at an odd row: rows B + k + 1, B + k + 2 pair up
           const uint64_t o = B + k + 1;
@@ -1365,16 +1283,13 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
             w.y = o1v;
             __builtin_nontemporal_store(w, reinterpret_cast<ll2 *>(c2 + o));
             __builtin_nontemporal_store(uu, reinterpret_cast<ll2 *>(c0 + o));
-            __builtin_nontemporal_store(xx, reinterpret_cast<ll2 *>(c1 + o));
           } else if (k + 1 < dout) {  // last row, alone
             c2[o] = e1v;
             c0[o] = uid;
-            c1[o] = xid;
           }
           if (jb == 0 && lane == 0) {  // first row of the block, alone (later J-blocks: the pair before covers it)
             c2[B] = e0v;
             c0[B] = uid;
-            c1[B] = xid;
           }
         }
       }
