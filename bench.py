@@ -59,6 +59,14 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def _pmc_traffic(key):
+    """HBM-side bytes from the committed counter passes (profiles/pmc_traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -219,7 +227,10 @@ def extra_bfs64(pkg, gg, csr, vid, oracle_graph, batches=16):
            "batches": batches, "wall_ms_per_batch": dt / batches * 1e3, "kernel_ms_per_batch": kern_ms / batches,
            "levels_per_batch": lv / batches, "value": te / dt, "unit": "traversed edges/s",
            "roofline": {"bound": "hbm", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": alg / (kern_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                        "frac": alg / (kern_ms * 1e-3) / HBM_PEAK, "traffic": _pmc_traffic("sf100/bfs64_batch/n1"),
+                        "traffic_note": "HBM-side bytes per 64-source batch (2*FETCH_SIZE + WRITE_SIZE over the batch's kernels, "
+                                        "profiles/pmc_traffic.json: counter passes of an earlier run, not measured in this run)",
+                        "algorithmic_bytes_per_batch": alg / batches,
                         "note": "per-level algorithmic bytes 8V + 16Va + 24TE + 24V over the BFS kernels' time"},
            "kernels_us_per_batch": {k: v[1] * 1e3 / batches for k, v in prof.items() if k.startswith("bfs_")}}
     if oracle_graph is not None:
@@ -260,7 +271,8 @@ def extra_materialised(pkg, orc, device):
     if k[0]:
         out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": written / (k[1] * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": written / (k[1] * 1e-3) / HBM_PEAK,
-                           "traffic": None, "avg_launch_ms": k[1] / k[0],
+                           "traffic": _pmc_traffic("sf10/mat_mid2/n1") if kname == "mat_mid2" else None,
+                           "avg_launch_ms": k[1] / k[0],
                            "note": "bytes actually written by the kernel (rows x 3 x 8) over its time"}
     # parity over ALL rows: the digest of what was written (gg_result_digest maps every id of every row back to its
     # dense index and sums the row hashes) against the count-mode expansion's and the oracle's digest of the same walks
