@@ -63,15 +63,24 @@ PhysicalGGLazySink::PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot_p, Kind kind
       kind(kind_p) {
 }
 
+PhysicalGGLazySink::PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot_p, EdgeOptions options_p, vector<LogicalType> types,
+                                       idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, move(types), estimated_cardinality), slot(move(slot_p)),
+      kind(EDGES_CUSTOM), options(options_p) {
+}
+
 unique_ptr<GlobalSinkState> PhysicalGGLazySink::GetGlobalSinkState(ClientContext &context) const {
 	lock_guard<mutex> guard(slot->lock);
-	if (kind == VERTICES || kind == EDGES_DERIVE_VERTICES) {
+	if (kind == VERTICES || kind == EDGES_DERIVE_VERTICES || (kind == EDGES_CUSTOM && options.first)) {
 		slot->graph = make_shared<GGGraph>(0); // first sink of an execution: a fresh graph
 	}
 	if (!slot->graph) {
 		throw InternalException("GG_EDGE_SINK scheduled before its vertex sink");
 	}
-	if (kind == VERTICES) {
+	if (kind == EDGES_CUSTOM) {
+		inner = make_unique<PhysicalGGEdgeSink>(slot->graph, types, estimated_cardinality, options.as_filter,
+		                                        options.derive_vertices, options.keep_vertices, options.build);
+	} else if (kind == VERTICES) {
 		inner = make_unique<PhysicalGGVertexSink>(slot->graph, types, estimated_cardinality);
 	} else {
 		inner = make_unique<PhysicalGGEdgeSink>(slot->graph, types, estimated_cardinality, false,
@@ -95,7 +104,12 @@ void PhysicalGGLazySink::Combine(ExecutionContext &context, GlobalSinkState &gst
 
 SinkFinalizeType PhysicalGGLazySink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
                                               GlobalSinkState &gstate) const {
-	return inner->Finalize(pipeline, event, context, gstate);
+	auto result = inner->Finalize(pipeline, event, context, gstate);
+	if (kind == EDGES_CUSTOM && options.clear_edges_after) {
+		lock_guard<mutex> guard(slot->lock);
+		GGGraph::Check(gg_staging_clear_edges(slot->graph->ctx), "gg_staging_clear_edges");
+	}
+	return result;
 }
 
 string PhysicalGGLazySink::GetName() const {
@@ -213,6 +227,21 @@ bool GGPipelineSinksAvailable(ClientContext &context, const GGGraphSpec &spec) {
 	}
 	// a connection that asked for pinned graphs may not need to read the tables at all: decided at run time there
 	return !GGGetConnectionFlags(context).pinned_graphs;
+}
+
+unique_ptr<PhysicalOperator> GGMakeGraphScan(const vector<GGSinkSpec> &sinks, vector<LogicalType> types, string name,
+                                             string description, bool parallel_result,
+                                             PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality) {
+	auto slot = make_shared<GGGraphSlot>();
+	auto scan = make_unique<PhysicalGGGraphScan>(move(types), move(name), move(description), slot, move(factory),
+	                                             parallel_result, estimated_cardinality);
+	for (auto &spec : sinks) {
+		auto rows = BaseTableScan(spec.rows);
+		auto sink = make_unique<PhysicalGGLazySink>(slot, spec.options, rows->types, rows->estimated_cardinality);
+		sink->children.push_back(move(rows));
+		scan->children.push_back(move(sink));
+	}
+	return move(scan);
 }
 
 unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<LogicalType> types, string name,

@@ -18,11 +18,22 @@ struct GGGraphSlot {
 //! plan that is only explained or prepared never touches the GPU.
 class PhysicalGGLazySink : public PhysicalOperator {
 public:
-	enum Kind { VERTICES, EDGES, EDGES_DERIVE_VERTICES };
+	enum Kind { VERTICES, EDGES, EDGES_DERIVE_VERTICES, EDGES_CUSTOM };
 	PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot, Kind kind, vector<LogicalType> types, idx_t estimated_cardinality);
+	//! an edge sink with PhysicalGGEdgeSink's own switches (plans over two edge tables: ConnectedSegments).  `first`: the
+	//! sink that opens the execution's graph; `clear_edges_after`: its Finalize drops the staged edge rows once its own
+	//! CSR is built (gg_staging_clear_edges: the vertex numbering stays) — every sink's global state is created when
+	//! the pipelines are scheduled, before any of them runs, so nothing of that kind can happen there
+	struct EdgeOptions {
+		bool first = false, clear_edges_after = false;
+		bool as_filter = false, derive_vertices = false, keep_vertices = false, build = true;
+	};
+	PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot, EdgeOptions options, vector<LogicalType> types,
+	                   idx_t estimated_cardinality);
 
 	shared_ptr<GGGraphSlot> slot;
 	Kind kind;
+	EdgeOptions options;
 	mutable unique_ptr<PhysicalOperator> inner;
 
 public:
@@ -80,6 +91,14 @@ public:
 bool GGPipelineSinksAvailable(ClientContext &context, const GGGraphSpec &spec);
 //! GG_<name> scan with the sinks (and the reference's own table scans) of `spec` as children
 unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<LogicalType> types, string name,
+                                             string description, bool parallel_result,
+                                             PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality);
+//! the same for a plan whose graph takes several edge-table passes: one sink child per entry, in build order
+struct GGSinkSpec {
+	GGScanSource rows;
+	PhysicalGGLazySink::EdgeOptions options;
+};
+unique_ptr<PhysicalOperator> GGMakeGraphScan(const vector<GGSinkSpec> &sinks, vector<LogicalType> types, string name,
                                              string description, bool parallel_result,
                                              PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality);
 void GGRegisterPipelineRule();

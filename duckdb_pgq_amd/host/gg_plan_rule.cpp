@@ -1284,15 +1284,42 @@ unique_ptr<PhysicalOperator> PlanSameNeighbourPaths(LogicalComparisonJoin &op, P
 	                    pattern.filter_table->columns[pattern.filter_dst].name +
 	                    (pattern.source_table ? "\nfrom every " + pattern.source_table->name : string());
 	vector<LogicalType> types(hops + 2, LogicalType::BIGINT);
-	vector<column_t> column_ids;
-	vector<string> names;
-	for (idx_t c = 0; c < types.size(); c++) {
-		column_ids.push_back(c);
-		names.push_back(c == 0 ? "w" : "v" + to_string(c - 1));
-	}
 	g_rules_fired++;
-	auto scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_same_neighbour_walks"), move(data),
-	                                           move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	unique_ptr<PhysicalOperator> scan;
+	GGGraphSpec sinks_spec;  // (what GGPipelineSinksAvailable looks at: plain tables, no pinned graphs)
+	sinks_spec.edges = path;
+	if (g_plan_context && filter.table && GGPipelineSinksAvailable(*g_plan_context, sinks_spec)) {
+		// the three table passes as pipeline sinks the reference's executor schedules (gg_pipeline.cpp), in build order:
+		// endpoints of the path table, the filter table (its endpoints and its CSR), the path table's CSR
+		vector<GGSinkSpec> sinks(3);
+		sinks[0].rows = path;
+		sinks[0].options.first = true;
+		sinks[0].options.derive_vertices = true;
+		sinks[0].options.build = false;
+		sinks[1].rows = filter;
+		sinks[1].options.as_filter = sinks[1].options.derive_vertices = sinks[1].options.keep_vertices = true;
+		sinks[1].options.clear_edges_after = true;  // the path table's rows come back for its own CSR
+		sinks[2].rows = path;
+		scan = GGMakeGraphScan(
+		    sinks, move(types), "GG_SAME_NEIGHBOUR_WALKS", data->description, false /* one thread drains the result */,
+		    [=](ClientContext &context, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+			    vector<int64_t> source_ids;
+			    if (sources.table) {
+				    source_ids = GGScanInt64Column(context, sources);
+			    }
+			    return make_unique<PhysicalGGFilteredPaths>(move(graph), hops, move(source_ids), 0, sources.table == nullptr);
+		    },
+		    op.estimated_cardinality);
+	} else {
+		vector<column_t> column_ids;
+		vector<string> names;
+		for (idx_t c = 0; c < types.size(); c++) {
+			column_ids.push_back(c);
+			names.push_back(c == 0 ? "w" : "v" + to_string(c - 1));
+		}
+		scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_same_neighbour_walks"), move(data),
+		                                      move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	}
 	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
 	projection->children.push_back(move(scan));
 	return move(projection);

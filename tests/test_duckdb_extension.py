@@ -267,7 +267,12 @@ def test_plan_rule_connectedsegments_query_text():
         cpu = d.execute(sql)
         d.execute("PRAGMA enable_gpu_graph")
         assert "GG_SAME_NEIGHBOUR_WALKS" in d.explain(sql) and "HASH_JOIN" not in d.explain(sql)
+        # the plan's three table passes (endpoints of the path table, the filter table, the path table's CSR) are
+        # pipeline sinks over the reference's own table scans, like the other rules' build sides
+        assert "GG_EDGE_SINK" in d.explain(sql)
         gpu = d.execute(sql)
+        again = d.execute(sql)
+        assert np.array_equal(sort_rows(gpu), sort_rows(again))
         d.execute("PRAGMA disable_gpu_graph")
         return sort_rows(cpu), sort_rows(gpu)
 
