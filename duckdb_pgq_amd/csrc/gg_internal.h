@@ -223,6 +223,7 @@ struct gg_result {
   int k_min = 0, k_max = 0;
   uint64_t rows[GG_MAX_HOPS + 1] = {0};
   int64_t *cols[GG_MAX_HOPS + 1][GG_MAX_HOPS + 1] = {{nullptr}};  // cols[h][c], device
+  int64_t *ecols[GG_MAX_HOPS + 1][GG_MAX_HOPS + 1] = {{nullptr}};  // ecols[h][j]: rowid of the walk's (j + 1)-th edge (gg_expand_khop_edges)
 };
 
 namespace gg {

@@ -742,7 +742,9 @@ __global__ __launch_bounds__(XT) void k_mat_fill(const uint32_t *__restrict__ of
                                                  const OffT *__restrict__ foff, uint64_t n_entries, uint64_t M,
                                                  const uint32_t *__restrict__ tile_entry, int j,
                                                  const uint32_t *const *__restrict__ cols_in,
-                                                 uint32_t *const *__restrict__ cols_out, uint64_t *__restrict__ ndeg) {
+                                                 uint32_t *const *__restrict__ cols_out, uint64_t *__restrict__ ndeg,
+                                                 const uint32_t *const *__restrict__ epos_in /* nullable: CSR */,
+                                                 uint32_t *const *__restrict__ epos_out /* positions of the edges taken */) {
   __shared__ uint64_t s_foff[XT + 1];
   const uint64_t fbase = (uint64_t)foff[0];
   const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
@@ -753,11 +755,48 @@ __global__ __launch_bounds__(XT) void k_mat_fill(const uint32_t *__restrict__ of
   uint64_t k;
   uint64_t i = locate_entry(s_foff, foff, n_entries, i0, p, &k);
   const uint32_t v = cols_in[j][i];
-  const uint32_t x = nbr[(uint64_t)off[v] + k];
+  const uint64_t at = (uint64_t)off[v] + k;
+  const uint32_t x = nbr[at];
   const uint64_t o = p - fbase;
   for (int c = 0; c <= j; c++) cols_out[c][o] = cols_in[c][i];
   cols_out[j + 1][o] = x;
+  if (epos_out) {  // walks with their edges: hop j + 1 took CSR entry `at`
+    for (int c = 0; c < j; c++) epos_out[c][o] = epos_in[c][i];
+    epos_out[j][o] = (uint32_t)at;
+  }
   if (ndeg) ndeg[o] = (uint64_t)(off[x + 1] - off[x]);
+}
+
+// Last level of a materialisation WITH edge columns (gg_expand_khop_edges): one thread per output row, vertex ids and
+// edge rowids gathered per column.  (The plain path's k_mat_last / k_mat_mid2 are the tuned ones: rows with edge
+// columns feed a late join with the edge table's payload columns, typically from a handful of sources.)
+struct EdgeCols {
+  int64_t *v[GG_MAX_HOPS + 1];
+  int64_t *e[GG_MAX_HOPS + 1];
+};
+template <typename OffT>
+__global__ __launch_bounds__(XT) void k_mat_rows_edges(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                       const int64_t *__restrict__ vid, const int64_t *__restrict__ eid,
+                                                       const uint32_t *__restrict__ epos, const OffT *__restrict__ foff,
+                                                       uint64_t n_entries, uint64_t M,
+                                                       const uint32_t *__restrict__ tile_entry, int j,
+                                                       const uint32_t *const *__restrict__ cols_in,
+                                                       const uint32_t *const *__restrict__ epos_in, EdgeCols out) {
+  __shared__ uint64_t s_foff[XT + 1];
+  const uint64_t fbase = (uint64_t)foff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, foff, n_entries, i0);
+  __syncthreads();
+  if (p >= fbase + M) return;
+  uint64_t k;
+  uint64_t i = locate_entry(s_foff, foff, n_entries, i0, p, &k);
+  const uint64_t at = (uint64_t)off[cols_in[j][i]] + k, o = p - fbase;
+  auto rowid_of = [&](uint64_t pos) { return eid ? eid[pos] : (int64_t)epos[pos]; };  // explicit rowid, or append position
+  for (int c = 0; c <= j; c++) out.v[c][o] = vid[cols_in[c][i]];
+  out.v[j + 1][o] = vid[nbr[at]];
+  for (int c = 0; c < j; c++) out.e[c][o] = rowid_of(epos_in[c][i]);
+  out.e[j][o] = rowid_of(at);
 }
 
 // Last level of a materialised expansion, written directly as int64 ids: a tile of XT parent rows is
@@ -1344,9 +1383,15 @@ int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mi
 
 // materialise walks as int64 id columns (correctness config; level-by-level)
 int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64_t n0, int k_min, int k_max,
-                     gg_result *res) {
-  // level tables of dense columns
-  std::vector<uint32_t *> cols_prev, cols_cur;
+                     gg_result *res, bool with_edges = false) {
+  // level tables of dense columns (with_edges: and of the CSR positions of the edges taken, one column per hop)
+  std::vector<uint32_t *> cols_prev, cols_cur, epos_prev, epos_cur;
+  const uint32_t **e_in = nullptr;
+  uint32_t **e_out = nullptr;
+  if (with_edges) {
+    GG_TRY(ctx->dev_alloc((void **)&e_in, (GG_MAX_HOPS + 1) * sizeof(void *)));
+    GG_TRY(ctx->dev_alloc((void **)&e_out, (GG_MAX_HOPS + 1) * sizeof(void *)));
+  }
   uint64_t n_prev = n0;
   uint32_t *c0 = nullptr;
   GG_TRY(ctx->dev_alloc((void **)&c0, (n0 ? n0 : 1) * sizeof(uint32_t)));
@@ -1392,7 +1437,29 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
         ctx->keep(res->cols[h][c]);
         oc.c[c] = res->cols[h][c];
       }
-      if (M) {
+      if (M && with_edges) {
+        EdgeCols ec;
+        for (int c = 0; c <= GG_MAX_HOPS; c++) ec.v[c] = ec.e[c] = nullptr;
+        for (int c = 0; c <= h; c++) ec.v[c] = res->cols[h][c];
+        for (int c = 0; c < h; c++) {
+          GG_TRY(ctx->dev_alloc((void **)&res->ecols[h][c], M * sizeof(int64_t)));
+          ctx->keep(res->ecols[h][c]);
+          ec.e[c] = res->ecols[h][c];
+        }
+        uint32_t *tile_entry = nullptr;
+        uint64_t n_tiles = 0;
+        GG_TRY(make_tiles<uint64_t>(ctx, foff, n_prev, M, &tile_entry, &n_tiles));
+        GG_HIP(hipMemcpyAsync(d_in, cols_prev.data(), cols_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
+                              ctx->stream));
+        if (!epos_prev.empty())
+          GG_HIP(hipMemcpyAsync(e_in, epos_prev.data(), epos_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
+                                ctx->stream));
+        GG_HIP(hipStreamSynchronize(ctx->stream));
+        GG_LAUNCH(ctx, "mat_rows_edges", (k_mat_rows_edges<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off,
+                  csr->nbr, csr->vid, (const int64_t *)csr->eid, (const uint32_t *)csr->epos, (const uint64_t *)foff, n_prev, M,
+                  (const uint32_t *)tile_entry, h - 1, d_in, e_in, ec);
+        ctx->dev_free(tile_entry);
+      } else if (M) {
         GG_HIP(hipMemcpyAsync(d_in, cols_prev.data(), cols_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
                               ctx->stream));
         GG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1403,6 +1470,8 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
     }
     cols_cur.assign((size_t)h + 1, nullptr);
     for (int c = 0; c <= h; c++) GG_TRY(ctx->dev_alloc((void **)&cols_cur[c], (M ? M : 1) * sizeof(uint32_t)));
+    epos_cur.assign(with_edges ? (size_t)h : 0, nullptr);
+    for (auto &pc : epos_cur) GG_TRY(ctx->dev_alloc((void **)&pc, (M ? M : 1) * sizeof(uint32_t)));
     uint64_t *noff = nullptr;
     GG_TRY(ctx->dev_alloc((void **)&noff, (M + 1) * sizeof(uint64_t)));
     uint64_t Mn = 0;
@@ -1414,9 +1483,17 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
                             ctx->stream));
       GG_HIP(hipMemcpyAsync(d_out, cols_cur.data(), cols_cur.size() * sizeof(void *), hipMemcpyHostToDevice,
                             ctx->stream));
+      if (with_edges) {
+        if (!epos_prev.empty())
+          GG_HIP(hipMemcpyAsync(e_in, epos_prev.data(), epos_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
+                                ctx->stream));
+        GG_HIP(hipMemcpyAsync(e_out, epos_cur.data(), epos_cur.size() * sizeof(void *), hipMemcpyHostToDevice,
+                              ctx->stream));
+      }
       GG_HIP(hipStreamSynchronize(ctx->stream));  // host vectors are reused below
       GG_LAUNCH(ctx, "mat_fill", (k_mat_fill<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
-                foff, n_prev, M, tile_entry, h - 1, d_in, d_out, noff);
+                foff, n_prev, M, tile_entry, h - 1, d_in, d_out, noff, with_edges ? e_in : (const uint32_t **)nullptr,
+                with_edges ? e_out : (uint32_t **)nullptr);
       ctx->dev_free(tile_entry);
       GG_TRY(offsets_from_deg(ctx, noff, M, &Mn));
     }
@@ -1431,16 +1508,21 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
       }
     }
     for (auto p : cols_prev) ctx->dev_free(p);
+    for (auto p : epos_prev) ctx->dev_free(p);
     ctx->dev_free(foff);
     cols_prev = cols_cur;
+    epos_prev = epos_cur;
     foff = noff;
     n_prev = M;
     M = Mn;
   }
   for (auto p : cols_prev) ctx->dev_free(p);
+  for (auto p : epos_prev) ctx->dev_free(p);
   ctx->dev_free(foff);
   ctx->dev_free(d_in);
   ctx->dev_free(d_out);
+  ctx->dev_free(e_in);
+  ctx->dev_free(e_out);
   GG_HIP(hipStreamSynchronize(ctx->stream));
   return GG_OK;
 }
@@ -1591,6 +1673,98 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
 extern "C" int gg_expand_khop_result(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min,
                                      int k_max, gg_khop_stats *stats, gg_result **out_result) {
   return gg_expand_khop(ctx, csr, src_ids, n_src, k_min, k_max, 1, stats, out_result);
+}
+
+extern "C" int gg_expand_khop_edges(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k,
+                                    gg_khop_stats *stats, gg_result **out_result) {
+  ApiScope scope(ctx);
+  GG_TRY(check_args(ctx, csr, k, k, stats));
+  if (!out_result) return GG_ERR_INVALID_ARG;
+  *out_result = nullptr;
+  if (csr->n_parts > 1 || !csr->has_rowid) {
+    set_error("gg_expand_khop_edges needs a whole CSR built with edge rowids (gg_ctx_set_edge_rowid(ctx, 1))");
+    return GG_ERR_STATE;
+  }
+  GG_HIP(hipSetDevice(ctx->device));
+  // level 0: the given sources (dense, compacted) or every vertex
+  int64_t *ids_dev = nullptr;
+  uint32_t *dense = nullptr, *fv = nullptr;
+  uint64_t n0 = 0;
+  DevFrontier f0;
+  unsigned long long *cursor = nullptr;
+  int rc = GG_OK;
+  if (src_ids) {
+    const uint64_t n = n_src;
+    GG_TRY(ctx->dev_alloc((void **)&ids_dev, (n ? n : 1) * sizeof(int64_t)));
+    GG_TRY(ctx->dev_alloc((void **)&dense, (n ? n : 1) * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&f0.fv, (n ? n : 1) * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&f0.fq, (n ? n : 1) * sizeof(uint64_t)));
+    GG_TRY(ctx->dev_alloc((void **)&f0.foff, (n + 1) * sizeof(uint64_t)));
+    GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
+    GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->stream));
+    if (n) {
+      GG_HIP(hipMemcpyAsync(ids_dev, src_ids, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+      GG_HIP(hipStreamSynchronize(ctx->stream));  // src_ids is caller memory: consumed before return
+      GG_TRY(lookup_ids(ctx, csr, ids_dev, n, dense));
+      GG_LAUNCH(ctx, "compact_sources", k_compact_sources, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, dense, n,
+                f0.fv, f0.fq, f0.foff, csr->off, cursor);
+      GG_TRY(read_u64(ctx, (const uint64_t *)cursor, &n0));
+    }
+    fv = f0.fv;
+  } else {
+    n0 = csr->V;
+    uint64_t *fdeg = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&fv, (n0 ? n0 : 1) * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&fdeg, (n0 ? n0 : 1) * sizeof(uint64_t)));
+    if (n0)
+      hipLaunchKernelGGL(k_iota_deg, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, 0u, n0, csr->off, fv,
+                         fdeg);
+    ctx->dev_free(fdeg);
+  }
+  gg_result *res = new gg_result();
+  res->ctx = ctx;
+  res->k_min = res->k_max = k;
+  rc = khop_materialise(ctx, csr, fv, n0, k, k, res, true);
+  if (rc == GG_OK) {
+    memset(stats, 0, sizeof(*stats));
+    stats->rows[k] = res->rows[k];
+  }
+  if (!src_ids) ctx->dev_free(fv);
+  ctx->dev_free(ids_dev);
+  ctx->dev_free(dense);
+  ctx->dev_free(cursor);
+  if (src_ids) free_frontier(ctx, f0);
+  if (rc != GG_OK) {
+    gg_result_destroy(res);
+    return rc;
+  }
+  *out_result = res;
+  return GG_OK;
+}
+
+extern "C" int gg_result_fetch_edges(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows,
+                                     int64_t *const *ecols, uint32_t *n_out) {
+  if (!res || !ecols || !n_out || hops < res->k_min || hops > res->k_max) return GG_ERR_INVALID_ARG;
+  gg_ctx *ctx = res->ctx;
+  GG_HIP(hipSetDevice(ctx->device));
+  const uint64_t total = res->rows[hops];
+  if (offset >= total) {
+    *n_out = 0;
+    return GG_OK;
+  }
+  uint64_t take = total - offset;
+  if (take > max_rows) take = max_rows;
+  for (int c = 0; c < hops; c++) {
+    if (!ecols[c] || !res->ecols[hops][c]) {
+      set_error("gg_result_fetch_edges: the result carries no edge columns (gg_expand_khop_edges makes them)");
+      return GG_ERR_INVALID_ARG;
+    }
+    GG_HIP(hipMemcpyAsync(ecols[c], res->ecols[hops][c] + offset, take * sizeof(int64_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+  }
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  *n_out = (uint32_t)take;
+  return GG_OK;
 }
 
 extern "C" int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bounds) {
@@ -1805,7 +1979,10 @@ extern "C" void gg_result_destroy(gg_result *res) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int h = 0; h <= GG_MAX_HOPS; h++)
-      for (int c = 0; c <= GG_MAX_HOPS; c++) ctx->dev_free(res->cols[h][c]);
+      for (int c = 0; c <= GG_MAX_HOPS; c++) {
+        ctx->dev_free(res->cols[h][c]);
+        ctx->dev_free(res->ecols[h][c]);
+      }
   }
   delete res;
 }

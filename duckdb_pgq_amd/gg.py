@@ -21,6 +21,7 @@ SYMBOLS = [
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_debug_max_grid_tiles", "gg_debug_reset",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
+    "gg_expand_khop_edges", "gg_result_fetch_edges",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
     "gg_bfs64", "gg_bfs64_pairs", "gg_bfs64_pairs_packed", "gg_walk_endpoints", "gg_host_alloc", "gg_host_free", "gg_csr_lookup",
     "gg_bfs_sharded_begin", "gg_bfs_sharded_expand", "gg_bfs_sharded_words", "gg_bfs_sharded_commit",
@@ -108,6 +109,8 @@ def load_library(path: str | None = None):
     lib.gg_result_destroy.argtypes = [P]
     lib.gg_result_destroy.restype = None
     lib.gg_result_digest.argtypes = [P, P, P, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+    lib.gg_expand_khop_edges.argtypes = [P, P, i64p, u64, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
+    lib.gg_result_fetch_edges.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
     lib.gg_bfs64.argtypes = [P, P, i64p, C.c_int, C.c_int, i64p, u64, C.POINTER(C.c_int32), C.POINTER(BfsStats)]
     lib.gg_host_alloc.argtypes = [P, u64, C.POINTER(C.c_void_p)]
     lib.gg_host_free.argtypes = [P, C.c_void_p]
@@ -209,6 +212,14 @@ class KhopResult:
         n = C.c_uint64()
         self.gg._chk(self.gg.lib.gg_result_rows(self.handle, h, C.byref(n)))
         return int(n.value)
+
+    def fetch_edges(self, h: int, offset: int, max_rows: int = GG_CHUNK_ROWS) -> np.ndarray:
+        """Edge rowids e1..eh of rows [offset, offset + max_rows) (results of expand_khop_edges)."""
+        bufs = [np.empty(GG_CHUNK_ROWS, np.int64) for _ in range(h)]
+        ptrs = (C.POINTER(C.c_int64) * h)(*[b.ctypes.data_as(C.POINTER(C.c_int64)) for b in bufs])
+        got = C.c_uint32()
+        self.gg._chk(self.gg.lib.gg_result_fetch_edges(self.handle, h, offset, min(max_rows, GG_CHUNK_ROWS), ptrs, C.byref(got)))
+        return np.stack([b[: got.value] for b in bufs], axis=1)
 
     def digest(self, csr, h: int):
         """(rows, digest) of the h-hop rows as they stand in HBM — the figures a count-mode expansion reports."""
@@ -374,6 +385,18 @@ class GG:
             a, sp = _i64(sources)
             ns = a.size
         self._chk(self.lib.gg_expand_khop_result(self.ctx, csr.handle, sp, ns, k, k, C.byref(st), C.byref(res)))
+        return KhopResult(self, res, self._stats_dict(st))
+
+    def expand_khop_edges(self, csr: Csr, k: int, sources=None) -> "KhopResult":
+        """k-hop walks with the rowid of every edge taken (sources None: from every vertex)."""
+        st = KhopStats()
+        res = C.c_void_p()
+        if sources is None:
+            sp, ns = None, 0
+        else:
+            a, sp = _i64(sources)
+            ns = a.size
+        self._chk(self.lib.gg_expand_khop_edges(self.ctx, csr.handle, sp, ns, k, C.byref(st), C.byref(res)))
         return KhopResult(self, res, self._stats_dict(st))
 
     def staging_clear_edges(self):

@@ -142,7 +142,8 @@ static shared_ptr<GGGraph> FindPinned(ClientContext &context, const GGGraphSpec 
 
 static shared_ptr<GGGraph> BuildGraphNow(ClientContext &context, const GGGraphSpec &spec) {
 	PhaseTimer timer;
-	auto graph = make_shared<GGGraph>(0);
+	const bool edge_rowids = spec.edges.columns.size() >= 3 || (!spec.edges.table && spec.edges_with_rowid);
+	auto graph = make_shared<GGGraph>(0, edge_rowids);  // (a third edge column is the rowid: walks with their edges)
 	timer.Lap("device context");
 	const bool derive = spec.vertices.Empty();
 	if (!derive) {
@@ -150,7 +151,8 @@ static shared_ptr<GGGraph> BuildGraphNow(ClientContext &context, const GGGraphSp
 		GGRunSinkPipeline(context, spec.vertices, vsink);
 		timer.Lap("vertex table ingest");
 	}
-	PhysicalGGEdgeSink esink(graph, {LogicalType::BIGINT, LogicalType::BIGINT}, 0, false, derive);
+	vector<LogicalType> edge_types(edge_rowids ? 3 : 2, LogicalType::BIGINT);
+	PhysicalGGEdgeSink esink(graph, edge_types, 0, false, derive);
 	GGRunSinkPipeline(context, spec.edges, esink);
 	timer.Lap("edge ingest + CSR build");
 	return graph;

@@ -8,6 +8,9 @@
 #include "duckdb/common/types/data_chunk.hpp"
 #include "duckdb/common/types/vector.hpp"
 #include "duckdb/main/client_context.hpp"
+#include "duckdb/catalog/catalog_entry/table_catalog_entry.hpp"
+#include "duckdb/storage/data_table.hpp"
+#include "duckdb/transaction/transaction.hpp"
 
 namespace duckdb {
 
@@ -62,16 +65,16 @@ struct GGContextPool {
 };
 static GGContextPool g_context_pool;
 
-GGGraph::GGGraph(int device_p) : device(device_p) {
+GGGraph::GGGraph(int device_p, bool keep_edge_rowids) : device(device_p) {
 	ctx = g_context_pool.Acquire(device);
 	if (ctx) {
 		Check(gg_staging_clear(ctx), "gg_staging_clear");
 	} else {
 		Check(gg_ctx_create(device, &ctx), "gg_ctx_create");
 	}
-	// none of the operators below returns edge ids: build without the edge-rowid payload, as the
-	// reference's hash-join build side carries only the columns the query references
-	Check(gg_ctx_set_edge_rowid(ctx, 0), "gg_ctx_set_edge_rowid");
+	// only walks with payload columns of their edges return edge ids: every other plan builds without the
+	// edge-rowid payload, as the reference's hash-join build side carries only the columns the query references
+	Check(gg_ctx_set_edge_rowid(ctx, keep_edge_rowids ? 1 : 0), "gg_ctx_set_edge_rowid");
 }
 
 GGGraph::~GGGraph() {
@@ -615,6 +618,111 @@ void PhysicalGGFilteredPaths::GetData(ExecutionContext &context, DataChunk &chun
 		               "gg_result_fetch");
 	}
 	gstate.offset += n;
+	chunk.SetCardinality(n);
+}
+
+//===--------------------------------------------------------------------===//
+// Walks with payload columns of their edges
+//===--------------------------------------------------------------------===//
+vector<LogicalType> PhysicalGGPathEdges::OutputTypes(int hops, TableCatalogEntry &edge_table,
+                                                     const vector<std::pair<idx_t, column_t>> &payload) {
+	vector<LogicalType> types {LogicalType::INTEGER};
+	for (int c = 0; c <= hops; c++) {
+		types.push_back(LogicalType::BIGINT);
+	}
+	for (auto &entry : payload) {
+		types.push_back(edge_table.columns[entry.second].type);
+	}
+	return types;
+}
+
+PhysicalGGPathEdges::PhysicalGGPathEdges(shared_ptr<GGGraph> graph_p, int hops_p, vector<int64_t> sources_p,
+                                         bool all_sources_p, TableCatalogEntry *edge_table_p,
+                                         vector<std::pair<idx_t, column_t>> payload_p, idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::INVALID, OutputTypes(hops_p, *edge_table_p, payload_p),
+                       estimated_cardinality),
+      graph(move(graph_p)), hops(hops_p), sources(move(sources_p)), all_sources(all_sources_p),
+      edge_table(edge_table_p), payload(move(payload_p)) {
+}
+
+unique_ptr<GlobalSourceState> PhysicalGGPathEdges::GetGlobalSourceState(ClientContext &context) const {
+	auto state = make_unique<GGFilteredGlobalState>();
+	lock_guard<mutex> guard(graph->lock);
+	if (!graph->csr) {
+		throw InternalException("GG_PATH_EDGES scheduled before the CSR was built");
+	}
+	gg_khop_stats stats;
+	GGGraph::Check(gg_expand_khop_edges(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(),
+	                                    all_sources ? 0 : sources.size(), hops, &stats, &state->result),
+	               "gg_expand_khop_edges");
+	uint64_t n = 0;
+	GGGraph::Check(gg_result_rows(state->result, hops, &n), "gg_result_rows");
+	state->rows = n;
+	return move(state);
+}
+
+void PhysicalGGPathEdges::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
+                                  LocalSourceState &lstate) const {
+	auto &gstate = (GGFilteredGlobalState &)gstate_p;
+	if (gstate.offset >= gstate.rows) {
+		return;
+	}
+	int64_t *cols[GG_MAX_HOPS + 1];
+	for (int c = 0; c <= hops; c++) {
+		cols[c] = FlatVector::GetData<int64_t>(chunk.data[1 + c]);
+	}
+	vector<Vector> rowids;
+	int64_t *ecols[GG_MAX_HOPS + 1];
+	for (int j = 0; j < hops; j++) {
+		rowids.emplace_back(LOGICAL_ROW_TYPE);
+		ecols[j] = (int64_t *)FlatVector::GetData<row_t>(rowids.back());
+	}
+	uint32_t n = 0, ne = 0;
+	{
+		lock_guard<mutex> guard(graph->lock);
+		GGGraph::Check(gg_result_fetch(gstate.result, hops, gstate.offset, STANDARD_VECTOR_SIZE, cols, &n), "gg_result_fetch");
+		GGGraph::Check(gg_result_fetch_edges(gstate.result, hops, gstate.offset, STANDARD_VECTOR_SIZE, ecols, &ne),
+		               "gg_result_fetch_edges");
+	}
+	if (n != ne) {
+		throw InternalException("GG_PATH_EDGES: vertex and edge columns out of step");
+	}
+	gstate.offset += n;
+	chunk.data[0].Reference(Value::INTEGER(hops));
+	// the payload columns of edge j, all in one fetch by rowid
+	auto &transaction = Transaction::GetTransaction(context.client);
+	for (int j = 1; j <= hops; j++) {
+		vector<column_t> column_ids;
+		vector<LogicalType> types;
+		vector<idx_t> targets;
+		for (idx_t p = 0; p < payload.size(); p++) {
+			if ((int)payload[p].first == j) {
+				column_ids.push_back(payload[p].second);
+				types.push_back(edge_table->columns[payload[p].second].type);
+				targets.push_back(2 + hops + p);
+			}
+		}
+		if (column_ids.empty()) {
+			continue;
+		}
+		auto ids = FlatVector::GetData<row_t>(rowids[j - 1]);
+		for (uint32_t r = 0; r < n; r++) {
+			if (ids[r] < 0 || ids[r] >= MAX_ROW_ID) {
+				throw NotImplementedException("GG_PATH_EDGES: edge rows that this transaction has not committed yet cannot be "
+				                              "fetched by rowid (PRAGMA disable_gpu_graph for this statement)");
+			}
+		}
+		DataChunk fetched;
+		fetched.Initialize(types);
+		ColumnFetchState fetch_state;
+		edge_table->storage->Fetch(transaction, fetched, column_ids, rowids[j - 1], n, fetch_state);
+		if (fetched.size() != n) {
+			throw InternalException("GG_PATH_EDGES: an edge row of the walk is not visible to the statement any more");
+		}
+		for (idx_t c = 0; c < targets.size(); c++) {
+			chunk.data[targets[c]].Reference(fetched.data[c]);
+		}
+	}
 	chunk.SetCardinality(n);
 }
 

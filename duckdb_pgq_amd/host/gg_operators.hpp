@@ -27,10 +27,12 @@
 #include "gg.h"
 
 namespace duckdb {
+class TableCatalogEntry;
 
 //! Device graph shared by the sinks that build it and the sources that query it.
 struct GGGraph {
-	explicit GGGraph(int device);
+	//! keep_edge_rowids: the CSR keeps the rowid the edge sink gets as its third column (walks with their edges)
+	explicit GGGraph(int device, bool keep_edge_rowids = false);
 	~GGGraph();
 	//! Turn a non-zero gg status into the exception the reference's operators would throw.
 	static void Check(int rc, const char *what);
@@ -170,6 +172,41 @@ public:
 	}
 	string GetName() const override {
 		return "GG_PATH_EXPAND";
+	}
+};
+
+//! Source: `hops`-hop walks WITH payload columns of the edge table (a join chain that projects columns of its edge
+//! instances other than the two keys).  The device returns every walk with the rowid of each edge taken
+//! (gg_expand_khop_edges); the payload columns are then fetched from the base table by rowid, in the statement's
+//! transaction — the late-materialising counterpart of the gather the reference's hash join does per match from its
+//! build side (src/execution/join_hashtable.cpp:466-473), through the call its index join uses
+//! (DataTable::Fetch, src/execution/operator/join/physical_index_join.cpp).
+//! Output: (hops INTEGER, v0 BIGINT, ..., v{hops} BIGINT, payload columns in the order given).
+class PhysicalGGPathEdges : public PhysicalOperator {
+public:
+	//! payload: (1-based edge number of the walk, column of the edge table)
+	PhysicalGGPathEdges(shared_ptr<GGGraph> graph, int hops, vector<int64_t> sources, bool all_sources,
+	                    TableCatalogEntry *edge_table, vector<std::pair<idx_t, column_t>> payload,
+	                    idx_t estimated_cardinality);
+	static vector<LogicalType> OutputTypes(int hops, TableCatalogEntry &edge_table,
+	                                       const vector<std::pair<idx_t, column_t>> &payload);
+
+	shared_ptr<GGGraph> graph;
+	int hops;
+	vector<int64_t> sources;
+	bool all_sources;
+	TableCatalogEntry *edge_table;
+	vector<std::pair<idx_t, column_t>> payload;
+
+public:
+	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;
+	void GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate,
+	             LocalSourceState &lstate) const override;
+	bool IsSource() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_PATH_EDGES";
 	}
 };
 

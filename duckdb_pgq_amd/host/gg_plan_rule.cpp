@@ -78,6 +78,7 @@
 #include "duckdb/planner/operator/logical_get.hpp"
 #include "duckdb/planner/operator/logical_insert.hpp"
 #include "duckdb/planner/operator/logical_delete.hpp"
+#include "duckdb/transaction/transaction.hpp"
 #include "duckdb/planner/operator/logical_update.hpp"
 #include "gg_extension.hpp"
 #include "gg_pipeline.hpp"
@@ -1326,6 +1327,39 @@ unique_ptr<PhysicalOperator> PlanSameNeighbourPaths(LogicalComparisonJoin &op, P
 }
 
 //! Join rule: the subtree's columns are walk vertices.
+//! The same walks with payload columns of the edge table: the graph is built with the edges' rowids, the expansion
+//! returns the rowid of every edge of every walk, PhysicalGGPathEdges fetches the columns by rowid (scan-function
+//! route: the tables are read when the scan opens).
+unique_ptr<PhysicalOperator> MakeEdgeScan(const WalkPattern &pattern, const vector<std::pair<idx_t, column_t>> &payload,
+                                          idx_t estimated_cardinality) {
+	auto spec = GraphSpecOf(pattern);
+	spec.edges.columns.push_back(COLUMN_IDENTIFIER_ROW_ID);
+	const int hops = (int)pattern.hops;
+	const auto sources = pattern.sources;
+	const bool all_sources = pattern.all_sources;
+	auto edge_table = pattern.edge_table;
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = GGBuildGraph(context, spec);
+		opened.source = make_unique<PhysicalGGPathEdges>(opened.graph, hops, sources, all_sources, edge_table, payload, 0);
+	};
+	data->description = pattern.edge_table->name + ": " + pattern.edge_table->columns[pattern.src_column].name + " -> " +
+	                    pattern.edge_table->columns[pattern.dst_column].name + "\n" + to_string(hops) +
+	                    (hops == 1 ? " hop" : " hops") + "\nwith " + to_string(payload.size()) +
+	                    (payload.size() == 1 ? " edge column by rowid" : " edge columns by rowid") +
+	                    (all_sources ? string() : "\nfrom " + to_string(sources[0]));
+	auto types = PhysicalGGPathEdges::OutputTypes(hops, *edge_table, payload);
+	vector<column_t> column_ids;
+	vector<string> names;
+	for (idx_t c = 0; c < types.size(); c++) {
+		column_ids.push_back(c);
+		names.push_back("c" + to_string(c));
+	}
+	g_rules_fired++;
+	return make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_path_edges"), move(data), move(column_ids),
+	                                      move(names), nullptr, estimated_cardinality);
+}
+
 unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 	PatternInput in;
 	WalkPattern pattern;
@@ -1341,6 +1375,9 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 		return nullptr;
 	}
 	vector<unique_ptr<Expression>> select_list;
+	//! columns of edge instances other than the two keys: (1-based edge number, column) — fetched by rowid behind the
+	//! expansion (PhysicalGGPathEdges); scan column 2 + hops + index
+	vector<std::pair<idx_t, column_t>> payload;
 	for (idx_t i = 0; i < bindings.size(); i++) {
 		LeafColumn column;
 		if (!ResolveLeafColumn(in, bindings[i], column)) {
@@ -1354,7 +1391,16 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 			} else if (column.column == pattern.dst_column) {
 				position = pattern.edge_position[column.leaf];
 			} else {
-				return nullptr;
+				if (table.columns[column.column].type != op.types[i] || pattern.hops > 4) {
+					return nullptr;
+				}
+				const auto entry = std::make_pair(pattern.edge_position[column.leaf], (column_t)column.column);
+				idx_t at = std::find(payload.begin(), payload.end(), entry) - payload.begin();
+				if (at == payload.size()) {
+					payload.push_back(entry);
+				}
+				select_list.push_back(make_unique<BoundReferenceExpression>(op.types[i], 2 + pattern.hops + at));
+				continue;
 			}
 		} else {
 			if (column.column != pattern.vertex_key) {
@@ -1372,7 +1418,11 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 		}
 		select_list.push_back(move(ref));
 	}
-	auto scan = MakeExpandScan(pattern, false, op.estimated_cardinality);
+	if (!payload.empty() && (!g_plan_context || Transaction::GetTransaction(*g_plan_context).ChangesMade())) {
+		return nullptr; // (rows this transaction has appended have no rowid the base table could be asked for)
+	}
+	auto scan = payload.empty() ? MakeExpandScan(pattern, false, op.estimated_cardinality)
+	                            : MakeEdgeScan(pattern, payload, op.estimated_cardinality);
 	if (!pattern.residual.empty()) {
 		// predicates on walk positions other than the source: a filter over the scan's (hops, v0, v1, ...)
 		vector<unique_ptr<Expression>> predicates;

@@ -178,6 +178,16 @@ int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows);
 /* Copy rows [offset, offset+max_rows) of the h-hop table into cols[0..h] (host arrays of >= max_rows). */
 int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *cols,
                     uint32_t *n_out);
+/* k-hop walks with the ROWID of every edge taken (src_ids NULL: from every vertex): table k of the result has the id
+ * columns v0..vk (gg_result_fetch) and the edge columns e1..ek (gg_result_fetch_edges: the rowid the Sink passed with
+ * the edge row, or its append position if it passed none).  This is what a late join with the edge table's payload
+ * columns needs (the reference gathers build-side columns per match, src/execution/join_hashtable.cpp:466-473).  The
+ * CSR must have been built with edge rowids kept (gg_ctx_set_edge_rowid(ctx, 1), the default).  stats: rows[k] only. */
+int gg_expand_khop_edges(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k,
+                         gg_khop_stats *stats, gg_result **out_result);
+/* Copy rows [offset, offset+max_rows) of the edge columns e1..e_hops into ecols[0..hops-1]. */
+int gg_result_fetch_edges(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *ecols,
+                          uint32_t *n_out);
 /* Checksum of the `hops`-hop rows (1 <= hops <= 4) as they stand in HBM: every id of every row is mapped back to its
  * dense index and the rows' hashes are summed exactly as gg_khop_stats.digest[hops] sums them, so a materialising
  * expansion can be compared with the count-only expansion (and with the oracle) over ALL its rows without fetching

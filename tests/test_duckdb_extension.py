@@ -712,6 +712,51 @@ def test_a_substituted_scan_in_the_recursive_arm_of_a_cte(db):
 
 
 @pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
+def test_join_chains_with_payload_columns_of_their_edges(db):
+    """Columns of the edge instances other than the two keys (the reference gathers them from the hash join's build
+    side per match, join_hashtable.cpp:466-473): the walks come back from the device with the rowid of every edge,
+    the columns are fetched by rowid in the statement's transaction (GG_PATH_EDGES).  INTEGER and VARCHAR columns
+    with NULLs, parallel edges (every combination of them is a row of its own), one and all sources, three hops,
+    under an aggregate; a transaction with changes of its own keeps the reference's joins."""
+    d, vid = db
+    d.execute("CREATE TABLE kw (a BIGINT NOT NULL, b BIGINT NOT NULL, w INTEGER, tag VARCHAR)")
+    d.execute("INSERT INTO kw SELECT k_person1id, k_person2id, CAST(k_person1id % 97 AS INTEGER), "
+              "CASE WHEN k_person2id % 5 = 0 THEN NULL ELSE 't' || CAST(k_person2id % 11 AS VARCHAR) END "
+              "FROM knows WHERE k_person1id >= 0 AND k_person2id >= 0 AND k_person1id % 4 = 0")
+    d.execute("INSERT INTO kw SELECT a, b, w + 1000, 'dup' FROM kw WHERE a % 8 = 0")  # parallel edges, other payload
+    s = int(d.execute("SELECT min(a) FROM kw")[0, 0])
+    cases = [
+        "SELECT k1.a, k1.w, k2.b, k2.w FROM kw k1, kw k2 WHERE k1.b = k2.a",
+        f"SELECT k1.w, k2.tag, k2.b FROM kw k1, kw k2 WHERE k1.b = k2.a AND k1.a = {s}",
+        "SELECT count(*), sum(k1.w), sum(k3.w), count(k2.tag), min(k3.tag) FROM kw k1, kw k2, kw k3 "
+        "WHERE k1.b = k2.a AND k2.b = k3.a",
+    ]
+    for sql in cases:
+        d.execute("PRAGMA disable_gpu_graph")
+        cpu = d.execute_text(sql)
+        d.execute("PRAGMA enable_gpu_graph")
+        try:
+            plan = d.explain(sql)
+            gpu = d.execute_text(sql)
+        finally:
+            d.execute("PRAGMA disable_gpu_graph")
+        assert "GG_PATH_EDGES" in plan and "HASH_JOIN" not in plan, plan
+        key = lambda row: tuple("\0NULL" if c is None else c for c in row)  # noqa: E731
+        assert len(cpu) > 0 and sorted(cpu, key=key) == sorted(gpu, key=key), sql
+    # rows this transaction has appended have no rowid the base table could be asked for: the joins stay
+    d.execute("PRAGMA enable_gpu_graph")
+    try:
+        d.execute("BEGIN TRANSACTION")
+        d.execute(f"INSERT INTO kw VALUES ({s}, {s}, 5, 'mine')")
+        assert "GG_PATH_EDGES" not in d.explain(cases[0])
+        inside = d.execute_text(cases[1])
+        d.execute("ROLLBACK")
+    finally:
+        d.execute("PRAGMA disable_gpu_graph")
+    assert any("mine" in " ".join(str(c) for c in row) for row in inside)
+
+
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_several_substituted_scans_in_one_plan(db):
     """Two (three) GPU scans in one statement, each with its own sink pipelines: under UNION ALL (the second scan
     is the source of a union pipeline), on both sides of a join, and under a UNION that is deduped."""

@@ -223,6 +223,59 @@ def test_two_hop_rows_by_middle_vertex_ranges_partition_the_materialised_result(
     g.close()
 
 
+def test_walks_with_their_edge_rowids(gg, orc):
+    """gg_expand_khop_edges: every walk comes with the rowid of each edge it takes (what a late join with the edge
+    table's payload columns needs).  Checked on a multigraph with explicit, non-contiguous rowids: the vertex columns
+    are the join formulation's rows; edge j of every row really is a table row (v_{j-1}, v_j); no edge sequence
+    repeats; with parallel edges the number of rows is the product of the multiplicities; all sources and a source
+    list; and append positions stand in when the Sink passed no rowids."""
+    vid, src, dst = datagen.small_graph(200, 1500, 77, dangling=5, dup_edges=40)
+    rowid = (np.arange(src.size, dtype=np.int64) * 7 + 1000)[::-1].copy()  # explicit, not the append order
+    gg.staging_clear()
+    gg.set_edge_rowid(True)
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst, rowid=rowid)
+    csr = gg.build_csr()
+    by_rowid = {int(r): (int(a), int(b)) for r, a, b in zip(rowid, src, dst)}
+    sources = np.concatenate([datagen.pick_sources(vid, 25, 4), np.array([-3], np.int64)])
+    for k in (1, 2, 3):
+        ref = vid[orc.khop_join(vid, src, dst, k, k)[k]]
+        for srcs in (None, sources):
+            res = gg.expand_khop_edges(csr, k, sources=srcs)
+            n = res.rows(k)
+            v = np.concatenate([res.fetch(k, o) for o in range(0, n, 1024)]) if n else np.zeros((0, k + 1), np.int64)
+            e = np.concatenate([res.fetch_edges(k, o) for o in range(0, n, 1024)]) if n else np.zeros((0, k), np.int64)
+            res.close()
+            want = ref if srcs is None else ref[np.isin(ref[:, 0], srcs)]
+            assert np.array_equal(sort_rows(v), sort_rows(want)), (k, srcs is None)
+            for j in range(k):
+                ends = np.array([by_rowid[int(r)] for r in e[:, j]], np.int64).reshape(-1, 2)
+                assert np.array_equal(ends, v[:, j:j + 2]), (k, j)
+            assert np.unique(e, axis=0).shape[0] == e.shape[0]
+    csr.close()
+    # no explicit rowids: the append position is the edge's id
+    gg.staging_clear()
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    csr = gg.build_csr()
+    res = gg.expand_khop_edges(csr, 2)
+    n = res.rows(2)
+    v = np.concatenate([res.fetch(2, o) for o in range(0, n, 1024)])
+    e = np.concatenate([res.fetch_edges(2, o) for o in range(0, n, 1024)])
+    res.close()
+    for j in range(2):
+        assert np.array_equal(np.stack([src[e[:, j]], dst[e[:, j]]], axis=1), v[:, j:j + 2])
+    csr.close()
+    gg.set_edge_rowid(False)
+    gg.staging_clear()
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    csr = gg.build_csr()
+    with pytest.raises(Exception):
+        gg.expand_khop_edges(csr, 1)
+    csr.close()
+
+
 def test_khop_source_list(gg, orc):
     vid, src, dst = datagen.ldbc_knows(2000, 60_000, 5)
     csr, g = build_both(gg, orc, vid, src, dst)

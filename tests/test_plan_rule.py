@@ -55,6 +55,11 @@ TAKEN = [
     (R.sql_khop(1), "GG_PATH_COUNT", "vertices: person.p_personid"),
     (R.sql_khop(2), "GG_PATH_COUNT", "vertices: person.p_personid"),
     (R.sql_khop_rows(2), "GG_PATH_EXPAND", "2 hops"),
+    # payload columns of the edge instances: the walks come with their edges' rowids, the columns by rowid
+    (chain(2, select="k1.k_weight"), "GG_PATH_EDGES", "with 1 edge column by rowid"),
+    (chain(3, select="k1.k_person1id, k1.k_weight, k3.k_weight, k3.k_person2id, k1.k_weight"), "GG_PATH_EDGES",
+     "with 2 edge columns by rowid"),
+    (chain(2, select="k2.k_weight") + " AND k1.k_person1id = 2", "GG_PATH_EDGES", "from 2"),
     # single source pinned by a constant
     (chain(2, select="k2.k_person2id") + " AND k1.k_person1id = 2", "GG_PATH_EXPAND", "from 2"),
     (chain(2) + " AND k2.k_person2id = 3", "GG_PATH_COUNT", "from 3"),
@@ -78,8 +83,8 @@ LEFT_ALONE = [
     "WHERE p0.p_personid = k1.k_person1id AND k1.k_person2id = p1.p_personid",
     # nullable edge columns in an edge-only chain: the outer ends are not join keys
     chain(2, table="knows_nullable", a="a", b="b"),
-    # payload columns, non-equality predicates, outer joins, other filters
-    chain(2, select="k1.k_weight"),
+    # non-equality predicates, outer joins, other filters; a predicate on an edge's payload column
+    "SELECT k1.k_weight FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id AND k2.k_weight > 0",
     "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id < k2.k_person1id",
     "SELECT count(*) FROM knows k1 LEFT JOIN knows k2 ON k1.k_person2id = k2.k_person1id",
     # aggregates other than an ungrouped count(*) keep their aggregate; the join under them is still a walk
