@@ -143,7 +143,8 @@ static shared_ptr<GGGraph> FindPinned(ClientContext &context, const GGGraphSpec 
 static shared_ptr<GGGraph> BuildGraphNow(ClientContext &context, const GGGraphSpec &spec) {
 	PhaseTimer timer;
 	const bool edge_rowids = spec.edges.columns.size() >= 3 || (!spec.edges.table && spec.edges_with_rowid);
-	auto graph = make_shared<GGGraph>(0, edge_rowids);  // (a third edge column is the rowid: walks with their edges)
+	// (a third edge column is the rowid: walks with their edges)
+	auto graph = make_shared<GGGraph>(0, edge_rowids, edge_rowids ? 1 : spec.shards);
 	timer.Lap("device context");
 	const bool derive = spec.vertices.Empty();
 	if (!derive) {

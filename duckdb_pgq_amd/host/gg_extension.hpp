@@ -49,6 +49,7 @@ struct GGGraphSpec {
 	GGScanSource vertices; // key column; empty: vertex set = distinct endpoint ids of the edges
 	GGScanSource edges;    // (src, dst[, rowid])
 	bool edges_with_rowid = false; // (SQL sources: the statement's third column is the edge's rowid)
+	int shards = 1; // > 1: ownership-sharded over that many device contexts (GGGraph::peers)
 };
 
 //! Push every row of `source` through `sink` the way a pipeline would: GetGlobalSinkState, Sink per

@@ -65,7 +65,48 @@ struct GGContextPool {
 };
 static GGContextPool g_context_pool;
 
-GGGraph::GGGraph(int device_p, bool keep_edge_rowids) : device(device_p) {
+int GGGraph::ConfiguredParts() {
+	auto env = std::getenv("GG_DEVICES");
+	const long n = env ? std::strtol(env, nullptr, 10) : 1;
+	return (int)MaxValue<long>(1, MinValue<long>(n, 64));
+}
+
+void GGGraph::ForEachPart(const std::function<void(int, GGGraph &)> &fn) {
+	if (peers.empty()) {
+		fn(0, *this);
+		return;
+	}
+	// one host thread per part: each part's calls go to its own context (own device, own stream), so the
+	// parts' uploads and kernels run side by side
+	vector<std::thread> threads;
+	vector<std::exception_ptr> errors(Parts());
+	for (int p = 0; p < Parts(); p++) {
+		threads.emplace_back([&, p] {
+			try {
+				fn(p, Part(p));
+			} catch (...) {
+				errors[p] = std::current_exception();
+			}
+		});
+	}
+	for (auto &thread : threads) {
+		thread.join();
+	}
+	for (auto &error : errors) {
+		if (error) {
+			std::rethrow_exception(error);
+		}
+	}
+}
+
+GGGraph::GGGraph(int device_p, bool keep_edge_rowids, int parts) : device(device_p) {
+	if (parts > 1) {
+		int devices = 0;
+		Check(gg_device_count(&devices), "gg_device_count");
+		for (int p = 1; p < parts; p++) {
+			peers.push_back(make_unique<GGGraph>((device_p + p) % MaxValue(devices, 1), keep_edge_rowids, 1));
+		}
+	}
 	ctx = g_context_pool.Acquire(device);
 	if (ctx) {
 		Check(gg_staging_clear(ctx), "gg_staging_clear");
@@ -226,9 +267,11 @@ static void FlushEdgeBatch(GGGraph &graph, GGSinkLocalState &lstate, bool has_ro
 	if (lstate.batch_rows == 0) {
 		return;
 	}
-	GGGraph::Check(gg_edges_append(graph.ctx, lstate.batch[0].data(), lstate.batch[1].data(),
-	                               has_rowid ? lstate.batch[2].data() : nullptr, lstate.batch_rows),
-	               "gg_edges_append");
+	for (int p = 0; p < graph.Parts(); p++) {
+		GGGraph::Check(gg_edges_append(graph.Part(p).ctx, lstate.batch[0].data(), lstate.batch[1].data(),
+		                               has_rowid ? lstate.batch[2].data() : nullptr, lstate.batch_rows),
+		               "gg_edges_append");
+	}
 	lstate.batch_rows = 0;
 }
 
@@ -238,7 +281,9 @@ PhysicalGGVertexSink::PhysicalGGVertexSink(shared_ptr<GGGraph> graph_p, vector<L
 }
 
 unique_ptr<GlobalSinkState> PhysicalGGVertexSink::GetGlobalSinkState(ClientContext &context) const {
-	GGGraph::Check(gg_staging_clear(graph->ctx), "gg_staging_clear");
+	for (int p = 0; p < graph->Parts(); p++) {
+		GGGraph::Check(gg_staging_clear(graph->Part(p).ctx), "gg_staging_clear");
+	}
 	return make_unique<GGSinkGlobalState>();
 }
 
@@ -252,7 +297,9 @@ SinkResultType PhysicalGGVertexSink::Sink(ExecutionContext &context, GlobalSinkS
 	auto &lstate = (GGSinkLocalState &)lstate_p;
 	idx_t n = GGKeyColumns(input, {0}, lstate.columns, lstate.keys);
 	// thread-safe append (gg.h): one call per DataChunk, like JoinHashTable::Build per Sink call
-	GGGraph::Check(gg_vertices_append(graph->ctx, lstate.keys[0], n), "gg_vertices_append");
+	for (int p = 0; p < graph->Parts(); p++) {
+		GGGraph::Check(gg_vertices_append(graph->Part(p).ctx, lstate.keys[0], n), "gg_vertices_append");
+	}
 	gstate.rows += n;
 	return SinkResultType::NEED_MORE_INPUT;
 }
@@ -273,12 +320,17 @@ PhysicalGGEdgeSink::PhysicalGGEdgeSink(shared_ptr<GGGraph> graph_p, vector<Logic
 }
 
 unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext &context) const {
+	if (graph->Parts() > 1 && (as_filter || !build)) {
+		throw InternalException("a sharded graph has one edge table");
+	}
 	if (as_filter) {
 		// second edge table over the same staged vertices: drop the first table's staged rows only
 		GGGraph::Check(gg_staging_clear_edges(graph->ctx), "gg_staging_clear_edges");
 	} else if (derive_vertices && !keep_vertices) {
 		// no vertex sink ran before this one: start from empty staging
-		GGGraph::Check(gg_staging_clear(graph->ctx), "gg_staging_clear");
+		for (int p = 0; p < graph->Parts(); p++) {
+			GGGraph::Check(gg_staging_clear(graph->Part(p).ctx), "gg_staging_clear");
+		}
 	}
 	return make_unique<GGSinkGlobalState>();
 }
@@ -321,6 +373,23 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
                                               GlobalSinkState &gstate) const {
 	// single-threaded, after every Sink/Combine (physical_operator.hpp:145-147): build the index
 	lock_guard<mutex> guard(graph->lock);
+	if (graph->Parts() > 1) {
+		// every part saw every row; each derives the same vertex numbering (sorted distinct endpoint ids) or staged
+		// the same vertex table, and keeps the CSR rows of the vertices it owns
+		const int parts = graph->Parts();
+		graph->ForEachPart([&](int p, GGGraph &part) {
+			if (part.csr) {
+				gg_csr_destroy(part.csr);
+				part.csr = nullptr;
+			}
+			if (derive_vertices) {
+				GGGraph::Check(gg_vertices_from_edges(part.ctx, keep_vertices ? 1 : 0, nullptr),
+				               "gg_vertices_from_edges");
+			}
+			GGGraph::Check(gg_csr_build_shard(part.ctx, p, parts, &part.csr), "gg_csr_build_shard");
+		});
+		return SinkFinalizeType::READY;
+	}
 	gg_csr *&target = as_filter ? graph->filter_csr : graph->csr;
 	if (target) {
 		gg_csr_destroy(target);
@@ -421,6 +490,34 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 	lock_guard<mutex> guard(graph->lock);
 	if (!graph->csr) {
 		throw InternalException("GG_PATH_EXPAND scheduled before the CSR was built");
+	}
+	if (graph->Parts() > 1) {
+		// ownership-sharded graph: part p counts the walks whose middle vertex (1-hop: destination) it owns;
+		// counts add, digests add (gg.h: gg_csr_build_shard) — the same combine bench.py's ranks do with one
+		// all-reduce, here across the contexts of one process
+		if (!count_only || !all_sources || k_max > 2) {
+			throw InternalException("GG_PATH_EXPAND over a sharded graph: only the count of all walks of <= 2 hops");
+		}
+		vector<gg_khop_stats> per_part(graph->Parts());
+		graph->ForEachPart([&](int p, GGGraph &part) {
+			if (!part.csr) {
+				throw InternalException("GG_PATH_COUNT scheduled before the CSR shards were built");
+			}
+			GGGraph::Check(gg_expand_khop(part.ctx, part.csr, nullptr, 0, k_min, k_max, 0, &per_part[p], nullptr),
+			               "gg_expand_khop");
+		});
+		memset(&state->stats, 0, sizeof(state->stats));
+		for (auto &stats : per_part) {
+			for (int h = 0; h <= GG_MAX_HOPS; h++) {
+				state->stats.rows[h] += stats.rows[h];
+				// (a u32 sum carried in the low half: DESIGN.md "Row digest")
+				state->stats.digest[h] = (state->stats.digest[h] + stats.digest[h]) & 0xFFFFFFFFull;
+			}
+			state->stats.traversed_edges += stats.traversed_edges;
+			state->stats.frontier_entries += stats.frontier_entries;
+		}
+		state->hop = k_min;
+		return move(state);
 	}
 	// count first: cheap (nothing is written), and it tells how much HBM the walks would take
 	GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(), k_min,

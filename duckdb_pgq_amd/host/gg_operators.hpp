@@ -18,6 +18,7 @@
 #pragma once
 
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -32,8 +33,23 @@ class TableCatalogEntry;
 //! Device graph shared by the sinks that build it and the sources that query it.
 struct GGGraph {
 	//! keep_edge_rowids: the CSR keeps the rowid the edge sink gets as its third column (walks with their edges)
-	explicit GGGraph(int device, bool keep_edge_rowids = false);
+	//! parts > 1: the graph is ownership-sharded (gg_csr_build_shard, gg.h) — this object is part 0 and `peers`
+	//! are parts 1..parts-1, each with a context of its own on device part % gg_device_count.  The sinks hand every
+	//! chunk to every part (a part skips the rows it does not own before the id lookups), the parts build side by
+	//! side, and the only source that accepts such a graph is the count of all 1..2-hop walks, whose per-part
+	//! counts add (no data-path collective: SURVEY.md section 8e).
+	explicit GGGraph(int device, bool keep_edge_rowids = false, int parts = 1);
 	~GGGraph();
+	//! number of graphs a plan over all sources counting <= 2-hop walks is sharded over: GG_DEVICES (default 1)
+	static int ConfiguredParts();
+	int Parts() const {
+		return 1 + (int)peers.size();
+	}
+	GGGraph &Part(int p) {
+		return p == 0 ? *this : *peers[p - 1];
+	}
+	//! fn(part index, part) on one thread per part; the first exception is rethrown on the caller's
+	void ForEachPart(const std::function<void(int, GGGraph &)> &fn);
 	//! Turn a non-zero gg status into the exception the reference's operators would throw.
 	static void Check(int rc, const char *what);
 
@@ -42,6 +58,7 @@ struct GGGraph {
 	gg_csr *csr = nullptr;        // path graph
 	gg_csr *filter_csr = nullptr; // optional second edge table over the same vertex set (same-neighbour filter)
 	std::mutex lock; // gg calls other than the appends are externally serialised (gg.h)
+	vector<unique_ptr<GGGraph>> peers;
 };
 
 //! Copy one integer key column of a chunk into `out` (BIGINT or INTEGER physical type, any vector

@@ -72,7 +72,7 @@ PhysicalGGLazySink::PhysicalGGLazySink(shared_ptr<GGGraphSlot> slot_p, EdgeOptio
 unique_ptr<GlobalSinkState> PhysicalGGLazySink::GetGlobalSinkState(ClientContext &context) const {
 	lock_guard<mutex> guard(slot->lock);
 	if (kind == VERTICES || kind == EDGES_DERIVE_VERTICES || (kind == EDGES_CUSTOM && options.first)) {
-		slot->graph = make_shared<GGGraph>(0); // first sink of an execution: a fresh graph
+		slot->graph = make_shared<GGGraph>(0, false, slot->shards); // first sink of an execution: a fresh graph
 	}
 	if (!slot->graph) {
 		throw InternalException("GG_EDGE_SINK scheduled before its vertex sink");
@@ -248,6 +248,7 @@ unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<Log
                                              string description, bool parallel_result,
                                              PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality) {
 	auto slot = make_shared<GGGraphSlot>();
+	slot->shards = spec.shards;
 	auto scan = make_unique<PhysicalGGGraphScan>(move(types), move(name), move(description), slot, move(factory),
 	                                             parallel_result, estimated_cardinality);
 	const bool derive = spec.vertices.Empty();

@@ -12,6 +12,7 @@ namespace duckdb {
 struct GGGraphSlot {
 	mutex lock;
 	shared_ptr<GGGraph> graph;
+	int shards = 1; // GGGraphSpec::shards of the plan
 };
 
 //! PhysicalGGVertexSink / PhysicalGGEdgeSink created when the pipeline starts (the device context with them), so a

@@ -893,10 +893,6 @@ bool SolveWalkPattern(PatternInput &in, WalkPattern &out) {
 	return false;
 }
 
-string QualifiedName(TableCatalogEntry &table) {
-	return GGQuote(table.schema->name) + "." + GGQuote(table.name);
-}
-
 //! tables the plan being substituted reads; registered with the generator like LogicalGet's dependency
 //! callback does (plan_get.cpp:50-52), so a prepared statement notices when one of them is dropped
 thread_local vector<CatalogEntry *> g_plan_tables;
@@ -922,10 +918,16 @@ GGGraphSpec GraphSpecOf(const WalkPattern &pattern) {
 
 //! PhysicalTableScan over the gg scan function for `hops`-hop walks of the pattern.
 unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool count_only, idx_t estimated_cardinality) {
-	const auto spec = GraphSpecOf(pattern);
+	auto spec = GraphSpecOf(pattern);
 	const int hops = (int)pattern.hops;
 	const auto sources = pattern.sources;
 	const bool all_sources = pattern.all_sources;
+	if (count_only && all_sources && hops <= 2) {
+		// the one plan shape whose result adds over ownership shards of the graph: with GG_DEVICES=N the tables
+		// go to N device contexts (device p mod the devices present) and N CSR shards are built and counted side
+		// by side — bench.py's N ranks inside one process, for a host with several GPUs
+		spec.shards = GGGraph::ConfiguredParts();
+	}
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &context, GGOpened &opened) {
 		opened.graph = GGBuildGraph(context, spec);
@@ -937,7 +939,8 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	                    (pattern.vertex_table ? pattern.vertex_table->name + "." +
 	                                                pattern.vertex_table->columns[pattern.vertex_key].name
 	                                          : string("endpoint ids")) +
-	                    (all_sources ? string() : "\nfrom " + to_string(sources[0]));
+	                    (all_sources ? string() : "\nfrom " + to_string(sources[0])) +
+	                    (spec.shards > 1 ? "\nshards: " + to_string(spec.shards) : string());
 	data->parallel_result = !count_only;
 	auto types = PhysicalGGPathExpand::OutputTypes(hops, count_only);
 	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {

@@ -782,3 +782,47 @@ def test_several_substituted_scans_in_one_plan(db):
             d.execute("PRAGMA disable_gpu_graph")
         assert plan.count("GG_EDGE_SINK") >= 2, plan
         assert np.array_equal(sort_rows(cpu), sort_rows(gpu)), sql
+
+
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
+def test_the_count_of_two_hop_walks_over_an_ownership_sharded_graph(db, monkeypatch):
+    """GG_DEVICES=N: the one plan shape whose result adds over shards — count(*) of all 1- or 2-hop walks — has its
+    tables appended to N device contexts (device p mod the devices present: all on the one GPU here), N CSR shards
+    built by gg_csr_build_shard and counted side by side; the counts add.  bench.py's N ranks inside one process,
+    reached from the reference's executor.  Every other plan keeps its single graph."""
+    d, vid = db
+    d.execute("CREATE TABLE IF NOT EXISTS person_pk2 (p_personid BIGINT PRIMARY KEY)")
+    if int(d.execute("SELECT count(*) FROM person_pk2")[0, 0]) == 0:
+        d.execute("INSERT INTO person_pk2 SELECT p_personid FROM person")
+    keyed = lambda sql: sql.replace("person ", "person_pk2 ")
+    counts = [_chain(2, "count(*)"), "SELECT count(*) FROM knows", keyed(R.sql_khop(1)), keyed(R.sql_khop(2))]
+    d.execute("PRAGMA disable_gpu_graph")
+    want = [d.execute(q) for q in counts]
+    rows_sql = _chain(2, "k1.k_person1id, k2.k_person2id")
+    want_rows = d.execute(rows_sql)
+    want3 = d.execute(_chain(3, "count(*)"))
+    d.execute("PRAGMA enable_gpu_graph")
+    try:
+        for parts in ("3", "8"):
+            monkeypatch.setenv("GG_DEVICES", parts)
+            for q, w in zip(counts, want):
+                if "GG_PATH_COUNT" not in d.explain(q):
+                    continue  # (a bare count(*) of the edge table is not a walk pattern)
+                assert f"shards: {parts}" in d.explain(q), d.explain(q)
+                assert np.array_equal(d.execute(q), w), q
+            assert "shards" not in d.explain(rows_sql) and "shards" not in d.explain(_chain(3, "count(*)"))
+            assert np.array_equal(sort_rows(d.execute(rows_sql)), sort_rows(want_rows))
+            assert np.array_equal(d.execute(_chain(3, "count(*)")), want3)
+        # the scan-function route builds the same shards from its own sink pipelines
+        monkeypatch.setenv("GG_NO_PIPELINE_SINKS", "1")
+        assert "GG_EDGE_SINK" not in d.explain(counts[0]) and "shards: 8" in d.explain(counts[0])
+        assert np.array_equal(d.execute(counts[0]), want[0])
+        assert np.array_equal(d.execute(counts[3]), want[3])
+        monkeypatch.delenv("GG_NO_PIPELINE_SINKS")
+        # prepared: the graph is rebuilt, sharded, on every execution
+        d.execute("PREPARE sharded AS " + counts[0])
+        for _ in range(2):
+            assert np.array_equal(d.execute("EXECUTE sharded"), want[0])
+        d.execute("DEALLOCATE sharded")
+    finally:
+        d.execute("PRAGMA disable_gpu_graph")
