@@ -495,8 +495,8 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 		// ownership-sharded graph: part p counts the walks whose middle vertex (1-hop: destination) it owns;
 		// counts add, digests add (gg.h: gg_csr_build_shard) — the same combine bench.py's ranks do with one
 		// all-reduce, here across the contexts of one process
-		if (!count_only || !all_sources || k_max > 2) {
-			throw InternalException("GG_PATH_EXPAND over a sharded graph: only the count of all walks of <= 2 hops");
+		if (!count_only || !all_sources || k_max != 2) {
+			throw InternalException("GG_PATH_EXPAND over a sharded graph: only the count of all 2-hop walks (with or without the 1-hop ones)");
 		}
 		vector<gg_khop_stats> per_part(graph->Parts());
 		graph->ForEachPart([&](int p, GGGraph &part) {

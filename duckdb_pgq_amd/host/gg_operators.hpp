@@ -36,11 +36,11 @@ struct GGGraph {
 	//! parts > 1: the graph is ownership-sharded (gg_csr_build_shard, gg.h) — this object is part 0 and `peers`
 	//! are parts 1..parts-1, each with a context of its own on device part % gg_device_count.  The sinks hand every
 	//! chunk to every part (a part skips the rows it does not own before the id lookups), the parts build side by
-	//! side, and the only source that accepts such a graph is the count of all 1..2-hop walks, whose per-part
+	//! side, and the only source that accepts such a graph is the count of all 2-hop walks (k_max = 2, gg.h), whose per-part
 	//! counts add (no data-path collective: SURVEY.md section 8e).
 	explicit GGGraph(int device, bool keep_edge_rowids = false, int parts = 1);
 	~GGGraph();
-	//! number of graphs a plan over all sources counting <= 2-hop walks is sharded over: GG_DEVICES (default 1)
+	//! number of graphs a plan counting the 2-hop walks of all sources is sharded over: GG_DEVICES (default 1)
 	static int ConfiguredParts();
 	int Parts() const {
 		return 1 + (int)peers.size();

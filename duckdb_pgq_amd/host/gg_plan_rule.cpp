@@ -922,7 +922,7 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	const int hops = (int)pattern.hops;
 	const auto sources = pattern.sources;
 	const bool all_sources = pattern.all_sources;
-	if (count_only && all_sources && hops <= 2) {
+	if (count_only && all_sources && hops == 2) {
 		// the one plan shape whose result adds over ownership shards of the graph: with GG_DEVICES=N the tables
 		// go to N device contexts (device p mod the devices present) and N CSR shards are built and counted side
 		// by side — bench.py's N ranks inside one process, for a host with several GPUs
