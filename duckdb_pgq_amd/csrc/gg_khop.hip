@@ -1217,12 +1217,28 @@ int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
 // The materialising counterpart of k_expand_mid2 for walks from EVERY vertex: the rows u -> x -> w through a middle
 // vertex x are in(x) x out(x), and the reverse CSR lists the 1-hop rows u -> x grouped by x.  k_mat_last, one parent
 // row at a time in source order, translates every child to its id — a random 8-byte gather per OUTPUT row (1.06 G at
-// SF10, more time than the stores).  Here the ids of out(x) are gathered once per run of equal x (E gathers in all),
-// kept in registers, and every reverse entry of the run writes them behind its own (u, x) — stores only.  Row order
-// of a materialised result is unspecified (gg.h), so grouping the rows by middle vertex is the caller's right.
-// A tile is 256 consecutive reverse entries; the four waves share every run (entry i of a run goes to wave i mod 4).
-// Stores are 16 bytes per lane (two rows of one column); a row block that starts at an odd row writes its first row
-// singly and pairs up from the second (the same ids, paired the other way: both pairings are kept in registers).
+// SF10, more time than the stores).  Here the ids of out(x) are gathered once per run of equal x (E gathers in all)
+// into LDS, and the rest is stores.  Row order of a materialised result is unspecified (gg.h), so grouping the rows
+// by middle vertex is the caller's right.
+// A tile is 256 consecutive reverse entries.  The rows of a run's entries i0 .. i1 - 1 are (i1 - i0) blocks of dout
+// rows back to back, the same rows in all three columns: row r of that piece belongs to entry r / dout and leaf
+// r % dout (multiply-high by a per-run reciprocal).  The workgroup walks the piece flat from the 128-byte line its
+// first row lies in, two rows (16 bytes) per lane, so EVERY store instruction covers eight whole lines whatever dout
+// and the block boundaries are; only the first and last line of a piece are written in part.  That matters more than
+// anything else in this kernel: scripts/ubench_fill.hip (profiles/r03_ubench_fill.txt) writes the same three arrays
+// at 6.1 TB/s with line-aligned nontemporal 16-byte stores and at 4.45 TB/s when every instruction starts 16 bytes
+// past a line (its end lines shared with the neighbours); the earlier form — one store per entry and 128 leaves,
+// starting wherever the entry's block starts — ran at 4.8.  Out-rows longer than MAT_CAP leaves go through LDS in
+// chunks, one entry's segment of a chunk at a time (>= 16 KB per column: the part-written lines no longer count).
+#ifndef GG_MAT_CAP
+#define GG_MAT_CAP 2048
+#endif
+constexpr uint32_t MAT_CAP = GG_MAT_CAP;  // ids of out(x) staged in LDS at a time
+#ifndef GG_MAT_ALIGN
+#define GG_MAT_ALIGN 16
+#endif
+constexpr uint32_t MAT_ALIGN = GG_MAT_ALIGN;  // rows
+
 __global__ __launch_bounds__(256) void k_mat_mid2_prepare(const uint32_t *__restrict__ off, const uint32_t *__restrict__ rrow,
                                                           uint64_t e0, uint64_t n, uint64_t *__restrict__ foff) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1232,13 +1248,54 @@ __global__ __launch_bounds__(256) void k_mat_mid2_prepare(const uint32_t *__rest
   }
 }
 
+typedef long long mat_ll2 __attribute__((ext_vector_type(2)));
+
+// rows [S, S + n) of the three columns: row r = (entry ib + r / d, middle id, leaf r % d); d >= 1, n < 2^32 / d.
+// The whole workgroup; uid / oid are the tile's entry ids and the staged leaf ids in LDS.
+__device__ __forceinline__ void mat_write_rows(uint64_t S, uint32_t n, uint32_t d, uint32_t ib, long long xid,
+                                               const int64_t *uid, const int64_t *oid, int64_t *__restrict__ c0,
+                                               int64_t *__restrict__ c1, int64_t *__restrict__ c2) {
+  const uint64_t A0 = S & ~(uint64_t)(MAT_ALIGN - 1);  // first row of the 128-byte line S lies in (the columns are 256-byte aligned)
+  const uint32_t head = (uint32_t)(S - A0), total = head + n;
+  const uint32_t m = d >= 2 ? 0xFFFFFFFFu / d + 1u : 0u;  // r / d = umulhi(r, m) for r < 2^32 / d
+  mat_ll2 xx;
+  xx.x = xx.y = xid;
+  for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
+    const uint32_t hi = 2 * q + 1;  // rows 2q - head (low half) and hi - head (high half) of the piece
+    if (hi < head) continue;        // the pair lies before the piece
+    const uint32_t rh = hi - head;
+    const bool lo_ok = rh >= 1, hi_ok = rh < n;
+    const uint32_t ih = d >= 2 ? __umulhi(rh, m) : rh, jh = rh - ih * d;
+    const uint32_t il = jh ? ih : ih - 1u, jl = jh ? jh - 1u : d - 1u;
+    mat_ll2 uu, w;
+    uu.y = uid[ib + ih];  // (rh == n reads one element past the piece: the arrays are padded, the value is not stored)
+    w.y = oid[jh];
+    uu.x = lo_ok ? uid[ib + il] : 0;
+    w.x = lo_ok ? oid[jl] : 0;
+    const uint64_t o = A0 + 2 * (uint64_t)q;
+    if (lo_ok && hi_ok) {
+      __builtin_nontemporal_store(uu, reinterpret_cast<mat_ll2 *>(c0 + o));
+      __builtin_nontemporal_store(xx, reinterpret_cast<mat_ll2 *>(c1 + o));
+      __builtin_nontemporal_store(w, reinterpret_cast<mat_ll2 *>(c2 + o));
+    } else if (lo_ok) {  // last row of the piece, alone
+      c0[o] = uu.x;
+      c1[o] = xid;
+      c2[o] = w.x;
+    } else if (hi_ok) {  // first row, alone
+      c0[o + 1] = uu.y;
+      c1[o + 1] = xid;
+      c2[o + 1] = w.y;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
                                                   const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
                                                   const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
                                                   uint64_t e0, uint64_t n, int64_t *__restrict__ c0,
                                                   int64_t *__restrict__ c1, int64_t *__restrict__ c2) {
-  typedef long long ll2 __attribute__((ext_vector_type(2)));
-  __shared__ int64_t s_uid[256];
+  __shared__ int64_t s_uid[256 + 1];
+  __shared__ int64_t s_oid[MAT_CAP + 1];
   __shared__ uint64_t s_base[256];
   __shared__ uint32_t s_x[256], s_run[257], s_wcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1267,70 +1324,21 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
     s_run[nruns] = left < 256 ? (uint32_t)left : 256u;
   }
   __syncthreads();
-  for (uint32_t r = 0; r < nruns; r++) {
+  for (uint32_t r = 0; r < nruns; r++) {  // (everything below is uniform over the workgroup)
     const uint32_t i0 = s_run[r], i1 = s_run[r + 1];
     const uint32_t xr = s_x[i0], st = off[xr], dout = off[xr + 1] - st;
-    if (dout == 0) continue;  // (uniform)
+    if (dout == 0) continue;
     const long long xid = vid[xr];
-    {
-      // the middle column is ONE value over the whole piece of the run (rows of entries i0 .. i1 - 1 are contiguous):
-      // written as a plain fill, 1 KB per store instruction, a quarter of the piece per wave
-      const uint64_t Bs = s_base[i0], Be = s_base[i1 - 1] + dout;
-      ll2 xx;
-      xx.x = xx.y = xid;
-      const uint64_t a0 = (Bs + 1) & ~1ULL, npair = (Be - a0) >> 1;  // aligned pairs [a0, a0 + 2 npair)
-      const uint64_t per = (npair + 3) / 4, q0 = per * (uint64_t)wave, q1 = q0 + per < npair ? q0 + per : npair;
-      for (uint64_t q = q0 + (uint32_t)lane; q < q1; q += 64)
-        __builtin_nontemporal_store(xx, reinterpret_cast<ll2 *>(c1 + a0 + 2 * q));
-      if (wave == 0 && lane == 0) {
-        if (Bs & 1) c1[Bs] = xid;
-        if ((Be - a0) & 1) c1[Be - 1] = xid;
-      }
-    }
-    if (i0 + wave >= i1) continue;  // (uniform per wave)
-    // (several entries side by side in one store instruction for short out-rows — 64 / ppe entries of (dout + 1) / 2
-    // lane pairs each — was slower: 7.7 against 6.6 ms at SF10; the per-lane entry look-ups cost more than the
-    // half-empty stores)
-    for (uint32_t jb = 0; jb < dout; jb += 128) {
-      // leaves jb + 2 lane .. + 2 of the out-row, as ids: (e0, e1) is the pair of an even row block, (e1, o1) of an odd
-      const uint32_t k = jb + 2 * (uint32_t)lane;
-      const long long e0v = k < dout ? vid[nbr[st + k]] : 0;
-      const long long e1v = k + 1 < dout ? vid[nbr[st + k + 1]] : 0;
-      const long long o1v = k + 2 < dout ? vid[nbr[st + k + 2]] : 0;
-      for (uint32_t i = i0 + wave; i < i1; i += 4) {
-        const uint64_t B = s_base[i];  // first output row of this entry's block (uniform)
-        const long long uid = s_uid[i];
-        ll2 uu;
-        uu.x = uu.y = uid;
-        if ((B & 1) == 0) {  // rows B + k, B + k + 1: aligned pair
-          const uint64_t o = B + k;
-          if (k + 1 < dout) {
-            ll2 w;
-            w.x = e0v;
-            w.y = e1v;
-            __builtin_nontemporal_store(w, reinterpret_cast<ll2 *>(c2 + o));
-            __builtin_nontemporal_store(uu, reinterpret_cast<ll2 *>(c0 + o));
-          } else if (k < dout) {  // odd last row
-            c2[o] = e0v;
-            c0[o] = uid;
-          }
-        } else {  // the block starts at an odd row: rows B + k + 1, B + k + 2 pair up
-          const uint64_t o = B + k + 1;
-          if (k + 2 < dout) {
-            ll2 w;
-            w.x = e1v;
-            w.y = o1v;
-            __builtin_nontemporal_store(w, reinterpret_cast<ll2 *>(c2 + o));
-            __builtin_nontemporal_store(uu, reinterpret_cast<ll2 *>(c0 + o));
-          } else if (k + 1 < dout) {  // last row, alone
-            c2[o] = e1v;
-            c0[o] = uid;
-          }
-          if (jb == 0 && lane == 0) {  // first row of the block, alone (later J-blocks: the pair before covers it)
-            c2[B] = e0v;
-            c0[B] = uid;
-          }
-        }
+    for (uint32_t jc = 0; jc < dout; jc += MAT_CAP) {
+      const uint32_t clen = dout - jc < MAT_CAP ? dout - jc : MAT_CAP;
+      __syncthreads();  // the readers of the chunk before are done
+      for (uint32_t j = threadIdx.x; j < clen; j += 256) s_oid[j] = vid[nbr[st + jc + j]];
+      __syncthreads();
+      if (dout <= MAT_CAP) {  // the whole piece in one go (256 entries x 2048 leaves x 8 bytes < 2^32 / dout rows)
+        mat_write_rows(s_base[i0], (i1 - i0) * dout, dout, i0, xid, s_uid, s_oid, c0, c1, c2);
+      } else {
+        for (uint32_t i = i0; i < i1; i++)
+          mat_write_rows(s_base[i] + jc, clen, clen, i, xid, s_uid, s_oid, c0, c1, c2);
       }
     }
   }

@@ -182,19 +182,25 @@ def test_two_hop_rows_by_middle_vertex_ranges_partition_the_materialised_result(
     """The product form of the materialising expansion (k_mat_mid2: rows grouped by middle vertex, the ids of out(x)
     gathered once per run): the whole result equals the join formulation's rows as a sorted multiset; middle-vertex
     ranges partition it (rows and digests add up, the 1-hop tables are the edges into each range); odd and even row
-    blocks, out-rows longer than one 128-leaf block, vertices without out- or in-edges."""
+    blocks, out-rows on both sides of the flat form's 1024 leaves, vertices without out- or in-edges."""
     rng = np.random.default_rng(5)
-    V, E = 700, 9000
+    V, E = 700, 16000
     vid = np.arange(V, dtype=np.int64) * 7 + 11
     s, d = rng.integers(0, V - 50, E), rng.integers(0, V - 50, E)  # the last 50 vertices stay isolated
-    s[:600] = 3   # a hub with an out-row of ~600 leaves (five 128-leaf blocks)
+    s[:600] = 3   # a hub with an out-row of ~600 leaves
     d[600:1100] = 5  # and one with ~500 in-edges
-    for vtx, deg, at in ((40, 127, 1200), (41, 128, 1400), (42, 129, 1600), (43, 1, 1800), (44, 2, 1810)):
-        s[at:at + deg] = vtx  # out-rows right at the boundary between the two store forms (one lane pair .. 128 leaves)
-    keep = ~np.isin(s, (40, 41, 42, 43, 44))
-    keep[1200:1327] = keep[1400:1528] = keep[1600:1729] = keep[1800:1801] = keep[1810:1812] = True
+    # out-rows right at the boundaries of the store forms: one row, one lane pair, a 128-leaf block of the long form,
+    # the longest row the flat form takes (1024 leaves, staged in LDS) and the first ones of the long form
+    special = ((40, 127, 1200), (41, 128, 1400), (42, 129, 1600), (43, 1, 1800), (44, 2, 1810), (45, 1023, 2000),
+               (46, 1024, 3100), (47, 1025, 4200), (48, 2500, 5300))
+    keep = ~np.isin(s, [v for v, _, _ in special])
+    for vtx, deg, at in special:
+        s[at:at + deg] = vtx
+        keep[at:at + deg] = True
     s, d = s[keep], d[keep]
-    d[:5] = (40, 41, 42, 43, 44)  # every one of them has an in-edge, so their products are not empty
+    d[:9] = [v for v, _, _ in special]  # every one of them has an in-edge, so their products are not empty
+    d[9:13] = (47, 47, 48, 48)  # (several entries per run for the long form, an odd and an even number)
+    d[13] = 48
     src, dst = vid[s], vid[d]
     csr, g = build_both(gg, orc, vid, src, dst)
     ref = orc.khop_join(vid, src, dst, 1, 2)
