@@ -1220,16 +1220,18 @@ int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
 // SF10, more time than the stores).  Here the ids of out(x) are gathered once per run of equal x (E gathers in all)
 // into LDS, and the rest is stores.  Row order of a materialised result is unspecified (gg.h), so grouping the rows
 // by middle vertex is the caller's right.
-// A tile is 256 consecutive reverse entries.  The rows of a run's entries i0 .. i1 - 1 are (i1 - i0) blocks of dout
-// rows back to back, the same rows in all three columns: row r of that piece belongs to entry r / dout and leaf
-// r % dout (multiply-high by a per-run reciprocal).  The workgroup walks the piece flat from the 128-byte line its
-// first row lies in, two rows (16 bytes) per lane, so EVERY store instruction covers eight whole lines whatever dout
-// and the block boundaries are; only the first and last line of a piece are written in part.  That matters more than
-// anything else in this kernel: scripts/ubench_fill.hip (profiles/r03_ubench_fill.txt) writes the same three arrays
-// at 6.1 TB/s with line-aligned nontemporal 16-byte stores and at 4.45 TB/s when every instruction starts 16 bytes
-// past a line (its end lines shared with the neighbours); the earlier form — one store per entry and 128 leaves,
-// starting wherever the entry's block starts — ran at 4.8.  Out-rows longer than MAT_CAP leaves go through LDS in
-// chunks, one entry's segment of a chunk at a time (>= 16 KB per column: the part-written lines no longer count).
+// The rows of a run's entries i0 .. i1 - 1 are (i1 - i0) blocks of dout rows back to back, the same rows in all three
+// columns: row r of that piece belongs to entry r / dout and leaf r % dout (multiply-high by a per-run reciprocal).
+// The workgroup walks the piece flat from the 128-byte line its first row lies in, two rows (16 bytes) per lane, so
+// EVERY store instruction covers eight whole lines whatever dout and the block boundaries are; only the first and
+// last line of a piece are written in part.  That matters more than anything else in this kernel:
+// scripts/ubench_fill.hip (profiles/r03_ubench_fill.txt) writes the same three arrays at 6.1 TB/s with line-aligned
+// nontemporal 16-byte stores and at 4.45 TB/s when every instruction starts 16 bytes past a line (its end lines
+// shared with the neighbours); the earlier form — one store per entry and 128 leaves, starting wherever the entry's
+// block starts — ran at 4.8.  Out-rows longer than MAT_CAP leaves go through LDS in chunks, one entry's segment of a
+// chunk at a time (>= 16 KB per column: the part-written lines no longer count).
+// A workgroup owns MAT_ROWS consecutive OUTPUT rows, not a fixed number of entries (k_mat_tile_entries finds the entry
+// each tile starts in): tiles of equal bytes, no heavy tile left over at the end of a launch.
 #ifndef GG_MAT_CAP
 #define GG_MAT_CAP 2048
 #endif
@@ -1250,25 +1252,61 @@ __global__ __launch_bounds__(256) void k_mat_mid2_prepare(const uint32_t *__rest
 
 typedef long long mat_ll2 __attribute__((ext_vector_type(2)));
 
-// rows [S, S + n) of the three columns: row r = (entry ib + r / d, middle id, leaf r % d); d >= 1, n < 2^32 / d.
-// The whole workgroup; uid / oid are the tile's entry ids and the staged leaf ids in LDS.
-__device__ __forceinline__ void mat_write_rows(uint64_t S, uint32_t n, uint32_t d, uint32_t ib, long long xid,
-                                               const int64_t *uid, const int64_t *oid, int64_t *__restrict__ c0,
-                                               int64_t *__restrict__ c1, int64_t *__restrict__ c2) {
-  const uint64_t A0 = S & ~(uint64_t)(MAT_ALIGN - 1);  // first row of the 128-byte line S lies in (the columns are 256-byte aligned)
-  const uint32_t head = (uint32_t)(S - A0), total = head + n;
+#ifndef GG_MAT_ROWS
+#define GG_MAT_ROWS 32768
+#endif
+constexpr uint64_t MAT_ROWS = GG_MAT_ROWS;  // output rows per workgroup of k_mat_mid2 (x 24 bytes)
+
+// first output row of tile t (tiles start on 128-byte lines: MAT_ROWS is a multiple of 16 rows)
+__device__ __forceinline__ uint64_t mat_tile_start(uint64_t t, uint64_t n_tiles, uint64_t M2) {
+  const uint64_t b = t * MAT_ROWS;
+  return t < n_tiles && b < M2 ? b : M2;
+}
+static_assert(MAT_ROWS % 16 == 0, "tiles of k_mat_mid2 start on 128-byte lines");
+
+// tile t of k_mat_mid2 starts in the entry that holds its first output row: upper_bound(foff, start) - 1
+__global__ __launch_bounds__(256) void k_mat_tile_entries(const uint64_t *__restrict__ foff, uint64_t n_entries,
+                                                          uint64_t n_tiles, uint64_t M2,
+                                                          uint32_t *__restrict__ tile_entry) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_tiles) return;
+  const uint64_t target = mat_tile_start(t, n_tiles, M2);
+  if (target >= M2) {  // (an empty tile, or the end)
+    tile_entry[t] = (uint32_t)n_entries;
+    return;
+  }
+  uint64_t lo = 0, hi = n_entries;  // first idx in [0, n_entries] with foff[idx] > target
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (foff[mid] <= target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  tile_entry[t] = (uint32_t)(lo - 1);
+}
+
+// rows S + r, r in [r_lo, r_hi), of the three columns: row r = (entry ib + r / d, middle id, leaf r % d); d >= 1,
+// r_hi <= 2^32 / d.  The whole workgroup; uid / oid are the batch's entry ids and the staged leaf ids in LDS.
+__device__ __forceinline__ void mat_write_rows(uint64_t S, uint32_t r_lo, uint32_t r_hi, uint32_t d, uint32_t ib,
+                                               long long xid, const int64_t *uid, const int64_t *oid,
+                                               int64_t *__restrict__ c0, int64_t *__restrict__ c1,
+                                               int64_t *__restrict__ c2) {
+  // first row of the 128-byte line the first row lies in (the columns are 256-byte aligned)
+  const uint64_t A0 = (S + r_lo) & ~(uint64_t)(MAT_ALIGN - 1);
+  const uint32_t head = (uint32_t)(S + r_lo - A0), total = head + (r_hi - r_lo);
   const uint32_t m = d >= 2 ? 0xFFFFFFFFu / d + 1u : 0u;  // r / d = umulhi(r, m) for r < 2^32 / d
   mat_ll2 xx;
   xx.x = xx.y = xid;
   for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
-    const uint32_t hi = 2 * q + 1;  // rows 2q - head (low half) and hi - head (high half) of the piece
-    if (hi < head) continue;        // the pair lies before the piece
-    const uint32_t rh = hi - head;
-    const bool lo_ok = rh >= 1, hi_ok = rh < n;
+    const uint32_t hi = 2 * q + 1;  // the lane's pair: rows A0 + 2q (low half) and A0 + hi (high half)
+    if (hi < head) continue;        // both before the first row
+    const uint32_t rh = r_lo + (hi - head);
+    const bool lo_ok = hi > head, hi_ok = rh < r_hi;
     const uint32_t ih = d >= 2 ? __umulhi(rh, m) : rh, jh = rh - ih * d;
     const uint32_t il = jh ? ih : ih - 1u, jl = jh ? jh - 1u : d - 1u;
     mat_ll2 uu, w;
-    uu.y = uid[ib + ih];  // (rh == n reads one element past the piece: the arrays are padded, the value is not stored)
+    uu.y = uid[ib + ih];  // (rh == r_hi may read one element past the piece: the arrays are padded, nothing is stored)
     w.y = oid[jh];
     uu.x = lo_ok ? uid[ib + il] : 0;
     w.x = lo_ok ? oid[jl] : 0;
@@ -1277,7 +1315,7 @@ __device__ __forceinline__ void mat_write_rows(uint64_t S, uint32_t n, uint32_t 
       __builtin_nontemporal_store(uu, reinterpret_cast<mat_ll2 *>(c0 + o));
       __builtin_nontemporal_store(xx, reinterpret_cast<mat_ll2 *>(c1 + o));
       __builtin_nontemporal_store(w, reinterpret_cast<mat_ll2 *>(c2 + o));
-    } else if (lo_ok) {  // last row of the piece, alone
+    } else if (lo_ok) {  // last row, alone
       c0[o] = uu.x;
       c1[o] = xid;
       c2[o] = w.x;
@@ -1289,56 +1327,71 @@ __device__ __forceinline__ void mat_write_rows(uint64_t S, uint32_t n, uint32_t 
   }
 }
 
+// One workgroup per MAT_ROWS consecutive OUTPUT rows (tiles of equal bytes: a tile of 256 reverse entries is anything
+// between nothing and 256 x the largest out-degree rows, and the few heaviest were the kernel's tail); the entries
+// that overlap the tile are taken 256 at a time, their pieces clipped to the tile.
 __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
                                                   const uint32_t *__restrict__ rrow, const uint32_t *__restrict__ rnbr,
                                                   const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
-                                                  uint64_t e0, uint64_t n, int64_t *__restrict__ c0,
-                                                  int64_t *__restrict__ c1, int64_t *__restrict__ c2) {
+                                                  const uint32_t *__restrict__ tile_entry, uint64_t e0, uint64_t n,
+                                                  uint64_t M2, int64_t *__restrict__ c0, int64_t *__restrict__ c1,
+                                                  int64_t *__restrict__ c2) {
   __shared__ int64_t s_uid[256 + 1];
   __shared__ int64_t s_oid[MAT_CAP + 1];
   __shared__ uint64_t s_base[256];
   __shared__ uint32_t s_x[256], s_run[257], s_wcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = p < n;
-  uint32_t x = INVALID_U32;
-  if (valid) {
-    x = rrow[e0 + p];
-    s_uid[threadIdx.x] = vid[rnbr[e0 + p]];
-    s_base[threadIdx.x] = foff[p];
-  }
-  s_x[threadIdx.x] = x;
-  __syncthreads();
-  const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
-  const uint64_t hm = __ballot(head);
-  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
-  __syncthreads();
-  uint32_t before = 0, nruns = 0;
-  for (int q = 0; q < 4; q++) {
-    if (q < wave) before += s_wcnt[q];
-    nruns += s_wcnt[q];
-  }
-  if (head) s_run[before + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
-  if (threadIdx.x == 0) {
-    const uint64_t left = n - (uint64_t)blockIdx.x * 256;
-    s_run[nruns] = left < 256 ? (uint32_t)left : 256u;
-  }
-  __syncthreads();
-  for (uint32_t r = 0; r < nruns; r++) {  // (everything below is uniform over the workgroup)
-    const uint32_t i0 = s_run[r], i1 = s_run[r + 1];
-    const uint32_t xr = s_x[i0], st = off[xr], dout = off[xr + 1] - st;
-    if (dout == 0) continue;
-    const long long xid = vid[xr];
-    for (uint32_t jc = 0; jc < dout; jc += MAT_CAP) {
-      const uint32_t clen = dout - jc < MAT_CAP ? dout - jc : MAT_CAP;
-      __syncthreads();  // the readers of the chunk before are done
-      for (uint32_t j = threadIdx.x; j < clen; j += 256) s_oid[j] = vid[nbr[st + jc + j]];
-      __syncthreads();
-      if (dout <= MAT_CAP) {  // the whole piece in one go (256 entries x 2048 leaves x 8 bytes < 2^32 / dout rows)
-        mat_write_rows(s_base[i0], (i1 - i0) * dout, dout, i0, xid, s_uid, s_oid, c0, c1, c2);
-      } else {
-        for (uint32_t i = i0; i < i1; i++)
-          mat_write_rows(s_base[i] + jc, clen, clen, i, xid, s_uid, s_oid, c0, c1, c2);
+  const uint64_t t_lo = mat_tile_start(blockIdx.x, gridDim.x, M2), t_hi = mat_tile_start(blockIdx.x + 1ull, gridDim.x, M2);
+  const uint64_t e_lo = tile_entry[blockIdx.x];
+  uint64_t e_hi = (uint64_t)tile_entry[blockIdx.x + 1] + 1;  // (that entry holds the next tile's first row, and maybe ours)
+  e_hi = e_hi < n ? e_hi : n;
+  for (uint64_t eb = e_lo; eb < e_hi; eb += 256) {  // (everything about the control flow is uniform over the workgroup)
+    const uint64_t p = eb + threadIdx.x;
+    const bool valid = p < e_hi;
+    uint32_t x = INVALID_U32;
+    __syncthreads();  // the batch before is done with the arrays
+    if (valid) {
+      x = rrow[e0 + p];
+      s_uid[threadIdx.x] = vid[rnbr[e0 + p]];
+      s_base[threadIdx.x] = foff[p];
+    }
+    s_x[threadIdx.x] = x;
+    __syncthreads();
+    const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
+    const uint64_t hm = __ballot(head);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
+    __syncthreads();
+    uint32_t before = 0, nruns = 0;
+    for (int q = 0; q < 4; q++) {
+      if (q < wave) before += s_wcnt[q];
+      nruns += s_wcnt[q];
+    }
+    if (head) s_run[before + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
+    if (threadIdx.x == 0) s_run[nruns] = e_hi - eb < 256 ? (uint32_t)(e_hi - eb) : 256u;
+    __syncthreads();
+    for (uint32_t r = 0; r < nruns; r++) {
+      const uint32_t i0 = s_run[r], i1 = s_run[r + 1];
+      const uint32_t xr = s_x[i0], st = off[xr], dout = off[xr + 1] - st;
+      if (dout == 0) continue;
+      // the piece: (i1 - i0) blocks of dout rows from Bs on; [lo, hi) is its part inside the tile
+      const uint64_t Bs = s_base[i0], Be = Bs + (uint64_t)(i1 - i0) * dout;
+      const uint64_t lo = Bs > t_lo ? Bs : t_lo, hi = Be < t_hi ? Be : t_hi;
+      if (lo >= hi) continue;
+      const long long xid = vid[xr];
+      for (uint32_t jc = 0; jc < dout; jc += MAT_CAP) {
+        const uint32_t clen = dout - jc < MAT_CAP ? dout - jc : MAT_CAP;
+        __syncthreads();  // the readers of the chunk before are done
+        for (uint32_t j = threadIdx.x; j < clen; j += 256) s_oid[j] = vid[nbr[st + jc + j]];
+        __syncthreads();
+        if (dout <= MAT_CAP) {  // the whole piece in one go (256 entries x MAT_CAP leaves <= 2^32 / dout rows)
+          mat_write_rows(Bs, (uint32_t)(lo - Bs), (uint32_t)(hi - Bs), dout, i0, xid, s_uid, s_oid, c0, c1, c2);
+        } else {  // long out-rows: the chunk's segment of one entry at a time
+          for (uint32_t i = i0; i < i1; i++) {
+            const uint64_t S = s_base[i] + jc, slo = S > t_lo ? S : t_lo, shi = S + clen < t_hi ? S + clen : t_hi;
+            if (slo < shi)
+              mat_write_rows(S, (uint32_t)(slo - S), (uint32_t)(shi - S), clen, i, xid, s_uid, s_oid, c0, c1, c2);
+          }
+        }
       }
     }
   }
@@ -1372,9 +1425,17 @@ int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mi
     GG_TRY(ctx->dev_alloc((void **)&res->cols[2][c], (M2 ? M2 : 1) * sizeof(int64_t)));
     ctx->keep(res->cols[2][c]);
   }
-  if (M2)
-    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
-              csr->rnbr, csr->vid, (const uint64_t *)foff, e0, n, res->cols[2][0], res->cols[2][1], res->cols[2][2]);
+  if (M2) {
+    const uint64_t n_tiles = (M2 + MAT_ROWS - 1) / MAT_ROWS;
+    uint32_t *tile_entry = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&tile_entry, (n_tiles + 1) * sizeof(uint32_t)));
+    GG_LAUNCH(ctx, "mat_tile_entries", k_mat_tile_entries, dim3((unsigned)((n_tiles + 256) / 256)), dim3(256), 0,
+              (const uint64_t *)foff, n, n_tiles, M2, tile_entry);
+    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)n_tiles), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
+              csr->rnbr, csr->vid, (const uint64_t *)foff, (const uint32_t *)tile_entry, e0, n, M2, res->cols[2][0],
+              res->cols[2][1], res->cols[2][2]);
+    ctx->dev_free(tile_entry);
+  }
   if (k_min <= 1) {
     res->rows[1] = n;
     for (int c = 0; c <= 1; c++) {
