@@ -831,43 +831,40 @@ __global__ __launch_bounds__(XT) void k_mat_last(const uint32_t *__restrict__ of
     if (n == 0) continue;
     const uint32_t *__restrict__ row = nbr + s_start[r];
     const uint64_t base = s_base[r];
-    // Stores are 16 bytes per lane (two consecutive rows of a column): half the store instructions of
-    // 8-byte stores.  Rows before the first 16-byte-aligned output slot and a possible odd last row are
-    // written singly by lane 0.  All loads and id gathers of a trip come first, then its (non-temporal)
-    // stores: the output is written once, never re-read here, and stores must not serialise the loads.
+    // Stores are 16 bytes per lane (two consecutive rows of a column), and lane 0 of every store instruction sits on
+    // a 128-byte line: the pairs are counted from the line the parent's first row lies in, so an instruction covers
+    // eight whole lines except at the two ends of the parent's block (nontemporal stores that start anywhere ran at
+    // 4.45 instead of 6.1 TB/s: scripts/ubench_fill.hip).  The first and the last pair may hold one row only.  All
+    // loads and id gathers of a trip come first, then its stores: the output is written once, never re-read here,
+    // and stores must not serialise the loads.
     typedef long long ll2 __attribute__((ext_vector_type(2)));
-    const uint32_t head = (uint32_t)(base & 1);
-    if (lane == 0) {
-      if (head) {
-        out.c[j + 1][base] = vid[row[0]];
-        for (int c = 0; c <= j; c++) out.c[c][base] = s_id[c][r];
-      }
-      if (((n - head) & 1) && n > head) {
-        out.c[j + 1][base + n - 1] = vid[row[n - 1]];
-        for (int c = 0; c <= j; c++) out.c[c][base + n - 1] = s_id[c][r];
-      }
-    }
-    const uint32_t npairs = (n - head) >> 1;
-    for (uint32_t p0 = 0; p0 < npairs; p0 += 128) {
+    const uint64_t a0 = base & ~15ULL;
+    const uint32_t head = (uint32_t)(base - a0), total = head + n;  // row k of the parent is slot head + k behind a0
+    for (uint32_t p0 = 0; 2 * p0 < total; p0 += 128) {
       ll2 idv[2];
-      bool okv[2];
+      bool lov[2], hiv[2];
 #pragma unroll
       for (int q = 0; q < 2; q++) {
-        const uint32_t pi = p0 + q * 64 + lane;
-        okv[q] = pi < npairs;
-        const uint32_t k = head + 2 * pi;
-        idv[q].x = okv[q] ? vid[row[k]] : 0;
-        idv[q].y = okv[q] ? vid[row[k + 1]] : 0;
+        const uint32_t s0 = 2 * (p0 + q * 64 + lane);
+        lov[q] = s0 >= head && s0 < total;
+        hiv[q] = s0 + 1 >= head && s0 + 1 < total;
+        idv[q].x = lov[q] ? vid[row[s0 - head]] : 0;
+        idv[q].y = hiv[q] ? vid[row[s0 + 1 - head]] : 0;
       }
 #pragma unroll
       for (int q = 0; q < 2; q++) {
-        if (!okv[q]) continue;
-        const uint64_t o = base + head + 2 * (uint64_t)(p0 + q * 64 + lane);  // even: 16-byte aligned
-        __builtin_nontemporal_store(idv[q], reinterpret_cast<ll2 *>(&out.c[j + 1][o]));
-        for (int c = 0; c <= j; c++) {
-          ll2 two;
-          two.x = two.y = s_id[c][r];
-          __builtin_nontemporal_store(two, reinterpret_cast<ll2 *>(&out.c[c][o]));
+        const uint64_t o = a0 + 2 * (uint64_t)(p0 + q * 64 + lane);  // even: 16-byte aligned
+        if (lov[q] && hiv[q]) {
+          __builtin_nontemporal_store(idv[q], reinterpret_cast<ll2 *>(&out.c[j + 1][o]));
+          for (int c = 0; c <= j; c++) {
+            ll2 two;
+            two.x = two.y = s_id[c][r];
+            __builtin_nontemporal_store(two, reinterpret_cast<ll2 *>(&out.c[c][o]));
+          }
+        } else if (lov[q] || hiv[q]) {  // an end of the block: one row
+          const uint64_t o1 = lov[q] ? o : o + 1;
+          out.c[j + 1][o1] = lov[q] ? idv[q].x : idv[q].y;
+          for (int c = 0; c <= j; c++) out.c[c][o1] = s_id[c][r];
         }
       }
     }

@@ -19,6 +19,8 @@ g = pkg.GG(0)
 g.append_vertices(vid)
 g.append_edges(src, dst)
 csr = g.build_csr()
+if len(sys.argv) > 3 and sys.argv[3] == "frontier":  # the per-parent form (k_mat_last) instead of the product form
+    g.force_frontier(True)
 for rep in range(3):
     g.profile_reset()
     g.profile(True)
