@@ -1521,9 +1521,10 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
   uint32_t *dir = nullptr;
   unsigned long long *tab = nullptr;
   const uint32_t idx_bits = (uint32_t)bits_of(V - 1);
-  uint32_t q = 9;  // slot pairs = 2^q: the smallest power of two with a load factor <= GG_FB_LOAD_PCT
-  while ((2ull << q) * GG_FB_LOAD_PCT < V * 100) q++;
-  const uint64_t npairs = 1ull << q;
+  // slot pairs of the packed dictionary: the fewest with a load factor <= GG_FB_LOAD_PCT (not a power of two: the
+  // probe rate follows the table's size, gg_dict.h), a multiple of 64, at least 512
+  uint64_t npairs = ((V * 100 + 2 * GG_FB_LOAD_PCT - 1) / (2 * GG_FB_LOAD_PCT) + 63) / 64 * 64;
+  if (npairs < 512) npairs = 512;
   dm = reinterpret_cast<DirectMap *>(reinterpret_cast<unsigned long long *>(st) + 8);  // seeded with st (csr_build_impl)
   GG_TRY(ctx->dev_alloc((void **)&dir, DIRECT_MAX_RANGE * sizeof(uint32_t)));
   GG_TRY(ctx->dev_alloc((void **)&tab, 2 * npairs * sizeof(unsigned long long)));
@@ -1544,7 +1545,7 @@ int csr_build_fast(gg_ctx *ctx, gg_csr *csr, BuildStatus *st, int *taken) {
               csr->ht_cap, tab, 2 * npairs, dir, dm, st, (uint32_t)csr->part, (uint32_t)csr->n_parts, csr->vid, coltot,
               ncol);
     GG_LAUNCH(ctx, "dict_insert", k_dict_insert, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, csr->vid, V, csr->ht,
-              csr->ht_cap, tab, dir, dm, idx_bits, q, st);
+              csr->ht_cap, tab, dir, dm, idx_bits, (uint32_t)npairs, st);
     GG_LAUNCH(ctx, "dict_wide", k_dict_wide, dim3((unsigned)((V + 255) / 256 < 512 ? (V + 255) / 256 : 512)), dim3(256), 0,
               csr->vid, V, csr->ht,
               csr->ht_cap, (const DirectMap *)dm, st);

@@ -47,8 +47,8 @@ static __global__ __launch_bounds__(256) void k_id_minmax(const int64_t *__restr
   }
 }
 
-// idx_bits = bits of V - 1; q = log2(slot pairs) of the packed table (0: the caller has no packed table)
-static __global__ void k_dict_decide(DirectMap *__restrict__ dm, uint64_t V, uint32_t idx_bits, uint32_t q) {
+// idx_bits = bits of V - 1; pairs = 16-byte slot pairs of the packed table (0: the caller has no packed table)
+static __global__ void k_dict_decide(DirectMap *__restrict__ dm, uint64_t V, uint32_t idx_bits, uint32_t pairs) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const uint64_t span = (uint64_t)dm->max_id - (uint64_t)dm->min_id;  // exact in unsigned arithmetic
     const bool any = V > 0 && dm->max_id >= dm->min_id;
@@ -56,13 +56,14 @@ static __global__ void k_dict_decide(DirectMap *__restrict__ dm, uint64_t V, uin
     unsigned long long mode = DICT_WIDE16;
     if (any && span < DIRECT_MAX_RANGE)
       mode = DICT_DIRECT;
-    else if (any && q && span_bits >= q && span_bits <= 57u && span_bits - q + 6u /* PK_DISP_BITS */ + idx_bits <= 63u)
+    else if (any && pairs > 12u /* PK_MAX_DISP */ && span_bits > 31u - (uint32_t)__clz((int)pairs) && span_bits <= 57u &&
+             span_bits - (31u - (uint32_t)__clz((int)pairs)) + 6u /* PK_DISP_BITS */ + idx_bits <= 63u)
       mode = DICT_PACKED8;
     dm->mode = mode;
     dm->enabled = mode == DICT_DIRECT ? 1ULL : 0ULL;
     dm->idx_bits = idx_bits;
     dm->span_bits = span_bits;
-    dm->q = q;
+    dm->pairs = pairs;
   }
 }
 
@@ -89,10 +90,15 @@ __device__ __forceinline__ uint32_t direct_lookup(const uint32_t *__restrict__ d
 // ---- packed 8-byte slots --------------------------------------------------------------------------------
 // Exact with 8 bytes per vertex for ids spanning up to ~2^54: quotienting.  rel = id - min has S = span_bits
 // significant bits; pk_mix is a BIJECTION on S-bit values (odd multiplications mod 2^S and xor-shifts), so
-// h = pk_mix(rel) identifies the id.  The table has 2^q slot pairs (one aligned 16-byte granule each: a probe
-// loads both slots with one dwordx4); the home pair is the top q bits of h and only the remaining S - q bits
-// (rem) are stored, next to the pair displacement from home (PK_DISP_BITS, linear probing over pairs) and the
-// dense index:   slot = ((rem << PK_DISP_BITS | disp) << idx_bits) | idx,   bit 63 clear, empty = all ones.
+// h = pk_mix(rel) identifies the id.  The table has G slot pairs (one aligned 16-byte granule each: a probe
+// loads both slots with one dwordx4), G ANY number — the probe rate of the edge densification falls steadily
+// with the table's size between one XCD's L2 (4 MB) and twice that (scripts/ubench_gather_sizes.hip: 546 us
+// at 4 MB, 591 at 5.33, 650 at 6.4, 785 at 8), so the table is as small as the load factor allows, not the
+// next power of two.  The home pair is floor(h G / 2^S), taken from the top 32 bits t of h as umulhi(t, G);
+// the h that share a home differ in fewer than 2^(S - qf) places, qf = floor(log2 G), so the low S - qf bits
+// of h (rem) tell them apart and only those are stored, next to the pair displacement from home
+// (PK_DISP_BITS, linear probing over pairs) and the dense index:
+//   slot = ((rem << PK_DISP_BITS | disp) << idx_bits) | idx,   bit 63 clear, empty = all ones.
 // A lookup scans pairs from home and stops at the first empty slot.  If some key would be displaced further
 // than the field allows, the insert kernel flips the mode back to DICT_WIDE16 (nothing has read it yet).
 constexpr unsigned long long PK_EMPTY = ~0ULL;
@@ -126,59 +132,36 @@ __device__ __forceinline__ uint64_t pk_mix(uint64_t rel, uint32_t S) {  // 21 <=
 
 struct PkGeom {  // uniform values of a packed table, read once per kernel
   uint64_t min_id, max_id;
-  uint32_t S, q, b;
-  __device__ __forceinline__ void load(const DirectMap *dm) {
-    min_id = (uint64_t)dm->min_id;
-    max_id = (uint64_t)dm->max_id;
-    S = (uint32_t)dm->span_bits;
-    q = (uint32_t)dm->q;
-    b = (uint32_t)dm->idx_bits;
+  uint32_t S, G, qf, b;
+  __device__ __forceinline__ void set(uint64_t min_id_, uint64_t max_id_, uint32_t S_, uint32_t G_, uint32_t b_) {
+    min_id = min_id_;
+    max_id = max_id_;
+    S = S_;
+    G = G_;
+    qf = G_ ? 31u - (uint32_t)__clz((int)G_) : 0u;
+    b = b_;
   }
-  // home pair and the tag of displacement 0 for a key inside [min, max]
+  __device__ __forceinline__ void load(const DirectMap *dm) {
+    set((uint64_t)dm->min_id, (uint64_t)dm->max_id, (uint32_t)dm->span_bits, (uint32_t)dm->pairs, (uint32_t)dm->idx_bits);
+  }
+  // home pair and the tag of displacement 0 for a key inside [min, max] (any other key: some pair of the table)
   __device__ __forceinline__ void locate(int64_t key, uint64_t *home, uint64_t *tag0) const {
     const uint64_t h = pk_mix((uint64_t)key - min_id, S);
-    *home = h >> (S - q);
-    *tag0 = (h & ((1ULL << (S - q)) - 1ULL)) << PK_DISP_BITS;
+    const uint32_t t = S >= 32u ? (uint32_t)(h >> (S - 32u)) : (uint32_t)(h << (32u - S));
+    *home = __umulhi(t, G);
+    *tag0 = (h & ((1ULL << (S - qf)) - 1ULL)) << PK_DISP_BITS;
+  }
+  __device__ __forceinline__ uint64_t pair_at(uint64_t home, uint64_t disp) const {  // (disp <= PK_MAX_DISP < G)
+    const uint64_t g = home + disp;
+    return g >= G ? g - G : g;
   }
 };
-
-static __global__ __launch_bounds__(256) void k_packed_init(unsigned long long *__restrict__ tab,
-                                                            const DirectMap *__restrict__ dm) {
-  if (dm->mode != DICT_PACKED8) return;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (2ULL << dm->q)) tab[i] = PK_EMPTY;
-}
-
-static __global__ __launch_bounds__(256) void k_packed_insert(const int64_t *__restrict__ vid, uint64_t V,
-                                                              unsigned long long *__restrict__ tab,
-                                                              DirectMap *__restrict__ dm) {
-  if (*(volatile unsigned long long *)&dm->mode != DICT_PACKED8) return;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V) return;
-  PkGeom pk;
-  pk.load(dm);
-  uint64_t home, tag0;
-  pk.locate(vid[i], &home, &tag0);
-  const uint64_t pmask = (1ULL << pk.q) - 1ULL;
-  for (uint64_t disp = 0; disp <= PK_MAX_DISP; disp++) {
-    const uint64_t g = (home + disp) & pmask;
-    const unsigned long long entry = ((tag0 | disp) << pk.b) | i;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      const unsigned long long prev = atomicCAS(&tab[2 * g + s], PK_EMPTY, entry);
-      if (prev == PK_EMPTY) return;
-      if ((prev >> pk.b) == (tag0 | disp)) return;  // duplicate vertex id: k_ht_insert reports it, the build fails
-    }
-  }
-  dm->mode = DICT_WIDE16;  // displaced too far: the edge densification uses the 16-byte table instead
-}
 
 // finish a packed lookup whose first probe (pair `home`, raw) is already loaded
 __device__ __forceinline__ uint32_t packed_resolve(const unsigned long long *__restrict__ tab, const PkGeom &pk,
                                                    bool in_range, uint64_t home, uint64_t tag0, uint4 raw) {
   if (!in_range) return INVALID_U32;
   const unsigned long long idx_mask = (1ULL << pk.b) - 1ULL;
-  const uint64_t pmask = (1ULL << pk.q) - 1ULL;
   for (uint64_t disp = 0;;) {
     const unsigned long long e0 = ((unsigned long long)raw.y << 32) | raw.x;
     const unsigned long long e1 = ((unsigned long long)raw.w << 32) | raw.z;
@@ -187,7 +170,7 @@ __device__ __forceinline__ uint32_t packed_resolve(const unsigned long long *__r
     if ((e1 >> pk.b) == (tag0 | disp)) return (uint32_t)(e1 & idx_mask);
     if (e1 == PK_EMPTY) return INVALID_U32;
     if (++disp > PK_MAX_DISP) return INVALID_U32;
-    raw = *reinterpret_cast<const uint4 *>(&tab[2 * ((home + disp) & pmask)]);
+    raw = *reinterpret_cast<const uint4 *>(&tab[2 * pk.pair_at(home, disp)]);
   }
 }
 
@@ -196,14 +179,20 @@ __device__ __forceinline__ uint32_t packed_resolve(const unsigned long long *__r
 // k_dict_insert  every thread derives the mode from min / max (thread 0 publishes it), inserts its vertex into the
 //                table of that mode, reports duplicate ids
 // k_dict_wide    only if a packed insert had to give up (mode flipped to DICT_WIDE16): fills the 16-byte table
+__device__ __forceinline__ bool packed_fits(uint32_t span_bits, uint32_t pairs, uint32_t idx_bits) {
+  if (pairs <= PK_MAX_DISP) return false;  // (also: no packed table)
+  const uint32_t qf = 31u - (uint32_t)__clz((int)pairs);
+  return span_bits > qf && span_bits <= 57u && span_bits - qf + PK_DISP_BITS + idx_bits <= 63u;
+}
+
 __device__ __forceinline__ unsigned long long dict_mode_of(long long min_id, long long max_id, uint64_t V,
-                                                           uint32_t idx_bits, uint32_t q, uint32_t *span_bits_out) {
+                                                           uint32_t idx_bits, uint32_t pairs, uint32_t *span_bits_out) {
   const uint64_t span = (uint64_t)max_id - (uint64_t)min_id;
   const bool any = V > 0 && max_id >= min_id;
   const uint32_t span_bits = span ? 64u - (uint32_t)__clzll((long long)span) : 0u;
   *span_bits_out = span_bits;
   if (any && span < DIRECT_MAX_RANGE) return DICT_DIRECT;
-  if (any && q && span_bits >= q && span_bits <= 57u && span_bits - q + PK_DISP_BITS + idx_bits <= 63u) return DICT_PACKED8;
+  if (any && packed_fits(span_bits, pairs, idx_bits)) return DICT_PACKED8;
   return DICT_WIDE16;
 }
 
@@ -298,17 +287,18 @@ static __global__ __launch_bounds__(256) void k_dict_insert(const int64_t *__res
                                                             HtSlot *__restrict__ ht, uint64_t cap,
                                                             unsigned long long *__restrict__ tab,
                                                             uint32_t *__restrict__ dir, DirectMap *__restrict__ dm,
-                                                            uint32_t idx_bits, uint32_t q, BuildStatus *__restrict__ st) {
+                                                            uint32_t idx_bits, uint32_t pairs,
+                                                            BuildStatus *__restrict__ st) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const long long min_id = dm->min_id, max_id = dm->max_id;  // complete: k_dict_init has finished
   uint32_t span_bits;
-  const unsigned long long mode = dict_mode_of(min_id, max_id, V, idx_bits, q, &span_bits);
+  const unsigned long long mode = dict_mode_of(min_id, max_id, V, idx_bits, pairs, &span_bits);
   if (i == 0) {  // for the kernels after this one (nobody in this launch reads these fields)
     dm->decided = mode;
     dm->enabled = mode == DICT_DIRECT ? 1ULL : 0ULL;
     dm->idx_bits = idx_bits;
     dm->span_bits = span_bits;
-    dm->q = q;
+    dm->pairs = pairs;
     if (mode != DICT_PACKED8) dm->mode = mode;  // packed: starts as DICT_PACKED8 (host), a failed insert flips it
   }
   if (i >= V) return;
@@ -317,16 +307,11 @@ static __global__ __launch_bounds__(256) void k_dict_insert(const int64_t *__res
     if (prev != INVALID_U32) atomicOr(&st->dup_vertex, 1ULL);
   } else if (mode == DICT_PACKED8) {
     PkGeom pk;
-    pk.min_id = (uint64_t)min_id;
-    pk.max_id = (uint64_t)max_id;
-    pk.S = span_bits;
-    pk.q = q;
-    pk.b = idx_bits;
+    pk.set((uint64_t)min_id, (uint64_t)max_id, span_bits, pairs, idx_bits);
     uint64_t home, tag0;
     pk.locate(vid[i], &home, &tag0);
-    const uint64_t pmask = (1ULL << q) - 1ULL;
     for (uint64_t disp = 0; disp <= PK_MAX_DISP; disp++) {
-      const uint64_t g = (home + disp) & pmask;
+      const uint64_t g = pk.pair_at(home, disp);
       const unsigned long long entry = ((tag0 | disp) << idx_bits) | i;
 #pragma unroll
       for (int s = 0; s < 2; s++) {

@@ -86,7 +86,7 @@ struct DirectMap {
   unsigned long long mode;       // DictMode
   unsigned long long idx_bits;   // packed slots: bits of the dense index field
   unsigned long long span_bits;  // bits of max_id - min_id
-  unsigned long long q;          // packed table: log2 of the number of 16-byte slot pairs
+  unsigned long long pairs;      // packed table: number of 16-byte slot pairs (any number, gg_dict.h)
   unsigned long long decided;    // the mode chosen from min/max (mode may fall back to DICT_WIDE16 afterwards)
 };
 
