@@ -1156,6 +1156,7 @@ constexpr int FB_VLOW = GG_FB_VLOW;
 #define GG_FB_VG 16    // vertices per wave of k_vrows (<= 32)
 #endif
 constexpr int FB_VG = GG_FB_VG;
+static_assert(FB_VG <= 32 && (1 << FB_VLOW) / FB_VG <= 64, "k_vgroups: one lane per group of a bucket");
 #ifndef GG_FB_VCG
 #define GG_FB_VCG 16
 #endif
