@@ -1165,6 +1165,9 @@ constexpr int FB_VCG = GG_FB_VCG;  // chunks a wave of k_vrows takes at a time (
 #define GG_FB_VSTEPS 16  // 64-entry loads a wave of k_vrows keeps in flight
 #endif
 constexpr int FB_VSTEPS = GG_FB_VSTEPS;
+#ifndef GG_FB_ALIGNW
+#define GG_FB_ALIGNW 1  // k_vsort_pipe / k_vrows write their staged entries from a 128-byte line on
+#endif
 
 __global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict__ buf_f, uint32_t *__restrict__ buf_r,
                                                            const uint32_t *__restrict__ cstart,
@@ -1277,10 +1280,14 @@ __global__ __launch_bounds__(FB_THREADS) void k_vsort_pipe(uint32_t *__restrict_
     }
     __syncthreads();
     const uint32_t n = s_n;
+    {
+      // written back from the 128-byte line the chunk starts in (chunks start wherever their bucket does)
+      const uint32_t hd = GG_FB_ALIGNW ? (uint32_t)((reinterpret_cast<uintptr_t>(buf) >> 2) & 31u) : 0u;
 #pragma unroll
-    for (int it = 0; it < FB_ITEMS; it++) {
-      const uint32_t sidx = (uint32_t)it * FB_THREADS + threadIdx.x;
-      if (sidx < n) buf[sidx] = xw[sidx];
+      for (int it = 0; it <= FB_ITEMS; it++) {
+        const uint32_t sidx = (uint32_t)it * FB_THREADS + threadIdx.x - hd;
+        if (sidx < n) buf[sidx] = xw[sidx];
+      }
     }
     if (!has_next) break;
     __syncthreads();  // the stage and the cursors are reused
@@ -1456,8 +1463,11 @@ __global__ __launch_bounds__(64) void k_vrows(const uint32_t *__restrict__ buf_f
     __builtin_amdgcn_wave_barrier();  // the tables are rewritten by the next round of chunks
   }
   if (staged) {
-    for (uint32_t x0 = 0; x0 < n; x0 += 64) {
-      const uint32_t x = x0 + lane;
+    // written from the 128-byte line the group's first entry lies in: every store instruction covers whole lines
+    // (the first and the last are shared with the neighbouring groups)
+    const uint32_t hd = GG_FB_ALIGNW ? (t0 & 31u) : 0u;
+    for (uint32_t x0 = 0; x0 < n + hd; x0 += 64) {
+      const uint32_t x = x0 + lane - hd;  // (wraps below zero for the lanes before the first entry)
       if (x < n) {
         const uint32_t sw = s_stage[x];
         o_nbr[t0 + x] = sw & pay_mask;
