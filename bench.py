@@ -273,7 +273,11 @@ def extra_materialised(pkg, orc, device):
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": written / (k[1] * 1e-3) / HBM_PEAK,
                            "traffic": _pmc_traffic("sf10/mat_mid2/n1") if kname == "mat_mid2" else None,
                            "avg_launch_ms": k[1] / k[0],
-                           "note": "bytes actually written by the kernel (rows x 3 x 8) over its time"}
+                           "note": "bytes actually written by the kernel (rows x 3 x 8) over its time",
+                           "traffic_note": "2*FETCH_SIZE + WRITE_SIZE of an earlier counter run (profiles/pmc_traffic.json); "
+                                           "WRITE_SIZE tallies this kernel's nontemporal 16-byte stores at half their "
+                                           "bytes (12.8 GB counted, 25.5 GB written by construction and read back by "
+                                           "the digest): the kernel fetches 0.04 GB and writes each row once"}
     # parity over ALL rows: the digest of what was written (gg_result_digest maps every id of every row back to its
     # dense index and sums the row hashes) against the count-mode expansion's and the oracle's digest of the same walks
     rc, g = orc.csr_build(vid, src, dst)
