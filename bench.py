@@ -59,6 +59,35 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def _probe_rate_record(V, probes, seconds):
+    """The densification beside the roofline that actually bounds it: two random 16-byte dictionary probes per edge
+    row, against the rate a kernel of the same shape (two id columns streamed in, pairs streamed out) reaches with a
+    table of the dictionary's size — scripts/ubench_gather_sizes.hip, output committed under profiles/."""
+    pairs = max(512, ((V * 100 + 99) // 100 + 63) // 64 * 64)  # gg_csr_fast.hip: load factor 50 %, 16 bytes per pair
+    table_mb = pairs * 16 / 1048576.0
+    rec = {"probes_per_launch": int(probes), "achieved": probes / seconds / 1e9, "unit": "G probes/s",
+           "dictionary_MB": table_mb, "ceiling": None, "frac": None,
+           "note": "ceiling = measured rate of random 16-byte probes beside the same streams for a table of this size "
+                   "(profiles/r03_ubench_gather_sizes.txt, interpolated); the HBM fraction above charges SURVEY 8d's "
+                   "bytes, which this kernel does not move at HBM's pace because every probe is its own request"}
+    path = os.path.join(ROOT, "profiles", "r03_ubench_gather_sizes.txt")
+    try:
+        pts = {}
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 7 and f[0] == "table" and f[2] == "MB":
+                pts[float(f[1])] = max(pts.get(float(f[1]), 0.0), float(f[5]))
+        xs = sorted(pts)
+        lo = max([x for x in xs if x <= table_mb], default=xs[0])
+        hi = min([x for x in xs if x >= table_mb], default=xs[-1])
+        c = pts[lo] if hi == lo else pts[lo] + (pts[hi] - pts[lo]) * (table_mb - lo) / (hi - lo)
+        rec["ceiling"] = c
+        rec["frac"] = rec["achieved"] / c
+    except Exception:
+        pass
+    return rec
+
+
 def _pmc_traffic(key):
     """HBM-side bytes from the committed counter passes (profiles/pmc_traffic.json), or None."""
     try:
@@ -551,6 +580,9 @@ def main():
 
     recs = {k: record(k) for k in prof}
     recs = {k: v for k, v in recs.items() if v}
+    for name in ("densify_pairs", "densify_shard"):
+        if name in recs:
+            recs[name]["request_rate"] = _probe_rate_record(V, 2 * R_local, recs[name]["avg_launch_ms"] * 1e-3)
     dom = max(recs, key=lambda k: prof[k][1], default=None)
     roof = recs.get(dom)
     # phases: the timed region's figure where a kernel was timed there, the untimed pass's otherwise
