@@ -270,7 +270,39 @@ def extra_bfs64(pkg, gg, csr, vid, oracle_graph, batches=16):
         out["parity"] = bool(np.array_equal(d, dist) and ost == gst)
         out["cpu_port"] = {"value": ost["traversed_edges"] / cdt, "unit": "traversed edges/s", "cores": 1,
                            "sample": f"one 64-source batch, C oracle bitset BFS, {cdt:.2f}s"}
+        ref = _reference_cte_baseline(pkg)
+        if ref:
+            out["cpu_reference"] = ref
     return out
+
+
+def _reference_cte_baseline(pkg, scale="sf1", n_src=64, max_hops=5):
+    """The reference's own shortest-path statement (recursive CTE friends / friends_shortest, bi-10) on a bounded
+    sample: SF1, 64 seeds, hopCount < 5, all host threads, 1 cold + 2 hot runs in a child process
+    (oracle/ref_cte_bench.py).  Traversed edges of the same search from the C oracle's BFS with the same hop bound."""
+    import subprocess
+    from oracle import ref_duckdb as R
+    from tests import oracle_lib
+    if not R.available():
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_cte_bench.py"), scale, str(n_src), str(max_hops)],
+                           capture_output=True, text=True, timeout=300, cwd=ROOT)
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        vid, src, dst = pkg.datagen.ldbc(scale)
+        rc, g = oracle_lib.load().csr_build(vid, src, dst)
+        seeds = pkg.datagen.pick_sources(vid, n_src, 0x5EED)
+        d, ost = g.bfs64(g.lookup(seeds), max_hops)
+        rows = int((d >= 0).sum())
+        g.close()
+        return {"value": ost["traversed_edges"] / line["median_hot_s"], "unit": "traversed edges/s", "kind": "reference",
+                "cores": line["threads"], "cold_s": line["cold_s"], "hot_s": line["hot_s"], "median_hot_s": line["median_hot_s"],
+                "rows_match_oracle": bool(rows == line["rows"]),
+                "sample": f"reference DuckDB (oracle/_ref/libduckdb.so) recursive CTE friends/friends_shortest, LDBC {scale}, "
+                          f"{n_src} seeds, hopCount < {max_hops}: {line['rows']} result rows, TE={ost['traversed_edges']} per run "
+                          "(the GPU section above is SF100 to fixpoint; the statement does not finish at that size in the bench's time)"}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        return {"error": str(e)[:200]}
 
 
 def extra_materialised(pkg, orc, device):

@@ -204,6 +204,11 @@ def main():
         line["cpu_port"] = {"value": ost["traversed_edges"] / cdt, "unit": "traversed edges/s", "cores": 1,
                             "sample": f"one 64-source batch, C oracle bitset BFS, {cdt:.2f}s"}
         g.close()
+        if world == 1:  # the reference's own statement on a bounded sample (bench.py: SF1, 64 seeds, hopCount < 5)
+            import bench
+            ref = bench._reference_cte_baseline(pkg)
+            if ref:
+                line["cpu_reference"] = ref
     if rank == 0:
         print(json.dumps(line))
     csr.close()
