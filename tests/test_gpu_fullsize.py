@@ -16,8 +16,8 @@ def stage(gg, vid, src, dst):
 
 
 def test_sf10_two_hop_and_bfs_against_oracle(gg, orc):
-    """configs[1]: SF10 Person-KNOWS*1..2-Person — counts, digests, TE bit-exact vs the oracle (1.07 G walks);
-    configs[2]-shaped BFS: 64 sources to fixpoint, every distance equal."""
+    """configs[1]: SF10 Person-KNOWS*1..2-Person — counts, digests, TE bit-exact vs the oracle (1.07 G walks), in count
+    mode and materialised; configs[2]-shaped BFS: 64 sources to fixpoint, every distance equal."""
     vid, src, dst = datagen.ldbc("sf10")
     stage(gg, vid, src, dst)
     csr = gg.build_csr()
@@ -26,6 +26,20 @@ def test_sf10_two_hop_and_bfs_against_oracle(gg, orc):
     got = gg.expand_khop(csr, 1, 2)
     assert got == g.khop(1, 2)
     assert got["rows"][2] > 1_000_000_000
+    # the same walks materialised (25.5 GB of id columns in HBM, 32 k tiles of k_mat_mid2): every row's hash summed
+    # on the device equals the oracle's digest; three middle-vertex ranges with odd bounds partition rows and digest
+    res = gg.expand_khop_result(csr, 2)
+    assert res.digest(csr, 2) == (got["rows"][2], got["digest"][2])
+    res.close()
+    V = int(vid.size)
+    n_sum = d_sum = 0
+    for lo, hi in ((0, 777), (777, V // 2 + 1), (V // 2 + 1, V)):
+        part = gg.expand_khop_mid_result(csr, lo, hi, k_min=2)
+        n, d = part.digest(csr, 2)
+        assert n == part.rows(2)
+        n_sum, d_sum = n_sum + n, (d_sum + d) & 0xFFFFFFFF
+        part.close()
+    assert (n_sum, d_sum) == (got["rows"][2], got["digest"][2])
     sources = datagen.pick_sources(vid, 64, 7)
     dist, st = gg.bfs64(csr, sources, -1)
     o_dist, o_st = g.bfs64(g.lookup(sources), -1)
