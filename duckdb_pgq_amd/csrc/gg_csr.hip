@@ -689,6 +689,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   // (gg_csr_fast.hip), which also picks and fills the id dictionary; the 16-byte table is then filled only if the
   // densification needs it (ensure_ht does it later for gg_csr_lookup, source lists, the neighbour filter)
   int fast = 0;
+  ctx->status_early = false;
   if (!ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));  // (copies the staged vertex ids itself)
   if (!fast) {
     if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -806,10 +807,14 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   // vertex, kept-edge count
   // (the bucketed build runs no chained scan; k_gather_rowid still does nothing while the word is set — an earlier
   // call that failed may have left it — so a build with explicit rowids reports it rather than an unwritten column)
-  if (!fast || csr->eid)
-    GG_HIP(hipMemcpyAsync(&st->scan_error, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
-  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, s));
-  GG_HIP(hipStreamSynchronize(s));
+  if (fast && ctx->status_early && !csr->eid) {
+    GG_HIP(hipEventSynchronize(ctx->status_ev));  // (the status left the device behind the column scan)
+  } else {
+    if (!fast || csr->eid)
+      GG_HIP(hipMemcpyAsync(&st->scan_error, ctx->dev_err, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(BuildStatus), hipMemcpyDeviceToHost, s));
+    GG_HIP(hipStreamSynchronize(s));
+  }
   BuildStatus hs;
   memcpy(&hs, ctx->pin_scratch, sizeof(hs));
   ctx->dev_free(st);

@@ -176,6 +176,10 @@ struct gg_ctx {
 
   // small pinned scratch for D2H of counters
   uint64_t *pin_scratch = nullptr;  // 64 x u64 (word 63: copy of dev_err, see scan_error_fetch)
+  // the bucketed build's status words are final long before its last kernel: copied to pin_scratch behind the
+  // column scan, status_ev recorded behind the copy — gg_csr_build waits for that, not for the stream
+  hipEvent_t status_ev = nullptr;
+  bool status_early = false;
   unsigned long long *dev_err = nullptr;  // device word: != 0 after a chained scan gave up waiting
   uint32_t scan_spin_limit = 1u << 24;    // polls per predecessor before a scan tile gives up
   uint64_t scan_mute_tile = ~0ull;        // gg_debug_scan_fault: this scan tile never publishes (tests)

@@ -298,6 +298,7 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   GG_HIP(hipHostMalloc((void **)&ctx->pin_scratch, 64 * sizeof(uint64_t), hipHostMallocDefault));
   memset(ctx->pin_scratch, 0, 64 * sizeof(uint64_t));
   GG_HIP(hipMalloc((void **)&ctx->dev_err, sizeof(unsigned long long)));
+  GG_HIP(hipEventCreateWithFlags(&ctx->status_ev, hipEventDisableTiming));
   GG_HIP(hipMemset(ctx->dev_err, 0, sizeof(unsigned long long)));
   *out = ctx;
   return GG_OK;
@@ -318,6 +319,7 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
   if (ctx->dev_err) (void)hipFree(ctx->dev_err);
+  if (ctx->status_ev) (void)hipEventDestroy(ctx->status_ev);
   for (auto ev : ctx->prof_event_pool) (void)hipEventDestroy(ev);
   for (auto &h : ctx->host_blocks)
     if (h.ptr) (void)hipHostFree(h.ptr);
