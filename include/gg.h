@@ -115,7 +115,9 @@ int gg_ctx_set_edge_rowid(gg_ctx *ctx, int keep);
 /* Densify ids (device hash table), histogram + prefix-scan + stable LSD radix scatter by source.
  * Within a CSR row, neighbours are in ascending edge-rowid (append) order: the build is
  * deterministic.  Staged columns stay resident, so the build can be repeated.
- * Fails with GG_ERR_DUPLICATE_VERTEX if the vertex key column is not unique. */
+ * Fails with GG_ERR_DUPLICATE_VERTEX if the vertex key column is not unique.
+ * Returns as soon as the build's outcome is known (duplicate ids, kept edges); the last kernels may still be
+ * queued on the context's stream, behind which every later call on the context is ordered. */
 int gg_csr_build(gg_ctx *ctx, gg_csr **out);
 /* Multi-GPU sharding of the whole hot path with NO data-path collective: every rank stages the vertex
  * table and (at least) the edge rows with an endpoint it owns, and builds only the CSR rows of the vertices
