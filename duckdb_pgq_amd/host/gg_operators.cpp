@@ -243,21 +243,61 @@ public:
 	std::atomic<idx_t> rows {0};
 };
 
+//! Batch buffers of the edge sinks, kept across statements: a statement's 256 Sink threads would otherwise each
+//! allocate, zero and page-fault a buffer they fill two or three times (SF100: 40 M rows over 256 threads).
+struct GGBatchPool {
+	static constexpr idx_t MAX_IDLE = 512;
+	std::mutex lock;
+	vector<std::pair<idx_t, int64_t *>> idle; // (capacity in int64 values, memory)
+	int64_t *Acquire(idx_t values) {
+		{
+			lock_guard<mutex> guard(lock);
+			for (idx_t i = 0; i < idle.size(); i++) {
+				if (idle[i].first == values) {
+					auto memory = idle[i].second;
+					idle.erase(idle.begin() + i);
+					return memory;
+				}
+			}
+		}
+		return new int64_t[values]; // (not value-initialised: every row is written before it is read)
+	}
+	void Release(idx_t values, int64_t *memory) {
+		{
+			lock_guard<mutex> guard(lock);
+			if (idle.size() < MAX_IDLE) {
+				idle.emplace_back(values, memory);
+				return;
+			}
+		}
+		delete[] memory;
+	}
+};
+static GGBatchPool g_batch_pool;
+
 class GGSinkLocalState : public LocalSinkState {
 public:
+	~GGSinkLocalState() override {
+		if (batch_memory) {
+			g_batch_pool.Release(3 * batch_capacity, batch_memory);
+		}
+	}
 	vector<vector<int64_t>> columns; // per-thread conversion buffers, reused across chunks
 	vector<const int64_t *> keys;    // what is handed to gg_*_append: the chunk's own vectors or `columns`
 	// Edge rows are batched per thread and handed to the staging area BATCH_ROWS at a time: one reservation
-	// per 64 chunks instead of one per chunk keeps a dozen Sink threads off each other's reservation lock
-	// (GG_SINK_BATCH_ROWS; 1024 = unbatched)
-	vector<int64_t> batch[3];
+	// per 16 chunks instead of one per chunk keeps the Sink threads off each other's reservation lock
+	// (GG_SINK_BATCH_ROWS; 1024 = unbatched).  Three columns of batch_capacity rows, from g_batch_pool.
+	int64_t *batch_memory = nullptr;
+	idx_t batch_capacity = 0;
+	int64_t *batch[3] = {nullptr, nullptr, nullptr};
+	bool batch_has_rowid = false;
 	idx_t batch_rows = 0;
 };
 
 static idx_t SinkBatchRows() {
 	static const idx_t rows = [] {
 		auto env = std::getenv("GG_SINK_BATCH_ROWS");
-		const idx_t n = env ? (idx_t)std::strtoull(env, nullptr, 10) : 64 * STANDARD_VECTOR_SIZE;
+		const idx_t n = env ? (idx_t)std::strtoull(env, nullptr, 10) : 16 * STANDARD_VECTOR_SIZE;
 		return MaxValue<idx_t>(n, STANDARD_VECTOR_SIZE);
 	}();
 	return rows;
@@ -268,8 +308,8 @@ static void FlushEdgeBatch(GGGraph &graph, GGSinkLocalState &lstate, bool has_ro
 		return;
 	}
 	for (int p = 0; p < graph.Parts(); p++) {
-		GGGraph::Check(gg_edges_append(graph.Part(p).ctx, lstate.batch[0].data(), lstate.batch[1].data(),
-		                               has_rowid ? lstate.batch[2].data() : nullptr, lstate.batch_rows),
+		GGGraph::Check(gg_edges_append(graph.Part(p).ctx, lstate.batch[0], lstate.batch[1],
+		                               has_rowid ? lstate.batch[2] : nullptr, lstate.batch_rows),
 		               "gg_edges_append");
 	}
 	lstate.batch_rows = 0;
@@ -348,16 +388,19 @@ SinkResultType PhysicalGGEdgeSink::Sink(ExecutionContext &context, GlobalSinkSta
 	                    : GGKeyColumns(input, {0, 1}, lstate.columns, lstate.keys);
 	const idx_t capacity = SinkBatchRows();
 	const idx_t ncols = has_rowid ? 3 : 2;
-	if (lstate.batch[0].size() < capacity) {
-		for (idx_t c = 0; c < ncols; c++) {
-			lstate.batch[c].resize(capacity);
+	if (!lstate.batch_memory) {
+		lstate.batch_memory = g_batch_pool.Acquire(3 * capacity);
+		lstate.batch_capacity = capacity;
+		for (idx_t c = 0; c < 3; c++) {
+			lstate.batch[c] = lstate.batch_memory + c * capacity;
 		}
 	}
+	lstate.batch_has_rowid = has_rowid;
 	if (lstate.batch_rows + n > capacity) {
 		FlushEdgeBatch(*graph, lstate, has_rowid);
 	}
 	for (idx_t c = 0; c < ncols; c++) {
-		memcpy(lstate.batch[c].data() + lstate.batch_rows, lstate.keys[c], n * sizeof(int64_t));
+		memcpy(lstate.batch[c] + lstate.batch_rows, lstate.keys[c], n * sizeof(int64_t));
 	}
 	lstate.batch_rows += n;
 	gstate.rows += n;
@@ -366,7 +409,7 @@ SinkResultType PhysicalGGEdgeSink::Sink(ExecutionContext &context, GlobalSinkSta
 
 void PhysicalGGEdgeSink::Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate_p) const {
 	auto &lstate = (GGSinkLocalState &)lstate_p;
-	FlushEdgeBatch(*graph, lstate, !lstate.batch[2].empty());
+	FlushEdgeBatch(*graph, lstate, lstate.batch_has_rowid);
 }
 
 SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
