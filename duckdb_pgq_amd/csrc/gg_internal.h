@@ -96,12 +96,19 @@ namespace gg {
 // Guards the few words an edge-row reservation touches.  Sink threads take it once per DataChunk; with a
 // sleeping mutex 64+ of them form a convoy (measured: 40 M rows staged in 33 ms by 8 threads, 600 ms by
 // 256), so the hot path spins for its ~50 ns critical section and only block switches use mu/cv.
+// Test-and-test-and-set with a growing pause: 255 waiters that all WRITE the lock word (a bare test_and_set loop)
+// keep its cache line away from the one thread that wants to release it.
 struct SpinLock {
-  std::atomic_flag flag = ATOMIC_FLAG_INIT;
+  std::atomic<bool> held{false};
   void lock() {
-    while (flag.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause();
+    for (unsigned spins = 1;; spins = spins < 64 ? spins * 2 : 64) {
+      if (!held.exchange(true, std::memory_order_acquire)) return;
+      do {
+        for (unsigned i = 0; i < spins; i++) __builtin_ia32_pause();
+      } while (held.load(std::memory_order_relaxed));
+    }
   }
-  void unlock() { flag.clear(std::memory_order_release); }
+  void unlock() { held.store(false, std::memory_order_release); }
 };
 }  // namespace gg
 
