@@ -690,6 +690,7 @@ static int csr_build_impl(gg_ctx *ctx, int part, int n_parts, gg_csr **out) {
   // densification needs it (ensure_ht does it later for gg_csr_lookup, source lists, the neighbour filter)
   int fast = 0;
   ctx->status_early = false;
+  staging_trace_print();
   if (!ctx->legacy_build) GG_TRY(csr_build_fast(ctx, csr, st, &fast));  // (copies the staged vertex ids itself)
   if (!fast) {
     if (V) GG_HIP(hipMemcpyAsync(csr->vid, ctx->c_vid.dev, V * sizeof(int64_t), hipMemcpyDeviceToDevice, s));

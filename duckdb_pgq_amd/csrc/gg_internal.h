@@ -277,6 +277,8 @@ int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t 
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev);
 // make a staged column hold need_rows rows, keeping the first live_rows (gg_runtime.hip; caller holds mu)
 int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows);
+// GG_STAGING_TRACE=1: print and reset the edge staging's waiting-time counters (gg_runtime.hip)
+void staging_trace_print();
 // build csr->roff / csr->rnbr if absent (gg_csr.hip)
 int ensure_reverse(gg_ctx *ctx, gg_csr *csr);
 // fill csr->ht from csr->vid if the build did not need it (gg_csr.hip); every ht_lookup user calls this first

@@ -42,6 +42,10 @@
 #include "duckdb/transaction/transaction.hpp"
 #include "gg_extension.hpp"
 
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
+
 namespace duckdb {
 
 string GGQuote(const string &ident) {
@@ -602,9 +606,26 @@ static void LoadInternal(DatabaseInstance &db) {
 
 } // namespace duckdb
 
+// GG_CRASH_TRACE=1: a backtrace on stderr when the process dies of SIGSEGV / SIGBUS / SIGABRT (diagnostic: the boxes
+// this runs on have no debugger)
+static void GGCrashHandler(int sig) {
+	void *frames[64];
+	const int n = backtrace(frames, 64);
+	const char msg[] = "\n=== gg crash trace ===\n";
+	(void)!write(2, msg, sizeof(msg) - 1);
+	backtrace_symbols_fd(frames, n, 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+
 extern "C" {
 
 void gg_duckdb_init(duckdb::DatabaseInstance &db) {
+	if (std::getenv("GG_CRASH_TRACE")) {
+		for (int sig : {SIGSEGV, SIGBUS, SIGABRT}) {
+			signal(sig, GGCrashHandler);
+		}
+	}
 	duckdb::LoadInternal(db);
 }
 

@@ -20,6 +20,7 @@ from oracle import ref_duckdb as R  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXT = os.path.join(ROOT, "duckdb_pgq_amd", "gg_duckdb.duckdb_extension")
+os.environ.setdefault("GG_CRASH_TRACE", "1")  # a backtrace on stderr if a worker thread faults
 
 
 def main():

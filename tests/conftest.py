@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the extension prints a backtrace if the process dies of a signal (gg_duckdb_extension.cpp): the GPU boxes have no
+# debugger, and a fault inside the reference's worker threads would otherwise leave nothing but an exit code
+os.environ.setdefault("GG_CRASH_TRACE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
