@@ -147,7 +147,12 @@ struct gg_ctx {
     std::atomic<int> writers{0};   // reservations whose memcpy has not finished (not guarded by mu)
     bool has_rowid = false;        // some reservation in the block carries explicit rowids
     enum State { OPEN, CLOSED, FREE } state = FREE;
-  } eblk[2];
+  };
+  // A ring of blocks (two: a ring of four staged SF100's edge table no faster, 33 GB/s on the box where both were
+  // measured — 8 MB copies back to back reach 54 GB/s, scripts/ubench_h2d.hip: it is the host side that fills the
+  // blocks at that pace, not the copy engine that waits for it)
+  static constexpr int EDGE_BLOCKS = 2;
+  EdgeBlock eblk[EDGE_BLOCKS];
   int cur_e = 0;                                 // the OPEN block
 
   // ---- pinned host buffers handed out by gg_host_alloc (guarded by host_mu) ----

@@ -293,9 +293,11 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   GG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) {
     GG_HIP(hipHostMalloc((void **)&ctx->pin_v[i], gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
-    GG_HIP(hipHostMalloc((void **)&ctx->eblk[i].pin, 3 * gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
     GG_HIP(hipEventCreateWithFlags(&ctx->pin_v_free[i], hipEventDisableTiming));
-    GG_HIP(hipEventCreateWithFlags(&ctx->eblk[i].free_ev, hipEventDisableTiming));
+  }
+  for (auto &b : ctx->eblk) {
+    GG_HIP(hipHostMalloc((void **)&b.pin, 3 * gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
+    GG_HIP(hipEventCreateWithFlags(&b.free_ev, hipEventDisableTiming));
   }
   ctx->eblk[0].state = gg_ctx::EdgeBlock::OPEN;
   GG_HIP(hipHostMalloc((void **)&ctx->pin_scratch, 64 * sizeof(uint64_t), hipHostMallocDefault));
@@ -316,9 +318,11 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
     if (b.ptr) (void)hipFree(b.ptr);
   for (int i = 0; i < 2; i++) {
     if (ctx->pin_v[i]) (void)hipHostFree(ctx->pin_v[i]);
-    if (ctx->eblk[i].pin) (void)hipHostFree(ctx->eblk[i].pin);
     if (ctx->pin_v_free[i]) (void)hipEventDestroy(ctx->pin_v_free[i]);
-    if (ctx->eblk[i].free_ev) (void)hipEventDestroy(ctx->eblk[i].free_ev);
+  }
+  for (auto &b : ctx->eblk) {
+    if (b.pin) (void)hipHostFree(b.pin);
+    if (b.free_ev) (void)hipEventDestroy(b.free_ev);
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
   if (ctx->dev_err) (void)hipFree(ctx->dev_err);
@@ -541,10 +545,11 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
       // Whoever reserved the block's last row sends it off and opens the other one.  In THIS order: the flush is
       // queued as soon as the block's writers are done — behind the other block's copies, which are normally still
       // on their way, so the copy engine goes from one block to the next without a pause — and only then does the
-      // closer wait for those copies to leave the other block's pinned memory and reopen it.  (The other way round
+      // closer wait for the copies of the ring's next block to have left its pinned memory, and reopen it.  (The other way round
       // — reopen first, flush after — left the engine idle from the end of one block's copies until the host had
       // woken up and issued the next: 30 instead of 40 GB/s over PCIe; everybody else waits for the switch either way.)
-      gg_ctx::EdgeBlock &o = ctx->eblk[&b == &ctx->eblk[0] ? 1 : 0];
+      const int next_e = (int)((&b - ctx->eblk) + 1) % gg_ctx::EDGE_BLOCKS;
+      gg_ctx::EdgeBlock &o = ctx->eblk[next_e];  // the next block of the ring: the one flushed longest ago
       const uint64_t td0 = g_tr_on ? tr_now() : 0;
       while (b.writers.load(std::memory_order_acquire) != 0) std::this_thread::yield();
       if (g_tr_on) g_tr_drain_ns += tr_now() - td0;
@@ -562,7 +567,7 @@ extern "C" int gg_edges_append(gg_ctx *ctx, const int64_t *src, const int64_t *d
       o.fill = 0;
       o.has_rowid = false;
       o.state = gg_ctx::EdgeBlock::OPEN;
-      ctx->cur_e ^= 1;
+      ctx->cur_e = next_e;
       ctx->edge_spin.unlock();
       lk.unlock();
       ctx->cv.notify_all();  // appenders waiting for a block with room
