@@ -12,12 +12,15 @@ import numpy as np  # noqa: E402
 import duckdb_pgq_amd as pkg  # noqa: E402
 
 scale = sys.argv[1] if len(sys.argv) > 1 else "sf100"
+if len(sys.argv) > 2:  # a libgg variant (scripts/build_variants.py)
+    from duckdb_pgq_amd import gg as ggmod
+    ggmod._lib = ggmod.load_library(os.path.abspath(sys.argv[2]))
 vid, src, dst = pkg.datagen.ldbc(scale)
 n = src.size
 CH = 65536
 g = pkg.GG(0)
 g.set_edge_rowid(False)
-for T in (1, 2, 4, 8, 16, 32, 64):
+for T in (1, 4, 8, 16, 64):
     best = 1e9
     for rep in range(3):
         g.staging_clear()
