@@ -84,6 +84,12 @@ public:
 		ExecutionContext ec(state.context, thread);
 		auto local_sink = state.sink.GetLocalSinkState(ec);
 		TableScanState scan;
+		// RowGroupScanState's constructor leaves row_group unset (scan_state.hpp:91-97), and NextParallelScan's last
+		// task — the transaction-local rows — does not set it either (data_table.cpp:340-349): a task whose FIRST
+		// morsel is that one would have DataTable::ScanBaseTable walk a row group at whatever the stack held.  (The
+		// reference keeps its scan state in a fresh heap object; here it lives on a worker's stack.  Seen as one
+		// fault in a few hundred pinned builds, in RowGroup::InitializeScan below IngestTask::Scan.)
+		scan.row_group_scan_state.row_group = nullptr;
 		auto column_ids = state.column_ids; // DataTable::Scan wants a mutable vector
 		DataChunk chunk;
 		chunk.Initialize(state.types);
