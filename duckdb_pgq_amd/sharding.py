@@ -58,9 +58,30 @@ def combine(vec, dist=None, device=None) -> list:
     # (a group of one rank still makes the call: that is how a one-GPU box exercises the RCCL path)
     import torch
 
-    t = torch.tensor(split_halves(vec), dtype=torch.int64, device=device or "cpu")
-    dist.all_reduce(t)
-    return join_halves(t.tolist())
+    halves = split_halves(vec)
+    if device in (None, "cpu"):
+        t = torch.tensor(halves, dtype=torch.int64)
+        dist.all_reduce(t)
+        return join_halves(t.tolist())
+    # device tensors: one page-locked staging tensor and one device tensor per vector length, kept across queries —
+    # up, all-reduce and down are queued on torch's stream without a host synchronisation in between (building a
+    # tensor from a list and reading it back with tolist() were two of them per query)
+    key = (len(halves), str(device))
+    bufs = _combine_buffers.get(key)
+    if bufs is None:
+        bufs = (torch.empty(len(halves), dtype=torch.int64).pin_memory(),
+                torch.empty(len(halves), dtype=torch.int64, device=device))
+        _combine_buffers[key] = bufs
+    host, dev = bufs
+    host.copy_(torch.tensor(halves, dtype=torch.int64))
+    dev.copy_(host, non_blocking=True)
+    dist.all_reduce(dev)
+    host.copy_(dev, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return join_halves(host.tolist())
+
+
+_combine_buffers = {}
 
 
 def dsum(a: int, b: int) -> int:
