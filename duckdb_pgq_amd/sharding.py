@@ -69,16 +69,16 @@ def combine(vec, dist=None, device=None) -> list:
     key = (len(halves), str(device))
     bufs = _combine_buffers.get(key)
     if bufs is None:
-        bufs = (torch.empty(len(halves), dtype=torch.int64).pin_memory(),
-                torch.empty(len(halves), dtype=torch.int64, device=device))
+        host = torch.empty(len(halves), dtype=torch.int64).pin_memory()
+        bufs = (host, host.numpy(), torch.empty(len(halves), dtype=torch.int64, device=device))
         _combine_buffers[key] = bufs
-    host, dev = bufs
-    host.copy_(torch.tensor(halves, dtype=torch.int64))
+    host, host_np, dev = bufs
+    host_np[:] = halves
     dev.copy_(host, non_blocking=True)
     dist.all_reduce(dev)
     host.copy_(dev, non_blocking=True)
     torch.cuda.current_stream().synchronize()
-    return join_halves(host.tolist())
+    return join_halves(host_np.tolist())
 
 
 _combine_buffers = {}
