@@ -518,20 +518,33 @@ def main():
         log(f"{args.workload}: V={V} knows rows={R} ({R_local} on this rank); datagen {t_gen:.1f}s, "
             f"staging (PCIe) {t_stage*1e3:.1f} ms")
 
-    def step():
+    def build():
         # all persons are sources; with N ranks this rank builds only the CSR rows of the vertices it
         # owns (owner = hash(id) mod N) and produces the walks whose middle vertex it owns
         if args.shard_of > 1:
-            c = gg.build_csr_shard(0, args.shard_of)
-        else:
-            c = gg.build_csr_shard(rank, world) if world > 1 else gg.build_csr()
-        st = gg.expand_khop(c, 1, 2)
-        c.close()
-        vec = sharding.combine(sharding.stats_to_vec(st), dist, device="cuda")
+            return gg.build_csr_shard(0, args.shard_of)
+        return gg.build_csr_shard(rank, world) if world > 1 else gg.build_csr()
+
+    def run_steps(n):
+        """n complete steps — build, expansion, combine of the ranks' results — with the host side pipelined by one
+        step when there are several ranks: the NEXT step's build is launched (gg_csr_build returns once its status is
+        known, two thirds of its kernels still queued) before the ranks' counts of THIS step are all-reduced, so the
+        collective and its host round trips run beside those kernels instead of in front of them.  Every step's
+        build, expansion and combine lie inside the caller's timed region; no CSR is built that is not expanded."""
+        vec = st = None
+        c = build()
+        for i in range(n):
+            st = gg.expand_khop(c, 1, 2)
+            c.close()
+            c = build() if i + 1 < n else None
+            vec = sharding.combine(sharding.stats_to_vec(st), dist, device="cuda")
         return vec, st
 
-    for _ in range(args.warmup):
-        step()
+    def step():
+        return run_steps(1)
+
+    if args.warmup:
+        run_steps(args.warmup)
     # HIP events around a launch are not free (two records per launch: ~0.3 ms of a step when all ~25 launches
     # are timed), so the timed region times only the kernels the roofline can name; the per-kernel table of
     # everything else comes from a few extra, untimed steps afterwards.
@@ -544,8 +557,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tot, st_local = step()
+    tot, st_local = run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
