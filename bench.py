@@ -10,7 +10,9 @@ vertices are hash-partitioned (owner = hash(person id) mod N) and so is the edge
 table is replicated), builds only the CSR rows of the vertices it owns (gg_csr_build_shard) and produces
 the walks whose middle vertex it owns; there is no data-path collective, only one small all-reduce of
 (rows, digest, TE) per step, so `value` = total traversed edges of the whole query / max-over-ranks
-time ("strong" scaling: the query is fixed, ranks split it).
+time ("strong" scaling: the query is fixed, ranks split it).  The K timed steps are K builds, K expansions and K
+all-reduces inside the timed region; with N > 1 the host launches step i + 1's build before it combines step i's
+counts, so the collective runs beside the build's queued kernels (run_steps).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sf100|sf10|sf1] [--no-cpu] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
