@@ -246,7 +246,7 @@ public:
 //! Batch buffers of the edge sinks, kept across statements: a statement's 256 Sink threads would otherwise each
 //! allocate, zero and page-fault a buffer they fill two or three times (SF100: 40 M rows over 256 threads).
 struct GGBatchPool {
-	static constexpr idx_t MAX_IDLE = 512;
+	static constexpr idx_t MAX_IDLE = 256; // (384 KB each at the default batch size: at most 96 MB kept)
 	std::mutex lock;
 	vector<std::pair<idx_t, int64_t *>> idle; // (capacity in int64 values, memory)
 	int64_t *Acquire(idx_t values) {
