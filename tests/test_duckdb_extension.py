@@ -829,3 +829,40 @@ def test_the_count_of_two_hop_walks_over_an_ownership_sharded_graph(db, monkeypa
         d.execute("DEALLOCATE sharded")
     finally:
         d.execute("PRAGMA disable_gpu_graph")
+
+
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
+def test_repeated_statements_and_pin_cycles_on_both_ingest_routes(db, monkeypatch):
+    """The same statements over and over: through pipeline sinks, through the scan-function route (ingest tasks on the
+    reference's scheduler) and on a graph pinned and unpinned each round.  (An ingest task whose first morsel was the
+    transaction-local one used to walk a row group at an unset pointer: one fault in ~40 pinned builds at SF100,
+    scripts/stress_sql.py; this loop keeps the paths it took exercised.)"""
+    d, vid = db
+    s = int(vid[11])
+    stmts = [_chain(2, "count(*)"),
+             _chain(2, "k1.k_person1id, k2.k_person2id") + f" AND k1.k_person1id = {s}",
+             R.sql_shortest([int(v) for v in vid[:7]], 3)]
+    d.execute("PRAGMA disable_gpu_graph")
+    want = [sort_rows(d.execute(q)) for q in stmts]
+    d.execute("PRAGMA enable_gpu_graph")
+    try:
+        for _ in range(6):
+            for route in ("sinks", "scan"):
+                if route == "scan":
+                    monkeypatch.setenv("GG_NO_PIPELINE_SINKS", "1")
+                else:
+                    monkeypatch.delenv("GG_NO_PIPELINE_SINKS", raising=False)
+                for q, w in zip(stmts, want):
+                    assert np.array_equal(sort_rows(d.execute(q)), w), (route, q)
+            monkeypatch.delenv("GG_NO_PIPELINE_SINKS", raising=False)
+            d.execute("PRAGMA gg_use_pinned_graphs")
+            d.execute(f"SELECT * FROM gg_graph_pin({GRAPH})")
+            d.execute("SELECT * FROM gg_graph_pin('', '', 'knows', 'k_person1id', 'k_person2id')")
+            for q, w in zip(stmts, want):
+                assert np.array_equal(sort_rows(d.execute(q)), w), ("pinned", q)
+            d.execute("SELECT * FROM gg_graph_unpin()")
+            d.execute("PRAGMA gg_ignore_pinned_graphs")
+    finally:
+        monkeypatch.delenv("GG_NO_PIPELINE_SINKS", raising=False)
+        d.execute("PRAGMA gg_ignore_pinned_graphs")
+        d.execute("PRAGMA disable_gpu_graph")
