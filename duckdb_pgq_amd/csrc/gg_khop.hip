@@ -1593,6 +1593,109 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
   return GG_OK;
 }
 
+// ---- walk COUNTS from degrees ---------------------------------------------------------------------------------------
+// count(*) over a join chain needs no row and no digest (the reference's aggregate above the joins only counts the
+// chunks' cardinalities): with w_0(v) = how often v is a source and w_h(v) = sum over the in-neighbours u of v of
+// w_{h-1}(u) = the h-hop walks that end in v, the h-hop walks number  rows_h = sum over v of w_{h-1}(v) * outdeg(v).
+// From every vertex w_0 = 1 and w_1 = indeg, so the 1- and 2-hop counts are two passes over offset arrays and every
+// further hop is one pull over the reverse rows.  Counts wrap mod 2^64 like the digest-bearing kernels' counters.
+__global__ __launch_bounds__(256) void k_wc_seed(const uint32_t *__restrict__ dense, uint64_t n,
+                                                 unsigned long long *__restrict__ w0) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && dense[i] != INVALID_U32) atomicAdd(&w0[dense[i]], 1ULL);
+}
+
+// out[0] += sum over v of weight(v) * outdeg(v); weight = w[v], or indeg(v) (w == nullptr, roff given), or 1
+__global__ __launch_bounds__(256) void k_wc_dot(const uint32_t *__restrict__ off, const uint32_t *__restrict__ roff,
+                                                const unsigned long long *__restrict__ w, uint64_t V,
+                                                unsigned long long *__restrict__ out) {
+  __shared__ uint64_t s_red[4];
+  uint64_t acc = 0;
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t wt = w ? w[v] : (roff ? (uint64_t)(roff[v + 1] - roff[v]) : 1ull);
+    acc += wt * (uint64_t)(off[v + 1] - off[v]);
+  }
+  acc = wave_reduce_add_u64(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(s_red[0] + s_red[1] + s_red[2] + s_red[3]));
+}
+
+// w_out[v] = sum over the in-neighbours u of v of weight(u) (w_in[u], or indeg(u) when w_in == nullptr); 16 lanes per vertex
+__global__ __launch_bounds__(256) void k_wc_pull(const uint32_t *__restrict__ roff, const uint32_t *__restrict__ rnbr,
+                                                 const unsigned long long *__restrict__ w_in, uint64_t V,
+                                                 unsigned long long *__restrict__ w_out) {
+  const uint64_t v = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  uint64_t acc = 0;
+  if (v < V) {
+    for (uint32_t i = roff[v] + sub; i < roff[v + 1]; i += 16) {
+      const uint32_t u = rnbr[i];
+      acc += w_in ? w_in[u] : (uint64_t)(roff[u + 1] - roff[u]);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (v < V && sub == 0) w_out[v] = acc;
+}
+
+// rows[h] for h in [k_min, k_max]; dense_src == nullptr: from every vertex (shards: the walks whose middle vertex —
+// 1-hop rows: destination — is owned, k_max <= 2), else from the n_src dense indices (INVALID_U32 entries skipped)
+int khop_count_rows(gg_ctx *ctx, gg_csr *csr, const uint32_t *dense_src, uint64_t n_src, int k_min, int k_max,
+                    uint64_t *rows) {
+  for (int h = 0; h <= GG_MAX_HOPS; h++) rows[h] = 0;
+  const uint64_t V = csr->V;
+  if (V == 0) return GG_OK;
+  const bool all = dense_src == nullptr;
+  if (k_max >= 2 || (all && csr->n_parts > 1)) GG_TRY(ensure_reverse(ctx, csr));
+  unsigned long long *out = nullptr, *wa = nullptr, *wb = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&out, (GG_MAX_HOPS + 1) * sizeof(unsigned long long)));
+  GG_HIP(hipMemsetAsync(out, 0, (GG_MAX_HOPS + 1) * sizeof(unsigned long long), ctx->stream));
+  const unsigned dot_grid = (unsigned)std::min<uint64_t>((V + 255) / 256, 1024);
+  const unsigned pull_grid = (unsigned)((V * 16 + 255) / 256);
+  const unsigned long long *w = nullptr;  // weights of the level the next dot takes (nullptr: implicit)
+  int level = 0;                         // w describes w_level
+  if (!all) {
+    GG_TRY(ctx->dev_alloc((void **)&wa, V * sizeof(unsigned long long)));
+    GG_HIP(hipMemsetAsync(wa, 0, V * sizeof(unsigned long long), ctx->stream));
+    if (n_src)
+      GG_LAUNCH(ctx, "wc_seed", k_wc_seed, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, dense_src, n_src, wa);
+    w = wa;
+  }
+  for (int h = 1; h <= k_max; h++) {
+    // rows_h = sum of w_{h-1} * outdeg
+    if (all && h == 1) {
+      // (w_0 = 1: every forward entry, or for a shard every entry into an owned vertex — a constant)
+    } else if (all && h == 2) {
+      GG_LAUNCH(ctx, "wc_dot", k_wc_dot, dim3(dot_grid), dim3(256), 0, csr->off, csr->roff,
+                (const unsigned long long *)nullptr, V, out + h);
+    } else {
+      // make w_{h-1} explicit if it is not yet
+      while (level < h - 1) {
+        unsigned long long *&dst = (w == wa) ? wb : wa;
+        if (!dst) GG_TRY(ctx->dev_alloc((void **)&dst, V * sizeof(unsigned long long)));
+        // from every vertex the first explicit level is w_2 = pull(indeg)
+        const bool from_indeg = all && level < 2;
+        GG_LAUNCH(ctx, "wc_pull", k_wc_pull, dim3(pull_grid), dim3(256), 0, csr->roff, csr->rnbr,
+                  from_indeg ? (const unsigned long long *)nullptr : w, V, dst);
+        level = from_indeg ? 2 : level + 1;
+        w = dst;
+      }
+      if (h >= k_min)
+        GG_LAUNCH(ctx, "wc_dot", k_wc_dot, dim3(dot_grid), dim3(256), 0, csr->off, (const uint32_t *)nullptr, w, V, out + h);
+    }
+  }
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, out, (GG_MAX_HOPS + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  GG_HIP(hipStreamSynchronize(ctx->stream));
+  for (int h = k_min; h <= k_max; h++) rows[h] = ctx->pin_scratch[h];
+  if (all && k_min <= 1) rows[1] = csr->n_parts > 1 ? csr->E_rev : csr->E;
+  ctx->dev_free(out);
+  ctx->dev_free(wa);
+  ctx->dev_free(wb);
+  return GG_OK;
+}
+
 int check_args(gg_ctx *ctx, const gg_csr *csr, int k_min, int k_max, gg_khop_stats *stats) {
   if (!ctx || !csr || !stats || csr->ctx != ctx) {
     set_error("gg_expand_khop: bad context/csr/stats argument");
@@ -1733,6 +1836,34 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
   ctx->dev_free(dense);
   ctx->dev_free(cursor);
   free_frontier(ctx, f0);
+  return rc;
+}
+
+extern "C" int gg_khop_count(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min, int k_max,
+                            uint64_t *rows) {
+  ApiScope scope(ctx);
+  gg_khop_stats unused;
+  GG_TRY(check_args(ctx, csr, k_min, k_max, &unused));
+  if (!rows) return GG_ERR_INVALID_ARG;
+  if (csr->n_parts > 1 && src_ids) {
+    set_error("a CSR shard (gg_csr_build_shard) only supports all-source 2-hop count expansion");
+    return GG_ERR_STATE;
+  }
+  GG_HIP(hipSetDevice(ctx->device));
+  if (!src_ids) return khop_count_rows(ctx, const_cast<gg_csr *>(csr), nullptr, 0, k_min, k_max, rows);
+  int64_t *ids_dev = nullptr;
+  uint32_t *dense = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&ids_dev, (n_src ? n_src : 1) * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&dense, (n_src ? n_src : 1) * sizeof(uint32_t)));
+  int rc = GG_OK;
+  if (n_src) {
+    GG_HIP(hipMemcpyAsync(ids_dev, src_ids, n_src * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));  // src_ids is caller memory: consumed before return
+    rc = lookup_ids(ctx, csr, ids_dev, n_src, dense);
+  }
+  if (rc == GG_OK) rc = khop_count_rows(ctx, const_cast<gg_csr *>(csr), dense, n_src, k_min, k_max, rows);
+  ctx->dev_free(ids_dev);
+  ctx->dev_free(dense);
   return rc;
 }
 

@@ -17,7 +17,7 @@ SYMBOLS = [
     "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
-    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
+    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_count", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_debug_max_grid_tiles", "gg_debug_reset",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
@@ -91,6 +91,7 @@ def load_library(path: str | None = None):
     lib.gg_expand_khop.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_expand_khop_range.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_khop_partition.argtypes = [P, P, C.c_int, C.POINTER(u64)]
+    lib.gg_khop_count.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(u64)]
     lib.gg_expand_khop_mid.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.POINTER(KhopStats)]
     lib.gg_khop_partition_mid.argtypes = [P, P, C.c_int, C.POINTER(u64)]
     lib.gg_expand_khop_mid_result.argtypes = [P, P, u64, u64, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
@@ -374,6 +375,16 @@ class GG:
         if materialise:
             d["tables"] = self._collect(res, k_min, k_max)
         return d
+
+    def khop_count(self, csr: Csr, k_min: int, k_max: int, sources=None) -> list:
+        """Number of h-hop walks per length (index h), from degrees: no row, no digest (gg_khop_count)."""
+        rows = (C.c_uint64 * (GG_MAX_HOPS + 1))()
+        if sources is None:
+            self._chk(self.lib.gg_khop_count(self.ctx, csr.handle, None, 0, k_min, k_max, rows))
+        else:
+            a, p = _i64(sources)
+            self._chk(self.lib.gg_khop_count(self.ctx, csr.handle, p, a.size, k_min, k_max, rows))
+        return list(rows)
 
     def expand_khop_result(self, csr: Csr, k: int, sources=None) -> KhopResult:
         """k-hop walks from `sources` (None: all vertices) materialised in HBM; nothing crosses PCIe."""

@@ -241,6 +241,12 @@ int64_t **GGResultSlab::Columns(idx_t columns) {
 class GGSinkGlobalState : public GlobalSinkState {
 public:
 	std::atomic<idx_t> rows {0};
+	//! What a sink does to the staging area before its own rows go in (PhysicalGGEdgeSink::PrepareStaging) happens when
+	//! the sink RUNS — its first Sink call, or its Finalize when the table is empty — not when its state is made:
+	//! Pipeline::Ready makes every sink's global state at schedule time (pipeline.cpp:125-142), before the sinks ahead of
+	//! it in the build order have staged anything.
+	std::atomic<bool> prepared {false};
+	std::mutex prepare_lock;
 };
 
 //! Batch buffers of the edge sinks, kept across statements: a statement's 256 Sink threads would otherwise each
@@ -363,6 +369,18 @@ unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext
 	if (graph->Parts() > 1 && (as_filter || !build)) {
 		throw InternalException("a sharded graph has one edge table");
 	}
+	return make_unique<GGSinkGlobalState>();
+}
+
+void PhysicalGGEdgeSink::PrepareStaging(GlobalSinkState &gstate_p) const {
+	auto &gstate = (GGSinkGlobalState &)gstate_p;
+	if (gstate.prepared.load(std::memory_order_acquire)) {
+		return;
+	}
+	lock_guard<mutex> guard(gstate.prepare_lock);
+	if (gstate.prepared.load(std::memory_order_relaxed)) {
+		return;
+	}
 	if (as_filter) {
 		// second edge table over the same staged vertices: drop the first table's staged rows only
 		GGGraph::Check(gg_staging_clear_edges(graph->ctx), "gg_staging_clear_edges");
@@ -372,7 +390,7 @@ unique_ptr<GlobalSinkState> PhysicalGGEdgeSink::GetGlobalSinkState(ClientContext
 			GGGraph::Check(gg_staging_clear(graph->Part(p).ctx), "gg_staging_clear");
 		}
 	}
-	return make_unique<GGSinkGlobalState>();
+	gstate.prepared.store(true, std::memory_order_release);
 }
 
 unique_ptr<LocalSinkState> PhysicalGGEdgeSink::GetLocalSinkState(ExecutionContext &context) const {
@@ -383,6 +401,7 @@ SinkResultType PhysicalGGEdgeSink::Sink(ExecutionContext &context, GlobalSinkSta
                                         DataChunk &input) const {
 	auto &gstate = (GGSinkGlobalState &)gstate_p;
 	auto &lstate = (GGSinkLocalState &)lstate_p;
+	PrepareStaging(gstate_p);
 	const bool has_rowid = input.ColumnCount() >= 3;
 	idx_t n = has_rowid ? GGKeyColumns(input, {0, 1, 2}, lstate.columns, lstate.keys)
 	                    : GGKeyColumns(input, {0, 1}, lstate.columns, lstate.keys);
@@ -415,6 +434,7 @@ void PhysicalGGEdgeSink::Combine(ExecutionContext &context, GlobalSinkState &gst
 SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
                                               GlobalSinkState &gstate) const {
 	// single-threaded, after every Sink/Combine (physical_operator.hpp:145-147): build the index
+	PrepareStaging(gstate); // (an empty table never reached Sink)
 	lock_guard<mutex> guard(graph->lock);
 	if (graph->Parts() > 1) {
 		// every part saw every row; each derives the same vertex numbering (sorted distinct endpoint ids) or staged
@@ -494,10 +514,26 @@ vector<LogicalType> PhysicalGGPathExpand::OutputTypes(int k_max, bool count_only
 
 PhysicalGGPathExpand::PhysicalGGPathExpand(shared_ptr<GGGraph> graph_p, int k_min_p, int k_max_p, bool count_only_p,
                                            vector<int64_t> sources_p, bool all_sources_p,
-                                           idx_t estimated_cardinality)
+                                           idx_t estimated_cardinality, bool rows_only_p)
     : PhysicalOperator(PhysicalOperatorType::INVALID, OutputTypes(k_max_p, count_only_p), estimated_cardinality),
       graph(move(graph_p)), k_min(k_min_p), k_max(k_max_p), count_only(count_only_p), sources(move(sources_p)),
-      all_sources(all_sources_p) {
+      all_sources(all_sources_p), rows_only(rows_only_p && count_only_p) {
+}
+
+//! Row counts per walk length from degrees (gg_khop_count) in the shape the counting expansion reports them:
+//! digests 0, traversed edges = the rows of every length up to k_max (one adjacency entry per row).
+static void CountRowsFromDegrees(gg_ctx *ctx, const gg_csr *csr, const vector<int64_t> &sources, bool all_sources,
+                                 int k_min, int k_max, gg_khop_stats &stats) {
+	memset(&stats, 0, sizeof(stats));
+	uint64_t rows[GG_MAX_HOPS + 1];
+	GGGraph::Check(gg_khop_count(ctx, csr, all_sources ? nullptr : sources.data(), sources.size(), 1, k_max, rows),
+	               "gg_khop_count");
+	for (int h = 1; h <= k_max; h++) {
+		stats.traversed_edges += rows[h];
+		if (h >= k_min) {
+			stats.rows[h] = rows[h];
+		}
+	}
 }
 
 //! Device-memory budget for one materialised part (GG_RESULT_BUDGET_MB; default 16 GiB of the 288).
@@ -546,6 +582,10 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 			if (!part.csr) {
 				throw InternalException("GG_PATH_COUNT scheduled before the CSR shards were built");
 			}
+			if (rows_only) {
+				CountRowsFromDegrees(part.ctx, part.csr, sources, true, k_min, k_max, per_part[p]);
+				return;
+			}
 			GGGraph::Check(gg_expand_khop(part.ctx, part.csr, nullptr, 0, k_min, k_max, 0, &per_part[p], nullptr),
 			               "gg_expand_khop");
 		});
@@ -559,6 +599,12 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 			state->stats.traversed_edges += stats.traversed_edges;
 			state->stats.frontier_entries += stats.frontier_entries;
 		}
+		state->hop = k_min;
+		return move(state);
+	}
+	if (rows_only) {
+		// count(*) over the join chain: the answer is a sum of degree products, no walk is formed
+		CountRowsFromDegrees(graph->ctx, graph->csr, sources, all_sources, k_min, k_max, state->stats);
 		state->hop = k_min;
 		return move(state);
 	}

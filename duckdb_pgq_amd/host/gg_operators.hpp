@@ -137,6 +137,9 @@ public:
 	bool derive_vertices;
 	bool keep_vertices;
 	bool build;
+	//! Clears what this sink's options say must leave the staging area before its rows go in; runs once, when the
+	//! sink runs (first Sink call or Finalize), never at schedule time.
+	void PrepareStaging(GlobalSinkState &gstate) const;
 
 public:
 	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
@@ -162,8 +165,11 @@ public:
 //! traversed_edges BIGINT), one row per length.
 class PhysicalGGPathExpand : public PhysicalOperator {
 public:
+	//! rows_only (with count_only): the row counts come from degrees (gg_khop_count) — what `count(*)` over the join
+	//! chain needs; the digest column is 0 and no walk is formed.  Without it the counting expansion runs and the
+	//! digest of every walk comes with the count (the gg_path_count table function, parity tests, the benchmark).
 	PhysicalGGPathExpand(shared_ptr<GGGraph> graph, int k_min, int k_max, bool count_only, vector<int64_t> sources,
-	                     bool all_sources, idx_t estimated_cardinality);
+	                     bool all_sources, idx_t estimated_cardinality, bool rows_only = false);
 
 	static vector<LogicalType> OutputTypes(int k_max, bool count_only);
 	//! expand the current part of a result that is produced part by part (see GetGlobalSourceState)
@@ -174,6 +180,7 @@ public:
 	bool count_only;
 	vector<int64_t> sources;
 	bool all_sources;
+	bool rows_only;
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;

@@ -931,7 +931,9 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	auto data = make_unique<GGFunctionData>();
 	data->open = [=](ClientContext &context, GGOpened &opened) {
 		opened.graph = GGBuildGraph(context, spec);
-		opened.source = make_unique<PhysicalGGPathExpand>(opened.graph, hops, hops, count_only, sources, all_sources, 0);
+		// (the planner's count(*) needs the number of walks only: degrees, not the counting expansion's checksum)
+		opened.source = make_unique<PhysicalGGPathExpand>(opened.graph, hops, hops, count_only, sources, all_sources, 0,
+		                                                  count_only);
 	};
 	data->description = pattern.edge_table->name + ": " + pattern.edge_table->columns[pattern.src_column].name +
 	                    " -> " + pattern.edge_table->columns[pattern.dst_column].name + "\n" + to_string(hops) +
@@ -949,7 +951,8 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 		return GGMakeGraphScan(
 		    spec, move(types), count_only ? "GG_PATH_COUNT" : "GG_PATH_EXPAND", data->description, !count_only,
 		    [=](ClientContext &, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
-			    return make_unique<PhysicalGGPathExpand>(move(graph), hops, hops, count_only, sources, all_sources, 0);
+			    return make_unique<PhysicalGGPathExpand>(move(graph), hops, hops, count_only, sources, all_sources, 0,
+			                                             count_only);
 		    },
 		    estimated_cardinality);
 	}
@@ -1300,6 +1303,7 @@ unique_ptr<PhysicalOperator> PlanSameNeighbourPaths(LogicalComparisonJoin &op, P
 		sinks[0].options.first = true;
 		sinks[0].options.derive_vertices = true;
 		sinks[0].options.build = false;
+		sinks[0].options.clear_edges_after = true;  // only its endpoints were wanted: the filter CSR is built from the filter table's rows alone
 		sinks[1].rows = filter;
 		sinks[1].options.as_filter = sinks[1].options.derive_vertices = sinks[1].options.keep_vertices = true;
 		sinks[1].options.clear_edges_after = true;  // the path table's rows come back for its own CSR

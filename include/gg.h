@@ -140,7 +140,7 @@ int gg_csr_export(const gg_csr *csr, int64_t *off, int64_t *nbr, int64_t *eid, i
 /* ---- fixed-length path expansion (k-hop MATCH) -------------------------------------------- */
 typedef struct gg_khop_stats {
   uint64_t rows[GG_MAX_HOPS + 1];   /* rows[h] = number of h-hop walks emitted (h in k_min..k_max) */
-  uint64_t digest[GG_MAX_HOPS + 1]; /* digest[h] = sum over those rows of gg row hash mod 2^64 */
+  uint64_t digest[GG_MAX_HOPS + 1]; /* digest[h] = sum over those rows of the LOW 32 BITS of the gg row hash (DESIGN.md "Row digest"), mod 2^32, in a u64 field */
   uint64_t traversed_edges;         /* TE = adjacency entries read over all hops */
   uint64_t frontier_entries;        /* path prefixes whose adjacency list was expanded */
 } gg_khop_stats;
@@ -153,6 +153,15 @@ typedef struct gg_khop_stats {
  *                   columns, and handed back through *out_result. */
 int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min, int k_max,
                    int materialise, gg_khop_stats *stats, gg_result **out_result);
+/* Only the NUMBER of h-hop walks for h in [k_min, k_max] (rows[h]; other entries 0), computed from degrees: with
+ * w_0(v) = how often v is a source and w_h(v) = sum over in-neighbours u of w_{h-1}(u), rows_h = sum_v w_{h-1}(v) *
+ * outdeg(v) — from every vertex two passes over offset arrays for h <= 2, one pull over the reverse rows per further
+ * hop.  This is what `SELECT count(*)` over the join chain asks for: the reference's aggregate above the hash joins
+ * consumes chunk cardinalities, never the rows (src/execution/operator/aggregate/physical_simple_aggregate.cpp, fed by
+ * ScanStructure::NextInnerJoin, src/execution/join_hashtable.cpp:442-476).  Equal to gg_khop_stats.rows of
+ * gg_expand_khop with the same arguments (also on a shard: the walks whose middle vertex is owned); no digest. */
+int gg_khop_count(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min, int k_max,
+                  uint64_t *rows /* GG_MAX_HOPS + 1 entries */);
 /* Same, sources = dense vertex indices [src_lo, src_hi) — the multi-GPU sharding entry point
  * (each rank takes one contiguous range; no data-path collective). */
 int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src_lo, uint64_t src_hi, int k_min, int k_max,
@@ -163,7 +172,7 @@ int gg_khop_partition(gg_ctx *ctx, const gg_csr *csr, int n_parts, uint64_t *bou
 
 /* 2-hop walks (and, if k_min == 1, the 1-hop rows) of ALL sources whose MIDDLE vertex (1-hop rows:
  * destination) has dense index in [mid_lo, mid_hi).  k_max must be 2.  Disjoint ranges partition the
- * result of gg_expand_khop(all sources, k_min..2): counts add, digests add mod 2^64.  This is the
+ * result of gg_expand_khop(all sources, k_min..2): counts add, digests add mod 2^32.  This is the
  * multi-GPU sharding entry point of the 2-hop product kernel (reads each CSR row once per shard). */
 int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, int k_max,
                        gg_khop_stats *stats);

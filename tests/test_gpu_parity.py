@@ -302,6 +302,47 @@ def test_khop_source_list(gg, orc):
     g.close()
 
 
+@pytest.mark.parametrize("V,E,seed,dangling,dup", CASES[1:] + [(64, 6000, 41, 0, 200)])
+def test_walk_counts_from_degrees_equal_the_counting_expansion(gg, orc, V, E, seed, dangling, dup):
+    """gg_khop_count (what the planner's count(*) asks for: sums of degree products, no walk formed) against the rows
+    of the counting expansion and of the oracle — every vertex as source, source lists with repeats and strangers,
+    k up to 4, and ownership shards (the walks whose middle vertex is owned)."""
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    small = lambda k: E * (max(E, 1) / max(V, 1)) ** (k - 1) <= 2e8  # noqa: E731  (the oracle enumerates the walks)
+    for k_min, k_max in [(1, 1), (1, 2), (2, 2), (1, 3), (3, 3), (2, 4)]:
+        if not small(k_max):
+            continue
+        ref = g.khop(k_min, k_max)
+        got = gg.khop_count(csr, k_min, k_max)
+        assert got[k_min:k_max + 1] == ref["rows"][k_min:k_max + 1], (k_min, k_max)
+        assert got[:k_min] == [0] * k_min and got[k_max + 1:] == [0] * (8 - k_max)
+        if k_max <= 3:
+            assert got == gg.expand_khop(csr, k_min, k_max)["rows"]
+    sources = np.concatenate([vid[: max(1, V // 3)], vid[:2], np.array([-5, 123456789], np.int64)])
+    dense = g.lookup(sources)
+    dense = dense[dense >= 0].astype(np.uint32)
+    for k_min, k_max in [(1, 1), (1, 2), (2, 3), (4, 4)]:
+        if not small(k_max):
+            continue
+        ref = g.khop(k_min, k_max, sources_dense=dense)
+        assert gg.khop_count(csr, k_min, k_max, sources=sources)[k_min:k_max + 1] == ref["rows"][k_min:k_max + 1]
+    assert gg.khop_count(csr, 1, 3, sources=np.zeros(0, np.int64)) == [0] * 9
+    assert gg.khop_count(csr, 1, 3, sources=np.array([-3], np.int64)) == [0] * 9
+    csr.close()
+    whole = g.khop(1, 2)["rows"]
+    for parts in (2, 5):
+        acc = [0] * 9
+        for part in range(parts):
+            sh = gg.build_csr_shard(part, parts)
+            got = gg.khop_count(sh, 1, 2)
+            assert got == gg.expand_khop(sh, 1, 2)["rows"]
+            acc = [a + b for a, b in zip(acc, got)]
+            sh.close()
+        assert acc == whole
+    g.close()
+
+
 def test_khop_ranges_partition_the_result(gg, orc):
     """Sharding entry point: per-range counts/digests add up to the whole (what the multi-GPU path sums)."""
     vid, src, dst = datagen.ldbc_knows(5000, 200_000, 17)
