@@ -1,33 +1,46 @@
 #!/usr/bin/env python3
 """bench.py — traversed edges/sec on LDBC SNB 2-hop MATCH (Person-KNOWS*1..2-Person), MI355X.
 
-One "step" = one pass of the hot path over the synthetic LDBC-shaped tables already resident in HBM:
-    gg_csr_build (densify ids, bucket partition, sub-bucket sort, rows: forward + reverse CSR)  +
-    gg_expand_khop_range(1..2)
-i.e. what the reference does per query as hash-join build + probe chain.  With N > 1 ranks the
-vertices are hash-partitioned (owner = hash(person id) mod N) and so is the edge table: a rank holds the
-`knows` rows whose source or destination it owns (every row on at most two ranks; the 3.6 MB person
-table is replicated), builds only the CSR rows of the vertices it owns (gg_csr_build_shard) and produces
-the walks whose middle vertex it owns; there is no data-path collective, only one small all-reduce of
-(rows, digest, TE) per step, so `value` = total traversed edges of the whole query / max-over-ranks
-time ("strong" scaling: the query is fixed, ranks split it).  The K timed steps are K builds, K expansions and K
-all-reduces inside the timed region; with N > 1 the host launches step i + 1's build before it combines step i's
-counts, so the collective runs beside the build's queued kernels (run_steps).
+Two timed regions over the synthetic LDBC-shaped tables already resident in HBM, both build-inclusive:
+
+  A  count + checksum (the bench line's `value`, as in every earlier round).  One step = gg_csr_build (densify ids,
+     bucket partition, vertex sort, rows: forward + reverse CSR) + the counting 2-hop expansion: what the reference
+     does for `SELECT count(*)` over the join chain as hash-join build + probe.  The expansion kernel reads each CSR
+     row once and folds a 32-bit checksum per walk: it is bound by vector-ALU issue, NOT by HBM, and carries no HBM
+     fraction (config.workload says so).
+  B  rows materialised (`match_materialised`, the roofline-bearing region).  One step = gg_csr_build + EVERY 2-hop row
+     (person, friend, friend of friend) written to HBM as three int64 id columns, in middle-vertex parts of at most
+     --mat-budget-gb (12.8 G rows x 24 B = 306 GB do not fit 288 GB at once; the substituted hash join streams its
+     result the same way, host/gg_operators.cpp): what the reference's probe side does when the MATCH returns rows
+     (ScanStructure::NextInnerJoin / GatherResult, src/execution/join_hashtable.cpp:442-476).  Dominant kernel
+     k_mat_mid2, HBM-bound: bytes written / its time / 8 TB/s.  The top-level `roofline` is the kernel with the
+     largest total time over BOTH regions — k_mat_mid2 — with HBM traffic from counter passes made in this run.
+
+With N > 1 ranks the vertices are hash-partitioned (owner = hash(person id) mod N) and so is the edge table: a rank
+holds the `knows` rows whose source or destination it owns (every row on at most two ranks; the 3.6 MB person table is
+replicated), builds only the CSR rows of the vertices it owns (gg_csr_build_shard) and produces — counts in A, writes
+in B — the walks whose middle vertex it owns; no data-path collective.  Region A's per-step result is six words left
+on the device (gg_expand_khop_dev), all-reduced in place and copied to the host once (sharding.combine_dev); the
+host launches step i + 1's build before it waits for step i's words.  `value` = traversed edges of the whole query /
+max-over-ranks time ("strong" scaling: the query is fixed, ranks split it).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sf100|sf10|sf1] [--no-cpu] [--no-extras]
+                    [--mat-steps M] [--mat-budget-gb G] [--no-pmc]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement):
-  roofline           the kernel with the largest total time in the timed region.  HBM-bound kernels (the CSR
-                     build): algorithmic bytes per launch / average launch time / 8 TB/s.  The 2-hop
-                     product kernel moves 0.6 GB for 12.8 G walks and is bound by vector-ALU issue, so its record is
-                     {"bound": "valu"}: one v_xad_u32 per walk against the measured issue rate of that instruction
-                     (scripts/ubench_valu.hip).  No record ever divides bytes that are not moved by the HBM peak.
-  roofline_kernels   the same record for every kernel of the step that is charged algorithmic work
-  roofline_phases    csr_build (all build kernels, HBM) and expand (VALU)
+  roofline           the kernel with the largest total time over the timed regions (k_mat_mid2, region B): bytes it
+                     writes per launch / average launch time / 8 TB/s; `traffic` = 2 x FETCH_SIZE + WRITE_SIZE per
+                     launch from two rocprofv3 --pmc passes of this same program run as a child process in this run
+                     (--pmc-child; counter rules: profiles/r04_counter_calibration.txt)
+  match_materialised region B: TE/s for the same traversed edges, rows/s, bytes/s, parity (device-side digest over
+                     all rows of every part, untimed pass), its kernels and the build phase's HBM record
+  roofline_count_step / roofline_kernels / roofline_phases   region A: the densification (HBM), the build phase (HBM),
+                     the counting expansion (VALU issue: one v_xad_u32 per walk)
   cpu_baseline       the compiled reference (oracle/_ref/libduckdb.so; else the C oracle) on this box's host cores,
                      benchmark_runner protocol (1 cold + 5 hot runs, median hot: benchmark/benchmark_runner.cpp:132-147)
-                     on a bounded sample, plus a threads=1 figure and the CPU model
+                     on a bounded sample, plus a threads=1 figure, the CPU model, and the one full run committed as
+                     profiles/r04_cpu_full_sf100.json
   materialised, bfs64, connectedsegments   the other BASELINE.json configs on this GPU, each with its own parity
                      boolean (N = 1 only; --no-extras skips them)
 """
@@ -225,6 +238,17 @@ def cpu_baseline(vid, src, dst, V, want_seconds=6.0, with_reference=True):
                                 f"run, 1 cold + 2 hot runs (the hash-table builds over all knows rows dominate a run)",
                       "counts_match_oracle": bool(d1 == q1 and d2 == q2)},
     }
+    try:  # the one full run of the whole workload on the reference (scripts/cpu_full_sf100.py, committed output)
+        full = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_full_sf100.json")))
+        if full.get("traversed_edges") == te_full:
+            out["cpu_baseline"]["full_workload_measured"] = {
+                "value": full["value"], "unit": full["unit"], "seconds": full["seconds_1hop_plus_2hop"],
+                "threads": full["threads"], "cpu_model": full["cpu_model"], "counts_match_oracle": full["counts_match_oracle"],
+                "source": "profiles/r04_cpu_full_sf100.json: count(*) of the 1-hop and 2-hop chains over ALL knows rows, run once "
+                          "on a box of this pool in round 4 (not in this run); the sample above extrapolates low because the "
+                          "probe rate grows with the sample"}
+    except Exception:
+        pass
     out["cpu_port"] = port
     return out
 
@@ -318,8 +342,12 @@ def extra_materialised(pkg, orc, device):
     gg.profile_reset()
     gg.profile_select(None)
     gg.profile(True)
+    import torch
+
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = gg.expand_khop_result(csr, 2)
+    torch.cuda.synchronize()  # (the materialising kernel is launched asynchronously: wait for it before stopping the clock)
     dt = time.perf_counter() - t0
     gg.profile(False)
     prof = gg.profile_get()
@@ -334,13 +362,10 @@ def extra_materialised(pkg, orc, device):
     if k[0]:
         out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": written / (k[1] * 1e-3) / 1e9,
                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": written / (k[1] * 1e-3) / HBM_PEAK,
-                           "traffic": _pmc_traffic("sf10/mat_mid2/n1") if kname == "mat_mid2" else None,
-                           "avg_launch_ms": k[1] / k[0],
-                           "note": "bytes actually written by the kernel (rows x 3 x 8) over its time",
-                           "traffic_note": "2*FETCH_SIZE + WRITE_SIZE of an earlier counter run (profiles/pmc_traffic.json); "
-                                           "WRITE_SIZE tallies this kernel's nontemporal 16-byte stores at half their "
-                                           "bytes (12.8 GB counted, 25.5 GB written by construction and read back by "
-                                           "the digest): the kernel fetches 0.04 GB and writes each row once"}
+                           "traffic": None, "avg_launch_ms": k[1] / k[0],
+                           "note": "bytes actually written by the kernel (rows x 3 x 8) over its time; counters for this kernel: "
+                                   "the SF100 parts of match_materialised (same kernel) and profiles/r04_counter_calibration.txt "
+                                   "(WRITE_SIZE of the SF10 launch = 25.52 GB for 25.51 GB of rows)"}
     # parity over ALL rows: the digest of what was written (gg_result_digest maps every id of every row back to its
     # dense index and sums the row hashes) against the count-mode expansion's and the oracle's digest of the same walks
     rc, g = orc.csr_build(vid, src, dst)
@@ -358,48 +383,125 @@ def extra_materialised(pkg, orc, device):
     return out
 
 
-def extra_materialised_parts(gg, csr, counted, budget_gb=16.0):
-    """SF100 2-hop MATCH with the rows written to HBM: 12.8 G rows x 3 int64 columns = 306 GB do not fit 288 GB, so
-    the result is produced part by part — middle-vertex ranges of near-equal work (gg_khop_partition_mid), each
-    through the product kernel (gg_expand_khop_mid_result), handed over and freed — the way the substituted join
-    streams it (host/gg_operators.cpp).  Timed: expansion calls only (count + materialise per part); the digest of
-    every part's rows (gg_result_digest, all rows, device-side) is taken outside the timed region and must add up to
-    the count-mode expansion's."""
-    total_rows = counted["rows"][2]
-    n_parts = max(1, int(np.ceil(total_rows * 24 / (budget_gb * 2**30))))
-    bounds = gg.khop_partition_mid(csr, n_parts)
-    gg.profile_reset()
-    gg.profile_select(["mat_mid2"])
-    gg.profile(True)
-    rows = dig = 0
-    t_total = 0.0
-    import torch
+MAT_KERNELS = ["mat_mid2", "mat_mid2_prepare", "mat_tile_entries"]
 
+
+def match_step(gg, build, budget_bytes, verify=False):
+    """One step of region B on this rank: build, then every 2-hop row whose middle vertex this rank owns (all of them
+    at N = 1) written to HBM as three int64 id columns, part by part under the device-memory budget.  The number of
+    rows comes from degrees (gg_khop_count) and sizes the parts; parts are middle-vertex ranges of near-equal work
+    (gg_khop_partition_mid), each produced by gg_expand_khop_mid_result, handed over and freed.  verify: every part's
+    rows are digested on the device (gg_result_digest maps every id of every row back to its dense index and sums the
+    row hashes) — the untimed parity pass."""
+    c = build()
+    total = gg.khop_count(c, 2, 2)[2]
+    n_parts = max(1, int(-(-total * 24 // budget_bytes)))
+    bounds = gg.khop_partition_mid(c, n_parts) if n_parts > 1 else [0, c.V]
+    rows = dig = 0
     for lo, hi in zip(bounds[:-1], bounds[1:]):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = gg.expand_khop_mid_result(csr, lo, hi, k_min=2)
-        torch.cuda.synchronize()  # (the materialising kernel is launched asynchronously)
-        t_total += time.perf_counter() - t0
-        n, d = res.digest(csr, 2)
-        rows += n
-        dig = (dig + d) & 0xFFFFFFFF
+        res = gg.expand_khop_mid_result(c, lo, hi, k_min=2)
+        if verify:
+            n, d = res.digest(c, 2)
+            assert n == res.rows(2)
+            dig = (dig + d) & 0xFFFFFFFF
+        rows += res.rows(2)
         res.close()
-    gg.profile(False)
-    prof = gg.profile_get()
-    k = prof.get("mat_mid2", (0, 0.0))
-    out = {"workload": "LDBC SNB SF100 Person-KNOWS-Person-KNOWS-Person, all persons as sources, rows materialised in HBM "
-                       f"in {n_parts} middle-vertex parts of <= {budget_gb:.0f} GiB (3 int64 id columns each)",
-           "parts": n_parts, "rows": rows, "bytes_written": rows * 24, "wall_s": t_total,
-           "rows_per_s": rows / t_total, "bytes_per_s": rows * 24 / t_total,
-           "parity": bool(rows == total_rows and dig == counted["digest"][2]),
-           "parity_note": "sum over the parts of rows and of the device-side digests of all materialised rows == count-mode expansion"}
-    if k[0]:
-        out["roofline"] = {"bound": "hbm", "kernel": "mat_mid2", "achieved": rows * 24 / (k[1] * 1e-3) / 1e9,
-                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": rows * 24 / (k[1] * 1e-3) / HBM_PEAK,
-                           "traffic": None, "avg_launch_ms": k[1] / k[0], "launches": k[0],
-                           "note": "bytes written by the kernel (rows x 3 x 8) over its time, all parts"}
-    return out
+    c.close()
+    return rows, dig, n_parts
+
+
+def _kernel_short_name(full):
+    """'void gg::k_densify_pairs<false>(long const*, ...)' -> 'k_densify_pairs'; '(anonymous namespace)::k_mat_mid2(...)'
+    -> 'k_mat_mid2'."""
+    name = full.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    name = name.split("(")[0].split("<")[0]
+    return name.split("::")[-1].strip()
+
+
+def _pmc_child(args):
+    """--pmc-child: the program the counter passes profile — one GPU, the same tables, one warm-up and one counted step
+    of region A and of region B, nothing printed but a marker.  Run as `rocprofv3 --pmc X --kernel-trace -- python3
+    bench.py --pmc-child` by measure_pmc_traffic; the counters of every dispatch land in the pass's CSV."""
+    import duckdb_pgq_amd as pkg
+
+    vid, src, dst = pkg.datagen.ldbc(args.workload)
+    gg = pkg.GG(0)
+    gg.set_edge_rowid(False)
+    gg.chunk_rows = 122_880
+    gg.append_vertices(vid)
+    gg.append_edges(src, dst)
+    gg.staging_sync()
+    budget = int(args.mat_budget_gb * 2**30)
+    for _ in range(2):
+        c = gg.build_csr()
+        gg.expand_khop(c, 1, 2)
+        c.close()
+        match_step(gg, gg.build_csr, budget)
+    gg.close()
+    print("pmc-child done", flush=True)
+
+
+def measure_pmc_traffic(args, timeout_s=300):
+    """HBM-side bytes per kernel launch, measured in THIS run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE — they do
+    not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots") over `python3 bench.py --pmc-child` as a child
+    process.  Units and corrections as calibrated in profiles/r04_counter_calibration.txt on known byte counts: both
+    counters are in KiB; WRITE_SIZE is exact for the store forms used here, FETCH_SIZE reports half of the bytes read.
+    Returns {kernel: {"launches", "fetch_bytes", "write_bytes", "traffic"}} with per-launch averages, or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {"error": "rocprofv3 not on PATH"}
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return {"error": "already running under a profiler"}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="gg_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", "python3",
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload,
+                   "--mat-budget-gb", str(args.mat_budget_gb)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                    text=True, start_new_session=True)
+            try:
+                text, _ = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)  # (the process group this call started, nothing else)
+                proc.wait()
+                return {"error": f"{counter} pass timed out after {timeout_s}s"}
+            if proc.returncode != 0 or "pmc-child done" not in text:
+                return {"error": f"{counter} pass failed (rc {proc.returncode}): {text[-300:]}"}
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return {"error": f"{counter} pass wrote no counter file"}
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    name = _kernel_short_name(r["Kernel_Name"])
+                    rec = out.setdefault(name, {"launches": {}, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+                    rec[counter] += float(r["Counter_Value"]) * 1024.0
+                    rec["launches"][counter] = rec["launches"].get(counter, 0) + 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for name, rec in out.items():
+        n = max(rec["launches"].values()) if rec["launches"] else 0
+        if not n:
+            continue
+        fetch = 2.0 * rec["FETCH_SIZE"] / max(rec["launches"].get("FETCH_SIZE", n), 1)
+        write = rec["WRITE_SIZE"] / max(rec["launches"].get("WRITE_SIZE", n), 1)
+        res[name] = {"launches": n, "fetch_bytes": fetch, "write_bytes": write, "traffic": fetch + write}
+    return res
 
 
 def extra_connectedsegments(pkg, device, copies=1024, steps=10):
@@ -457,7 +559,14 @@ def main():
     ap.add_argument("--legacy-build", action="store_true", help="diagnostic: the multi-pass LSD build")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="diagnostic: time rank 0's share of an N-rank run on one GPU (output is not a bench line)")
+    ap.add_argument("--mat-steps", type=int, default=5, help="timed steps of region B (build + rows materialised in HBM)")
+    ap.add_argument("--mat-budget-gb", type=float, default=40.0,
+                    help="device-memory budget of one materialised part (GiB; the operators' GG_RESULT_BUDGET_MB default)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic from profiles/)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return _pmc_child(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -528,18 +637,26 @@ def main():
         return gg.build_csr_shard(rank, world) if world > 1 else gg.build_csr()
 
     def run_steps(n):
-        """n complete steps — build, expansion, combine of the ranks' results — with the host side pipelined by one
-        step when there are several ranks: the NEXT step's build is launched (gg_csr_build returns once its status is
-        known, two thirds of its kernels still queued) before the ranks' counts of THIS step are all-reduced, so the
-        collective and its host round trips run beside those kernels instead of in front of them.  Every step's
-        build, expansion and combine lie inside the caller's timed region; no CSR is built that is not expanded."""
+        """n complete steps of region A — build, counting expansion, combine of the ranks' results.  With a process
+        group the expansion leaves its six result words on the device (gg_expand_khop_dev: no host synchronisation),
+        the NEXT step's build is launched (gg_csr_build returns once its status is known, two thirds of its kernels
+        still queued), and only then are the words all-reduced in place and copied to the host once
+        (sharding.combine_dev) — the collective and its one round trip run beside the build's queued kernels.  Every
+        step's build, expansion and combine lie inside the caller's timed region; no CSR is built that is not
+        expanded."""
         vec = st = None
         c = build()
         for i in range(n):
-            st = gg.expand_khop(c, 1, 2)
-            c.close()
-            c = build() if i + 1 < n else None
-            vec = sharding.combine(sharding.stats_to_vec(st), dist, device="cuda")
+            if dist is None:
+                st = gg.expand_khop(c, 1, 2)
+                c.close()
+                c = build() if i + 1 < n else None
+                vec = sharding.stats_to_vec(st)
+            else:
+                words = gg.expand_khop_dev(c, 1)
+                c.close()  # (blocks go back to the pool in stream order; the queued expansion still reads them first)
+                c = build() if i + 1 < n else None
+                vec = sharding.combine_dev(gg, words, dist)
         return vec, st
 
     def step():
@@ -580,6 +697,46 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- region B: build + every 2-hop row written to HBM (this rank: the rows whose middle vertex it owns) ------------
+    budget = int(args.mat_budget_gb * 2**30)
+    mat = None
+    if args.mat_steps > 0 and not args.legacy_build:
+        match_step(gg, build, budget)  # warm-up: the pool takes the parts' blocks
+        gg.profile_reset()
+        gg.profile_select(BUILD_KERNELS + MAT_KERNELS)
+        gg.profile(True)
+        step_rows = []
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.mat_steps):
+            rows_l, _, n_parts_l = match_step(gg, build, budget)
+            rt = torch.tensor([rows_l], dtype=torch.int64, device="cuda")
+            if dist is not None:
+                dist.all_reduce(rt)  # the query's row count, once per step (the rows themselves stay sharded in HBM)
+            step_rows.append(rt)
+        torch.cuda.synchronize()
+        barrier()
+        mat_elapsed = time.perf_counter() - t0
+        gg.profile(False)
+        mat_prof = gg.profile_get()
+        if dist is not None:
+            tmax = torch.tensor([mat_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            mat_elapsed = float(tmax.item())
+        # untimed parity pass: every part's rows digested on the device, summed over parts and ranks
+        v_rows, v_dig, _ = match_step(gg, build, budget, verify=True)
+        vt = torch.tensor([v_rows, v_dig], dtype=torch.int64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(vt)
+        v_rows, v_dig = int(vt[0].item()), int(vt[1].item()) & 0xFFFFFFFF
+        mat = {"elapsed": mat_elapsed, "prof": mat_prof, "rows_local": rows_l, "parts_local": n_parts_l,
+               "rows_steps": [int(t.item()) for t in step_rows], "verify_rows": v_rows, "verify_digest": v_dig}
+
+    if st_local is None:  # (device-side combine: the rank's own counts never came to the host inside the timed region)
+        c = build()
+        st_local = gg.expand_khop(c, 1, 2)
+        c.close()
     rows1, rows2, dig1, dig2, te_total, fr_total = tot
     ms_per_step = elapsed / args.steps * 1e3
     value = te_total * args.steps / elapsed
@@ -654,11 +811,64 @@ def main():
     kernels.update({k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
                         "us_per_step": v[1] * 1e3 / args.steps, "timed_region": True} for k, v in prof.items()})
 
+    # ---- region B's records ------------------------------------------------------------------------------------------
+    match = None
+    if mat is not None:
+        m_ms = mat["elapsed"] / args.mat_steps * 1e3
+        k_l, k_ms = mat["prof"].get("mat_mid2", (0, 0.0))
+        rows_l = mat["rows_local"]
+        m_kernels = {k: {"launches": v[0], "avg_us": (v[1] / v[0] * 1e3 if v[0] else 0.0),
+                         "us_per_step": v[1] * 1e3 / args.mat_steps} for k, v in mat["prof"].items()}
+        mb_ms = sum(v[1] for k, v in mat["prof"].items() if k in BUILD_KERNELS) / args.mat_steps
+        match = {
+            "workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS-Person-KNOWS-Person, all persons as sources: CSR build "
+                        f"+ every 2-hop row written to HBM as 3 int64 id columns, in middle-vertex parts of <= "
+                        f"{args.mat_budget_gb:g} GiB (gg_expand_khop_mid_result; rows beyond HBM's size stream through, "
+                        "as through the hash join they replace)",
+            "steps": args.mat_steps, "ms_per_step": m_ms, "parts_per_step_this_rank": mat["parts_local"],
+            "rows": mat["rows_steps"][-1], "rows_this_rank": rows_l,
+            "value": te_total * args.mat_steps / mat["elapsed"], "unit": "traversed edges/s",
+            "rows_per_s": mat["rows_steps"][-1] * args.mat_steps / mat["elapsed"],
+            "bytes_written_per_s": mat["rows_steps"][-1] * 24 * args.mat_steps / mat["elapsed"],
+            "kernels": m_kernels,
+            "parity": bool(all(r == rows2 for r in mat["rows_steps"]) and mat["verify_rows"] == rows2 and
+                           mat["verify_digest"] == dig2),
+            "parity_note": "rows of every timed step, and rows + device-side digest over ALL materialised rows of an untimed "
+                           "pass (gg_result_digest per part, summed over parts and ranks), == the counting expansion of "
+                           "region A (which parity_vs_oracle compares with the CPU oracle)",
+        }
+        if k_l:
+            avg_s = k_ms / k_l * 1e-3
+            bytes_per_launch = rows_l * 24 * args.mat_steps / k_l
+            match["roofline"] = {
+                "bound": "hbm", "kernel": "mat_mid2", "timed_region": "match_materialised",
+                "achieved": bytes_per_launch / avg_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": bytes_per_launch / avg_s / HBM_PEAK, "traffic": None, "avg_launch_ms": avg_s * 1e3,
+                "launches_per_step": k_l / args.mat_steps, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "kernel_share_of_step": k_ms / args.mat_steps / m_ms,
+                "note": "algorithmic bytes = rows x 3 columns x 8 B written (SURVEY 8d's 8(k+1) per materialised row; its "
+                        "8 B per traversed edge of the counting form are NOT charged: the product kernel reads each CSR row "
+                        "once per tile, the counters put that at well under 1 % of the writes)"}
+        if mb_ms > 0:
+            alg_b = (32 * R_local + 8 * V) + (32 * R_local + 16 * V)
+            match["build_phase"] = {"bound": "hbm", "kernel_ms": mb_ms, "algorithmic_bytes": alg_b,
+                                    "achieved": alg_b / (mb_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                    "frac": alg_b / (mb_ms * 1e-3) / HBM_PEAK,
+                                    "note": "the four large build kernels timed inside region B (the small ones are in `kernels` of region A)"}
+
     if args.shard_of > 1:
-        log(f"shard 0 of {args.shard_of}: {ms_per_step:.3f} ms/step; kernels us/step:",
+        log(f"shard 0 of {args.shard_of}: count step {ms_per_step:.3f} ms; kernels us/step:",
             {k: round(v["us_per_step"]) for k, v in kernels.items()})
-        print(json.dumps({"diagnostic": f"shard 0 of {args.shard_of}", "ms_per_step": ms_per_step,
-                          "kernels_us_per_step": {k: v["us_per_step"] for k, v in kernels.items()}}), flush=True)
+        diag = {"diagnostic": f"shard 0 of {args.shard_of}", "ms_per_step": ms_per_step,
+                "kernels_us_per_step": {k: v["us_per_step"] for k, v in kernels.items()}}
+        if match is not None:
+            log(f"shard 0 of {args.shard_of}: materialised step {match['ms_per_step']:.3f} ms, rows {match['rows_this_rank']}")
+            diag["match_materialised"] = {"ms_per_step": match["ms_per_step"], "rows_this_rank": match["rows_this_rank"],
+                                          "parts": match["parts_per_step_this_rank"],
+                                          "kernels_us_per_step": {k: v["us_per_step"] for k, v in match["kernels"].items()},
+                                          "roofline_frac": match.get("roofline", {}).get("frac"),
+                                          "rows_digest_of_this_shard": [mat["verify_rows"], mat["verify_digest"]]}
+        print(json.dumps(diag), flush=True)
         gg.close()
         return
     if rank == 0:
@@ -678,7 +888,6 @@ def main():
                 if args.workload == "sf100":
                     c = gg.build_csr()
                     extra["bfs64"] = extra_bfs64(pkg, gg, c, vid, oracle_graph)
-                    extra["materialised_sf100_parts"] = extra_materialised_parts(gg, c, gg.expand_khop(c, 2, 2))
                     c.close()
                 if oracle_graph is not None:
                     oracle_graph.close()
@@ -691,6 +900,43 @@ def main():
                 extra["extras_error"] = repr(e)
         if oracle_graph is not None:
             oracle_graph.close()
+        # ---- HBM traffic from counters, measured now: the same program as a child under rocprofv3 --pmc --------------
+        pmc = None
+        if world == 1 and not args.no_pmc and "extras_error" not in extra:
+            gg.close()  # (the child needs the device memory; nothing below uses this context)
+            t0 = time.perf_counter()
+            pmc = measure_pmc_traffic(args)
+            log(f"counter passes: {time.perf_counter() - t0:.1f}s", pmc.get("error", "ok"))
+        pmc_src = "2 x FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 --pmc passes of `bench.py --pmc-child` made in this run"
+        stale_src = "profiles/pmc_traffic.json (counter passes of an earlier run, NOT of this one)"
+
+        def with_traffic(rec, kernel, stale_key):
+            if rec is None:
+                return rec
+            if pmc and kernel in pmc:
+                rec["traffic"] = int(pmc[kernel]["traffic"])
+                rec["traffic_detail"] = {k: int(v) for k, v in pmc[kernel].items()}
+                rec["traffic_source"] = pmc_src
+            else:
+                rec["traffic"] = traffic_tab.get(stale_key)
+                rec["traffic_source"] = stale_src if rec["traffic"] else None
+                if pmc and "error" in pmc:
+                    rec["traffic_error"] = pmc["error"]
+            return rec
+
+        short = {"densify_pairs": "k_densify_pairs", "partition_dual": "k_partition_dual", "sub_sort": "k_vsort_pipe",
+                 "leaf_rows": "k_vrows", "expand_mid2": "k_expand_mid2"}
+        for name, rec in recs.items():
+            with_traffic(rec, short.get(name, name), f"{args.workload}/{name}/n{world}")
+        if match is not None and "roofline" in match:
+            with_traffic(match["roofline"], "k_mat_mid2", f"{args.workload}/mat_mid2/n{world}")
+        # the bench line's roofline: the kernel with the largest total time over both timed regions
+        top = roof
+        if match is not None and "roofline" in match:
+            t_a = prof.get(dom, (0, 0.0))[1] if dom else 0.0
+            t_b = mat["prof"].get("mat_mid2", (0, 0.0))[1]
+            if t_b >= t_a:
+                top = match["roofline"]
         line = {
             "metric": "traversed edges/sec on LDBC SNB 2-hop MATCH",
             "value": value,
@@ -704,11 +950,16 @@ def main():
             "vs_baseline": None,
             "dtype": "int64 ids / u32 dense indices",
             "data": "synthetic (seeded LDBC-shaped person/knows, duckdb_pgq_amd/datagen.py)",
-            "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build (no edge-rowid payload) + 2-hop expansion (count + digest)",
+            "config": {"workload": f"LDBC SNB {args.workload.upper()} Person-KNOWS*1..2-Person, all persons as sources: CSR build (no edge-rowid "
+                                   "payload) + counting 2-hop expansion (row count + 32-bit checksum per walk: a VALU checksum, "
+                                   "not an HBM figure — the HBM-shaped form of the same MATCH, rows materialised, is "
+                                   "`match_materialised`, which `roofline` describes)",
                        "vertices": int(V), "knows_rows": int(R), "rows_1hop": int(rows1), "rows_2hop": int(rows2),
                        "traversed_edges": int(te_total),
                        "collective_backend": dist.get_backend() if dist is not None else None, "parallelism": f"vertex-ownership shards x{world} (edge table hash-partitioned by endpoint owner, vertex table replicated, CSR + expansion sharded, no data-path collective)"},
-            "roofline": roof,
+            "roofline": top,
+            "match_materialised": match,
+            "roofline_count_step": roof,
             "roofline_kernels": recs,
             "roofline_phases": phases,
             "kernels": kernels,
@@ -718,7 +969,8 @@ def main():
         if "cpu_baseline" not in line:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    gg.close()
+    if gg.ctx:
+        gg.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -625,8 +625,9 @@ extern "C" void gg_csr_destroy(gg_csr *csr) {
   if (!csr) return;
   gg_ctx *ctx = csr->ctx;
   if (ctx) {
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    // no synchronisation: the blocks go back to the context's pool, and whatever takes them next is queued on the
+    // same stream behind the kernels that still read them (one stream per context; the pool never hands a block to
+    // another context, and hipFree — the pool's last resort — waits for the device itself)
     ctx->dev_free(csr->off);
     ctx->dev_free(csr->nbr);
     ctx->dev_free(csr->row);

@@ -46,6 +46,7 @@ struct DevBlock {
   bool in_use;
   uint64_t serial;  // allocation number (ApiScope frees what an API call allocated and did not keep)
   bool keep;        // owned by a long-lived object (gg_csr, gg_result)
+  bool reserved = false;  // member of a placed column set (gg_ctx::dev_alloc_columns): only handed out with its set
 };
 
 struct ProfRec {
@@ -196,8 +197,23 @@ struct gg_ctx {
   uint32_t scan_spin_limit = 1u << 24;    // polls per predecessor before a scan tile gives up
   uint64_t scan_mute_tile = ~0ull;        // gg_debug_scan_fault: this scan tile never publishes (tests)
 
+  uint32_t mat_groups = 1;  // k_mat_mid2: places of the result columns the resident workgroups write at (GG_MAT_GROUPS)
+  unsigned long long *stats_dev = nullptr;  // gg_expand_khop_dev: the six result words of the last such call (8 x u64)
+  hipEvent_t xstream_event = nullptr;       // gg_stream_wait
+
   uint64_t next_serial = 1;
   int dev_alloc(void **out, size_t bytes);
+  // Three result columns of col_bytes each that will be written in lockstep (k_mat_mid2).  Small ones share one pooled
+  // block; large ones are three blocks chosen so that they lie in different memory ranks (gg_runtime.hip "Placement"),
+  // kept together as a set and recycled as a set.  cols[0..2] are freed individually with dev_free.
+  int dev_alloc_columns(void **cols, size_t col_bytes);
+  struct PlacedSet {
+    void *col[3];
+    size_t bytes;  // per column
+  };
+  std::vector<PlacedSet> placed_sets;
+  int place_probes = 6;                                        // GG_PLACE_PROBES: candidate blocks per set (<= 3: no probing)
+  uint64_t placed_built = 0, placed_fast_pairs = 0;            // diagnostics: sets built, fast pairs in the last one
   void dev_free(void *p);
   void keep(void *p);  // the block outlives the API call that allocated it
   int prof_begin(const char *name);

@@ -1099,8 +1099,25 @@ int khop_count(gg_ctx *ctx, const gg_csr *csr, bool ident, uint32_t lo, uint64_t
 
 
 // 2-hop count + digest through the product kernel for middle vertices [mid_lo, mid_hi)
-int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, gg_khop_stats *st) {
-  memset(st, 0, sizeof(*st));
+// (rows1, rows2, digest1, digest2, traversed edges, frontier entries) of a counting expansion as six u64 words in
+// device memory — the vector the ranks of a sharded query add up (duckdb_pgq_amd/sharding.py: FIELDS)
+__global__ void k_pack_stats(const unsigned long long *__restrict__ tmp3, unsigned long long M, unsigned long long fe,
+                             int with_one_hop, unsigned long long *__restrict__ out6) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned long long dig1 = tmp3 ? tmp3[0] : 0, dig2 = tmp3 ? tmp3[1] : 0, rows2 = tmp3 ? tmp3[2] : 0;
+    out6[0] = with_one_hop ? M : 0;
+    out6[1] = rows2;
+    out6[2] = with_one_hop ? dig1 : 0;
+    out6[3] = dig2;
+    out6[4] = M + rows2;
+    out6[5] = fe;
+  }
+}
+
+// st == nullptr: nothing comes back to the host and nothing waits — the six words are left in dev_out6
+int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, gg_khop_stats *st,
+                   unsigned long long *dev_out6 = nullptr) {
+  if (st) memset(st, 0, sizeof(*st));
   GG_TRY(ensure_reverse(ctx, csr));
   const uint64_t n_mid = mid_hi - mid_lo;
   uint64_t M = csr->E_rev, fbase = 0;
@@ -1116,6 +1133,23 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
     fbase = ends[0];
   }
   uint64_t rows2 = 0, dig1 = 0, dig2 = 0;
+  const uint64_t frontier_entries = (csr->n_parts > 1 ? csr->owned_vertices : n_mid) + M;
+  if (dev_out6) {  // device-side result: (the pool keeps freed blocks alive in stream order)
+    unsigned long long *partial = nullptr, *tmp = nullptr;
+    if (M) {
+      const uint64_t n_tiles = (M + MT - 1) / MT;
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
+      GG_LAUNCH(ctx, "expand_mid2", k_expand_mid2, dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr, csr->rrow,
+                csr->rnbr, fbase, M, (int)(k_min <= 1), partial, tmp);
+      GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp, true));
+    }
+    hipLaunchKernelGGL(k_pack_stats, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *)tmp,
+                       (unsigned long long)M, (unsigned long long)frontier_entries, (int)(k_min <= 1), dev_out6);
+    ctx->dev_free(tmp);
+    ctx->dev_free(partial);
+    return GG_OK;
+  }
   if (M) {
     const uint64_t n_tiles = (M + MT - 1) / MT;
     unsigned long long *partial = nullptr, *tmp = nullptr;
@@ -1139,7 +1173,7 @@ int khop_count_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, i
   st->rows[2] = rows2;
   st->digest[2] = dig2;
   st->traversed_edges = M + rows2;
-  st->frontier_entries = (csr->n_parts > 1 ? csr->owned_vertices : n_mid) + M;
+  st->frontier_entries = frontier_entries;
   return GG_OK;
 }
 
@@ -1332,15 +1366,21 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
                                                   const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
                                                   const uint32_t *__restrict__ tile_entry, uint64_t e0, uint64_t n,
                                                   uint64_t M2, int64_t *__restrict__ c0, int64_t *__restrict__ c1,
-                                                  int64_t *__restrict__ c2) {
+                                                  int64_t *__restrict__ c2, uint32_t n_tiles, uint32_t groups) {
   __shared__ int64_t s_uid[256 + 1];
   __shared__ int64_t s_oid[MAT_CAP + 1];
   __shared__ uint64_t s_base[256];
   __shared__ uint32_t s_x[256], s_run[257], s_wcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t t_lo = mat_tile_start(blockIdx.x, gridDim.x, M2), t_hi = mat_tile_start(blockIdx.x + 1ull, gridDim.x, M2);
-  const uint64_t e_lo = tile_entry[blockIdx.x];
-  uint64_t e_hi = (uint64_t)tile_entry[blockIdx.x + 1] + 1;  // (that entry holds the next tile's first row, and maybe ours)
+  // groups > 1: workgroup b takes tile (b % groups) * (grid / groups) + b / groups (the grid is padded to a multiple of
+  // `groups`): the workgroups resident at any moment write at `groups` places spread over the whole of every column
+  // instead of moving through the columns as one narrow window of three cursors
+  uint32_t tile = blockIdx.x;
+  if (groups > 1) tile = (blockIdx.x % groups) * (gridDim.x / groups) + blockIdx.x / groups;
+  if (tile >= n_tiles) return;
+  const uint64_t t_lo = mat_tile_start(tile, n_tiles, M2), t_hi = mat_tile_start(tile + 1ull, n_tiles, M2);
+  const uint64_t e_lo = tile_entry[tile];
+  uint64_t e_hi = (uint64_t)tile_entry[tile + 1] + 1;  // (that entry holds the next tile's first row, and maybe ours)
   e_hi = e_hi < n ? e_hi : n;
   for (uint64_t eb = e_lo; eb < e_hi; eb += 256) {  // (everything about the control flow is uniform over the workgroup)
     const uint64_t p = eb + threadIdx.x;
@@ -1418,9 +1458,16 @@ int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mi
   uint64_t M2 = 0;
   GG_TRY(offsets_from_deg(ctx, foff, n, &M2));
   res->rows[2] = M2;
-  for (int c = 0; c <= 2; c++) {
-    GG_TRY(ctx->dev_alloc((void **)&res->cols[2][c], (M2 ? M2 : 1) * sizeof(int64_t)));
-    ctx->keep(res->cols[2][c]);
+  {
+    // the three columns: one pooled block when small; when large, three blocks the pool chose to lie in different
+    // memory ranks — lockstep stores into one rank run at 5.8 TB/s, into two or three at 7.0-7.2 (gg_runtime.hip
+    // "Placement of large result columns")
+    void *cols[3] = {nullptr, nullptr, nullptr};
+    GG_TRY(ctx->dev_alloc_columns(cols, (M2 ? M2 : 1) * sizeof(int64_t)));
+    for (int c = 0; c <= 2; c++) {
+      res->cols[2][c] = reinterpret_cast<int64_t *>(cols[c]);
+      ctx->keep(cols[c]);
+    }
   }
   if (M2) {
     const uint64_t n_tiles = (M2 + MAT_ROWS - 1) / MAT_ROWS;
@@ -1428,9 +1475,11 @@ int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mi
     GG_TRY(ctx->dev_alloc((void **)&tile_entry, (n_tiles + 1) * sizeof(uint32_t)));
     GG_LAUNCH(ctx, "mat_tile_entries", k_mat_tile_entries, dim3((unsigned)((n_tiles + 256) / 256)), dim3(256), 0,
               (const uint64_t *)foff, n, n_tiles, M2, tile_entry);
-    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)n_tiles), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
+    const uint32_t groups = ctx->mat_groups > 1 && n_tiles >= 4ull * ctx->mat_groups ? ctx->mat_groups : 1;
+    const uint64_t grid = groups > 1 ? (n_tiles + groups - 1) / groups * groups : n_tiles;
+    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)grid), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
               csr->rnbr, csr->vid, (const uint64_t *)foff, (const uint32_t *)tile_entry, e0, n, M2, res->cols[2][0],
-              res->cols[2][1], res->cols[2][2]);
+              res->cols[2][1], res->cols[2][2], (uint32_t)n_tiles, groups);
     ctx->dev_free(tile_entry);
   }
   if (k_min <= 1) {
@@ -2018,7 +2067,7 @@ extern "C" int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_
                                          gg_khop_stats *stats, gg_result **out_result) {
   ApiScope scope(ctx);
   GG_TRY(check_args(ctx, csr, k_min, 2, stats));
-  if (!out_result || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
+  if (!out_result) return GG_ERR_INVALID_ARG;
   *out_result = nullptr;
   if (mid_hi > csr->V) mid_hi = csr->V;
   if (mid_lo > mid_hi) mid_lo = mid_hi;
@@ -2037,9 +2086,36 @@ extern "C" int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_
   return GG_OK;
 }
 
+extern "C" int gg_expand_khop_dev(gg_ctx *ctx, gg_csr *csr, int k_min, void **stats_dev) {
+  ApiScope scope(ctx);
+  gg_khop_stats unused;
+  GG_TRY(check_args(ctx, csr, k_min, 2, &unused));
+  if (!stats_dev) return GG_ERR_INVALID_ARG;
+  GG_HIP(hipSetDevice(ctx->device));
+  if (!ctx->stats_dev) GG_HIP(hipMalloc((void **)&ctx->stats_dev, 8 * sizeof(unsigned long long)));
+  GG_TRY(khop_count_mid(ctx, csr, 0, csr->V, k_min, nullptr, ctx->stats_dev));
+  *stats_dev = ctx->stats_dev;
+  return GG_OK;
+}
+
+extern "C" int gg_stream_wait(gg_ctx *ctx, void *other_stream, int direction) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  GG_HIP(hipSetDevice(ctx->device));
+  if (!ctx->xstream_event) GG_HIP(hipEventCreateWithFlags(&ctx->xstream_event, hipEventDisableTiming));
+  hipStream_t other = (hipStream_t)other_stream;
+  if (direction == 0) {  // the other stream waits for everything queued on the context's stream
+    GG_HIP(hipEventRecord(ctx->xstream_event, ctx->stream));
+    GG_HIP(hipStreamWaitEvent(other, ctx->xstream_event, 0));
+  } else {  // the context's stream waits for everything queued on the other stream
+    GG_HIP(hipEventRecord(ctx->xstream_event, other));
+    GG_HIP(hipStreamWaitEvent(ctx->stream, ctx->xstream_event, 0));
+  }
+  return GG_OK;
+}
+
 extern "C" int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds) {
   ApiScope scope(ctx);
-  if (!ctx || !csr || n_parts < 1 || !bounds || csr->n_parts > 1) return GG_ERR_INVALID_ARG;
+  if (!ctx || !csr || n_parts < 1 || !bounds) return GG_ERR_INVALID_ARG;
   GG_HIP(hipSetDevice(ctx->device));
   const uint64_t V = csr->V;
   bounds[0] = 0;
@@ -2173,8 +2249,9 @@ extern "C" void gg_result_destroy(gg_result *res) {
   if (!res) return;
   gg_ctx *ctx = res->ctx;
   if (ctx) {
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    // no synchronisation: the blocks return to the context's pool and their next user is queued on the same stream
+    // behind whatever still writes them (gg_csr_destroy: same argument); a part-by-part producer thus queues the next
+    // part while the last kernel of this one runs.  Fetches (gg_result_fetch) are complete when they return.
     for (int h = 0; h <= GG_MAX_HOPS; h++)
       for (int c = 0; c <= GG_MAX_HOPS; c++) {
         ctx->dev_free(res->cols[h][c]);

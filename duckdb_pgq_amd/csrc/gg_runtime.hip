@@ -55,7 +55,7 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
   }
   int best = -1;
   for (size_t i = 0; i < blocks.size(); i++) {
-    if (!blocks[i].in_use && blocks[i].size >= bytes && blocks[i].size <= bytes * 2 + (1u << 20)) {
+    if (!blocks[i].in_use && !blocks[i].reserved && blocks[i].size >= bytes && blocks[i].size <= bytes * 2 + (1u << 20)) {
       if (best < 0 || blocks[i].size < blocks[best].size) best = (int)i;
     }
   }
@@ -70,9 +70,20 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    // drop every cached free block and retry once
+    // drop every cached free block (placed column sets too: a set with a member gone is forgotten) and retry once
     for (auto &b : blocks)
       if (!b.in_use && b.ptr) {
+        if (b.reserved)
+          for (size_t si = 0; si < placed_sets.size();) {
+            auto &set = placed_sets[si];
+            if (set.col[0] == b.ptr || set.col[1] == b.ptr || set.col[2] == b.ptr) {
+              for (auto &o : blocks)
+                if (o.ptr && (o.ptr == set.col[0] || o.ptr == set.col[1] || o.ptr == set.col[2])) o.reserved = false;
+              placed_sets.erase(placed_sets.begin() + si);
+            } else {
+              si++;
+            }
+          }
         (void)hipFree(b.ptr);
         bytes_allocated -= b.size;
         b.ptr = nullptr;
@@ -88,6 +99,178 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
   bytes_allocated += bytes;
   blocks.push_back({p, bytes, true, next_serial++, false});
   *out = p;
+  return GG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Placement of large result columns.  Columns that are written in lockstep (k_mat_mid2: three int64 columns) reach
+// 7.0-7.2 TB/s or 5.5-5.9 TB/s depending on WHERE in device memory they lie.  scripts/ubench_fill_map.hip
+// (profiles/r04_ubench_fill_map.txt) maps it: device memory falls into THREE classes of ~96 GB each (the three ranks of
+// the 12-high HBM3E stacks, by every appearance; a 208 GiB allocation is a patchwork of them in pieces of 8-64 GiB);
+// two streams in the same class run at 5.8 TB/s, in different classes at 7.15; three streams 5.75 when all share a
+// class, 7.0 with two classes, 7.2 with three — independent of the order of the writes and of offsets inside a class.
+// Nothing in a virtual address says which class it is in, so the pool asks the hardware: for columns of >= 1 GiB it
+// allocates `place_probes` candidate blocks (with spacers between them, so that they reach into different classes),
+// times every pair with a sparse lockstep fill over the blocks' whole extent, keeps the three blocks with the most
+// fast pairs as a SET and returns the rest to the driver.  A set is recycled as a set (its blocks are reserved: the
+// general pool does not hand them out), so the probing is paid once per context and column size.
+// ------------------------------------------------------------------------------------------
+typedef long long place_ll2 __attribute__((ext_vector_type(2)));
+// chunk c of every `sample` chunks (PROBE_CHUNK pairs = 256 KiB per stream) of two streams, in lockstep
+constexpr uint64_t PROBE_CHUNK = 16384;
+__global__ __launch_bounds__(256) void k_place_probe(place_ll2 *__restrict__ a, place_ll2 *__restrict__ b, uint64_t pairs,
+                                                     uint32_t sample) {
+  const uint64_t lo = (uint64_t)blockIdx.x * sample * PROBE_CHUNK;
+  const uint64_t hi = lo + PROBE_CHUNK < pairs ? lo + PROBE_CHUNK : pairs;
+  place_ll2 v;
+  v.x = (long long)blockIdx.x;
+  v.y = (long long)threadIdx.x;
+  for (uint64_t q = lo + threadIdx.x; q < hi; q += 256) {
+    __builtin_nontemporal_store(v, a + q);
+    __builtin_nontemporal_store(v, b + q);
+  }
+}
+
+int gg_ctx::dev_alloc_columns(void **cols, size_t col_bytes) {
+  constexpr size_t PROBE_MIN = size_t(1) << 30;
+  const size_t stride = (col_bytes + 255) & ~size_t(255);
+  if (stride < PROBE_MIN || place_probes <= 3) {  // one pooled block, the columns side by side
+    char *base = nullptr;
+    GG_TRY(dev_alloc((void **)&base, 3 * stride));
+    for (int c = 0; c < 3; c++) cols[c] = base + c * stride;  // (cols[1], cols[2] are not pool blocks: dev_free ignores them)
+    return GG_OK;
+  }
+  size_t bytes = stride;
+  {  // the size classes of dev_alloc
+    size_t step = size_t(1) << 26;
+    while ((step << 4) <= bytes) step <<= 1;
+    bytes = (bytes + step - 1) / step * step;
+  }
+  {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    for (auto &set : placed_sets) {
+      if (set.bytes < bytes || set.bytes > bytes * 2 + (1u << 20)) continue;
+      DevBlock *blk[3] = {nullptr, nullptr, nullptr};
+      for (auto &b : blocks)
+        for (int c = 0; c < 3; c++)
+          if (b.ptr == set.col[c]) blk[c] = &b;
+      if (!blk[0] || !blk[1] || !blk[2] || blk[0]->in_use || blk[1]->in_use || blk[2]->in_use) continue;
+      for (int c = 0; c < 3; c++) {
+        blk[c]->in_use = true;
+        blk[c]->serial = next_serial++;
+        blk[c]->keep = false;
+        cols[c] = blk[c]->ptr;
+      }
+      return GG_OK;
+    }
+  }
+  // build a set: candidates (spacers between them are freed at the end), pair probes, best triple
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    e0 = e1 = nullptr;
+  }
+  std::vector<void *> cand, spacers;
+  const size_t spacer = bytes < (size_t(16) << 30) ? (size_t(16) << 30) - bytes : 0;
+  for (int t = 0; t < place_probes && e0; t++) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+    if (t >= 3 && free_b < bytes + spacer + total_b / 8) break;  // (leave an eighth of the device alone)
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+    cand.push_back(p);
+    if (spacer && t + 1 < place_probes && free_b > bytes + 2 * spacer + total_b / 8) {
+      void *sp = nullptr;
+      if (hipMalloc(&sp, spacer) == hipSuccess)
+        spacers.push_back(sp);
+      else
+        (void)hipGetLastError();
+    }
+  }
+  for (void *sp : spacers) (void)hipFree(sp);
+  if (cand.size() < 3) {  // not enough memory for separate blocks (or no events): whatever the pool has
+    for (void *p : cand) (void)hipFree(p);
+    if (e0) {
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+    char *base = nullptr;
+    GG_TRY(dev_alloc((void **)&base, 3 * stride));
+    for (int c = 0; c < 3; c++) cols[c] = base + c * stride;
+    return GG_OK;
+  }
+  const size_t n = cand.size();
+  const uint64_t pairs = stride / 16;
+  const uint64_t chunks = (pairs + PROBE_CHUNK - 1) / PROBE_CHUNK;
+  const uint32_t sample = chunks >= 4096 ? 8 : 1;  // (columns of >= 1 GiB: an eighth of the chunks, over the whole extent)
+  const unsigned grid = (unsigned)((chunks + sample - 1) / sample);
+  std::vector<double> rate(n * n, 0.0);
+  bool probed = true;
+  for (size_t i = 0; i < n && probed; i++)
+    for (size_t j = i + 1; j < n && probed; j++) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 2; rep++) {  // (the first launch after an allocation pays for its page tables)
+        float ms = 0.f;
+        (void)hipEventRecord(e0, stream);
+        hipLaunchKernelGGL(k_place_probe, dim3(grid), dim3(256), 0, stream, (place_ll2 *)cand[i], (place_ll2 *)cand[j], pairs,
+                           sample);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
+          (void)hipGetLastError();
+          probed = false;
+          break;
+        }
+        best = ms < best ? ms : best;
+      }
+      const double written = 2.0 * 16.0 * (double)std::min<uint64_t>(pairs, (uint64_t)grid * PROBE_CHUNK);
+      rate[i * n + j] = rate[j * n + i] = probed ? written / (best * 1e-3) : 0.0;
+    }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  // the triple with the most fast pairs (two streams: 5.8 against 7.15 TB/s — 6.5 divides them), then the fastest
+  size_t pick[3] = {0, 1, 2};
+  double pick_score = -1.0;
+  int pick_fast = 0;
+  for (size_t i = 0; i < n; i++)
+    for (size_t j = i + 1; j < n; j++)
+      for (size_t k = j + 1; k < n; k++) {
+        const double r[3] = {rate[i * n + j], rate[i * n + k], rate[j * n + k]};
+        int fast = 0;
+        for (double x : r) fast += x >= 6.5e12;
+        const double score = fast * 1e14 + r[0] + r[1] + r[2];
+        if (score > pick_score) {
+          pick_score = score;
+          pick_fast = fast;
+          pick[0] = i;
+          pick[1] = j;
+          pick[2] = k;
+        }
+      }
+  if (getenv("GG_PLACE_TRACE")) {
+    fprintf(stderr, "[gg] column set of 3 x %.1f GiB: %zu candidates, pair rates (TB/s):", bytes / 1073741824.0, n);
+    for (size_t i = 0; i < n; i++)
+      for (size_t j = i + 1; j < n; j++) fprintf(stderr, " %zu-%zu %.2f", i, j, rate[i * n + j] / 1e12);
+    fprintf(stderr, " -> blocks %zu %zu %zu (%d fast pairs)\n", pick[0], pick[1], pick[2], pick_fast);
+  }
+  for (size_t i = 0; i < n; i++)
+    if (i != pick[0] && i != pick[1] && i != pick[2]) (void)hipFree(cand[i]);
+  placed_built++;
+  placed_fast_pairs = (uint64_t)pick_fast;
+  std::lock_guard<std::mutex> lk(pool_mu);
+  PlacedSet set;
+  set.bytes = bytes;
+  for (int c = 0; c < 3; c++) {
+    set.col[c] = cols[c] = cand[pick[c]];
+    bytes_allocated += bytes;
+    DevBlock blk{cand[pick[c]], bytes, true, next_serial++, false};
+    blk.reserved = true;
+    blocks.push_back(blk);
+  }
+  placed_sets.push_back(set);
   return GG_OK;
 }
 
@@ -291,6 +474,8 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   GG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (const char *e = getenv("GG_MAT_GROUPS")) ctx->mat_groups = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("GG_PLACE_PROBES")) ctx->place_probes = atoi(e) > 0 ? (atoi(e) < 12 ? atoi(e) : 12) : 1;
   for (int i = 0; i < 2; i++) {
     GG_HIP(hipHostMalloc((void **)&ctx->pin_v[i], gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
     GG_HIP(hipEventCreateWithFlags(&ctx->pin_v_free[i], hipEventDisableTiming));
@@ -325,6 +510,8 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
     if (b.free_ev) (void)hipEventDestroy(b.free_ev);
   }
   if (ctx->pin_scratch) (void)hipHostFree(ctx->pin_scratch);
+  if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+  if (ctx->xstream_event) (void)hipEventDestroy(ctx->xstream_event);
   if (ctx->dev_err) (void)hipFree(ctx->dev_err);
   if (ctx->status_ev) (void)hipEventDestroy(ctx->status_ev);
   for (auto ev : ctx->prof_event_pool) (void)hipEventDestroy(ev);
@@ -356,7 +543,7 @@ extern "C" int gg_host_alloc(gg_ctx *ctx, uint64_t bytes, void **out) {
   }
   GG_HIP(hipSetDevice(ctx->device));
   void *p = nullptr;
-  GG_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  GG_HIP(hipHostMalloc(&p, bytes, hipHostMallocPortable));
   ctx->host_blocks.push_back({p, (size_t)bytes, true});
   *out = p;
   return GG_OK;

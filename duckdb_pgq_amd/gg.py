@@ -17,7 +17,7 @@ SYMBOLS = [
     "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
-    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_count", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
+    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_count", "gg_expand_khop_dev", "gg_stream_wait", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_debug_max_grid_tiles", "gg_debug_reset",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
@@ -92,6 +92,8 @@ def load_library(path: str | None = None):
     lib.gg_expand_khop_range.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
     lib.gg_khop_partition.argtypes = [P, P, C.c_int, C.POINTER(u64)]
     lib.gg_khop_count.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(u64)]
+    lib.gg_expand_khop_dev.argtypes = [P, P, C.c_int, C.POINTER(C.c_void_p)]
+    lib.gg_stream_wait.argtypes = [P, C.c_void_p, C.c_int]
     lib.gg_expand_khop_mid.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.POINTER(KhopStats)]
     lib.gg_khop_partition_mid.argtypes = [P, P, C.c_int, C.POINTER(u64)]
     lib.gg_expand_khop_mid_result.argtypes = [P, P, u64, u64, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
@@ -201,6 +203,19 @@ class ShardedBfs:
         if self.handle:
             self.gg.lib.gg_bfs_sharded_end(self.handle)
             self.handle = None
+
+
+class DeviceWords:
+    """n uint64 words in device memory owned by the library, viewable as a tensor (torch.as_tensor(words, device=...)):
+    what a device-side collective reduces in place."""
+
+    def __init__(self, ptr: int, n: int):
+        self.ptr, self.n = ptr, n
+
+    @property
+    def __cuda_array_interface__(self):
+        # (int64: torch has no uint64 arithmetic; sums of counts stay far below 2^63, digests are masked by the reader)
+        return {"shape": (self.n,), "typestr": "<i8", "data": (self.ptr, False), "version": 2}
 
 
 class KhopResult:
@@ -375,6 +390,18 @@ class GG:
         if materialise:
             d["tables"] = self._collect(res, k_min, k_max)
         return d
+
+    def expand_khop_dev(self, csr: Csr, k_min: int = 1) -> "DeviceWords":
+        """All-sources 1..2-hop count + digest with the six result words left on the device (sharding.FIELDS order);
+        nothing waits.  The returned view is valid until the next such call on this context."""
+        ptr = C.c_void_p()
+        self._chk(self.lib.gg_expand_khop_dev(self.ctx, csr.handle, k_min, C.byref(ptr)))
+        return DeviceWords(ptr.value, 6)
+
+    def stream_wait(self, other_stream: int, direction: int = 0):
+        """direction 0: `other_stream` (raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) waits for the
+        library's stream; 1: the library's stream waits for it.  No host synchronisation."""
+        self._chk(self.lib.gg_stream_wait(self.ctx, C.c_void_p(other_stream), direction))
 
     def khop_count(self, csr: Csr, k_min: int, k_max: int, sources=None) -> list:
         """Number of h-hop walks per length (index h), from degrees: no row, no digest (gg_khop_count)."""

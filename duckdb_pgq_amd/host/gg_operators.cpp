@@ -471,30 +471,53 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
 //===--------------------------------------------------------------------===//
 // Path expansion source
 //===--------------------------------------------------------------------===//
-class GGExpandGlobalState : public GlobalSourceState {
-public:
-	~GGExpandGlobalState() override {
+//! One producer of a materialised result: the graph part (device context) whose walks it makes, the ranges still to
+//! produce, and the part that stands in HBM right now with its scan position.  An unsharded graph has one stream; an
+//! ownership-sharded one (GG_DEVICES) one per part — the pipeline's threads drain them side by side, each stream's
+//! rows crossing its own device's PCIe link.
+struct GGExpandStream {
+	~GGExpandStream() {
 		if (result) {
 			gg_result_destroy(result);
 		}
 	}
-	idx_t MaxThreads() override {
-		return max_threads;
-	}
-
-	gg_khop_stats stats;           // of the part that is materialised right now (count_only: of everything)
+	int graph_part = 0;
+	bool by_middle = false;        // ranges are middle-vertex ranges (gg_expand_khop_mid_result), else source ranges / slices
+	gg_khop_stats stats;           // of the part that is materialised right now
 	gg_result *result = nullptr;   // walks of the current part, in HBM
-	// A result too large for the device-memory budget is produced part by part: contiguous source ranges
-	// (all sources) or slices of the source list, one materialised at a time.  parts[i] = [first, last).
+	// A result too large for the device-memory budget is produced part by part, one materialised at a time.
+	// parts[i] = [first, last): middle vertices, source vertices (all sources) or positions of the source list.
 	vector<std::pair<uint64_t, uint64_t>> parts;
 	idx_t part = 0;
+	bool started = false, done = false;
 	std::atomic<idx_t> fetching {0}; // slab fetches still reading `result` (it may not be freed under them)
 	// scan position: (current hop length, next row of it nobody has claimed); pipeline threads claim
 	// GGResultSlab::SLAB_ROWS rows at a time under the lock and fetch them into their own slab
 	mutex lock;
 	int hop = 0;
 	idx_t offset = 0;
+};
+
+class GGExpandGlobalState : public GlobalSourceState {
+public:
+	idx_t MaxThreads() override {
+		return max_threads;
+	}
+
+	gg_khop_stats stats; // count_only: of everything
+	mutex lock;          // count_only: the one row set is handed out once
+	int hop = 0;
+	vector<unique_ptr<GGExpandStream>> streams;
+	std::atomic<idx_t> next_stream {0}; // threads start on different streams
 	idx_t max_threads = 1;
+};
+
+//! The slab of a thread plus the stream it drains at the moment.
+class GGExpandLocalState : public GGResultSlab {
+public:
+	explicit GGExpandLocalState(shared_ptr<GGGraph> graph) : GGResultSlab(move(graph)) {
+	}
+	idx_t stream = INVALID_INDEX;
 };
 
 vector<LogicalType> PhysicalGGPathExpand::OutputTypes(int k_max, bool count_only) {
@@ -536,32 +559,39 @@ static void CountRowsFromDegrees(gg_ctx *ctx, const gg_csr *csr, const vector<in
 	}
 }
 
-//! Device-memory budget for one materialised part (GG_RESULT_BUDGET_MB; default 16 GiB of the 288).
+//! Device-memory budget for one materialised part (GG_RESULT_BUDGET_MB; default 40 GiB of the 288: three id columns
+//! of ~13 GiB each — parts whose columns are below ~8 GiB are written slower, csrc/gg_runtime.hip "Placement").
 static uint64_t ResultBudgetBytes() {
 	auto env = std::getenv("GG_RESULT_BUDGET_MB");
-	const uint64_t mb = env ? std::strtoull(env, nullptr, 10) : 16384;
+	const uint64_t mb = env ? std::strtoull(env, nullptr, 10) : 40960;
 	return MaxValue<uint64_t>(mb, 1) << 20;
 }
 
-//! Materialise the walks of parts[part] (caller holds graph->lock or is single-threaded).
-void PhysicalGGPathExpand::MaterialisePart(GlobalSourceState &gstate_p) const {
-	auto &state = (GGExpandGlobalState &)gstate_p;
-	if (state.result) {
-		gg_result_destroy(state.result);
-		state.result = nullptr;
+//! Materialise the walks of stream.parts[stream.part] (caller holds the stream's lock or is single-threaded).
+void PhysicalGGPathExpand::MaterialisePart(GGExpandStream &stream) const {
+	if (stream.result) {
+		gg_result_destroy(stream.result);
+		stream.result = nullptr;
 	}
-	const auto range = state.parts[state.part];
-	if (all_sources) {
-		GGGraph::Check(gg_expand_khop_range(graph->ctx, graph->csr, range.first, range.second, k_min, k_max, 1,
-		                                    &state.stats, &state.result),
+	auto &part = graph->Part(stream.graph_part);
+	lock_guard<mutex> device_guard(part.lock);
+	const auto range = stream.parts[stream.part];
+	if (stream.by_middle) {
+		GGGraph::Check(gg_expand_khop_mid_result(part.ctx, part.csr, range.first, range.second, k_min, &stream.stats,
+		                                         &stream.result),
+		               "gg_expand_khop_mid_result");
+	} else if (all_sources) {
+		GGGraph::Check(gg_expand_khop_range(part.ctx, part.csr, range.first, range.second, k_min, k_max, 1,
+		                                    &stream.stats, &stream.result),
 		               "gg_expand_khop_range");
 	} else {
-		GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, sources.data() + range.first, range.second - range.first,
-		                              k_min, k_max, 1, &state.stats, &state.result),
+		GGGraph::Check(gg_expand_khop(part.ctx, part.csr, sources.data() + range.first, range.second - range.first,
+		                              k_min, k_max, 1, &stream.stats, &stream.result),
 		               "gg_expand_khop");
 	}
-	state.hop = k_min;
-	state.offset = 0;
+	stream.hop = k_min;
+	stream.offset = 0;
+	stream.started = true;
 }
 
 unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientContext &context) const {
@@ -570,19 +600,20 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 	if (!graph->csr) {
 		throw InternalException("GG_PATH_EXPAND scheduled before the CSR was built");
 	}
+	const bool product_form = all_sources && k_max == 2; // rows grouped by middle vertex: in(x) x out(x), gg.h
 	if (graph->Parts() > 1) {
-		// ownership-sharded graph: part p counts the walks whose middle vertex (1-hop: destination) it owns;
-		// counts add, digests add (gg.h: gg_csr_build_shard) — the same combine bench.py's ranks do with one
-		// all-reduce, here across the contexts of one process
-		if (!count_only || !all_sources || k_max != 2) {
-			throw InternalException("GG_PATH_EXPAND over a sharded graph: only the count of all 2-hop walks (with or without the 1-hop ones)");
+		// ownership-sharded graph: part p holds the walks whose middle vertex (1-hop: destination) it owns; counts
+		// add, digests add, materialised rows concatenate (gg.h: gg_csr_build_shard) — what bench.py's ranks combine
+		// with one all-reduce, here across the contexts of one process
+		if (!product_form) {
+			throw InternalException("GG_PATH_EXPAND over a sharded graph: only the 2-hop walks of all sources (with or without the 1-hop ones)");
 		}
 		vector<gg_khop_stats> per_part(graph->Parts());
 		graph->ForEachPart([&](int p, GGGraph &part) {
 			if (!part.csr) {
-				throw InternalException("GG_PATH_COUNT scheduled before the CSR shards were built");
+				throw InternalException("GG_PATH_EXPAND scheduled before the CSR shards were built");
 			}
-			if (rows_only) {
+			if (rows_only || !count_only) {
 				CountRowsFromDegrees(part.ctx, part.csr, sources, true, k_min, k_max, per_part[p]);
 				return;
 			}
@@ -600,6 +631,21 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 			state->stats.frontier_entries += stats.frontier_entries;
 		}
 		state->hop = k_min;
+		if (count_only) {
+			return move(state);
+		}
+		uint64_t total = 0;
+		for (int p = 0; p < graph->Parts(); p++) {
+			auto stream = make_unique<GGExpandStream>();
+			stream->graph_part = p;
+			stream->by_middle = true;
+			PlanMiddleParts(*stream, graph->Part(p), per_part[p]);
+			state->streams.push_back(move(stream));
+			for (int h = k_min; h <= k_max; h++) {
+				total += per_part[p].rows[h];
+			}
+		}
+		state->max_threads = MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
 		return move(state);
 	}
 	if (rows_only) {
@@ -608,54 +654,87 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 		state->hop = k_min;
 		return move(state);
 	}
-	// count first: cheap (nothing is written), and it tells how much HBM the walks would take
-	GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(), k_min,
-	                              k_max, 0, &state->stats, nullptr),
-	               "gg_expand_khop");
-	state->hop = k_min;
+	// count first: cheap (nothing is written), and it tells how much HBM the walks would take — from degrees when
+	// the rows are wanted (their digest is nobody's business then), by the counting expansion for gg_path_count
 	if (count_only) {
+		GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(),
+		                              k_min, k_max, 0, &state->stats, nullptr),
+		               "gg_expand_khop");
+		state->hop = k_min;
 		return move(state);
 	}
+	CountRowsFromDegrees(graph->ctx, graph->csr, sources, all_sources, k_min, k_max, state->stats);
+	state->hop = k_min;
 	uint64_t total = 0, bytes = 0;
 	for (int h = k_min; h <= k_max; h++) {
 		total += state->stats.rows[h];
 		bytes += state->stats.rows[h] * (uint64_t)(h + 1) * sizeof(int64_t);
 	}
-	// The reference streams a join result of any size; so must its replacement: beyond the budget the
-	// sources are split into parts (twice as many as strictly needed: the split is balanced on 2-hop work,
-	// not on output bytes) that are expanded, handed out and freed one after the other.
-	uint64_t V = 0;
-	GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
-	const uint64_t units = all_sources ? V : sources.size();
-	uint64_t n_parts = bytes > ResultBudgetBytes() ? 2 * ((bytes + ResultBudgetBytes() - 1) / ResultBudgetBytes()) : 1;
-	n_parts = MaxValue<uint64_t>(1, MinValue<uint64_t>(n_parts, MaxValue<uint64_t>(units, 1)));
-	if (n_parts == 1 || units == 0) {
-		state->parts.emplace_back(0, units);
-	} else if (all_sources) {
-		vector<uint64_t> bounds(n_parts + 1);
-		GGGraph::Check(gg_khop_partition(graph->ctx, graph->csr, (int)n_parts, bounds.data()), "gg_khop_partition");
-		for (uint64_t i = 0; i < n_parts; i++) {
-			if (bounds[i + 1] > bounds[i]) {
-				state->parts.emplace_back(bounds[i], bounds[i + 1]);
-			}
-		}
+	auto stream = make_unique<GGExpandStream>();
+	if (product_form) {
+		stream->by_middle = true;
+		PlanMiddleParts(*stream, *graph, state->stats);
 	} else {
-		for (uint64_t i = 0; i < n_parts; i++) {
-			const uint64_t lo = units * i / n_parts, hi = units * (i + 1) / n_parts;
-			if (hi > lo) {
-				state->parts.emplace_back(lo, hi);
+		// The reference streams a join result of any size; so must its replacement: beyond the budget the
+		// sources are split into parts (twice as many as strictly needed: the split is balanced on 2-hop work,
+		// not on output bytes) that are expanded, handed out and freed one after the other.
+		uint64_t V = 0;
+		GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
+		const uint64_t units = all_sources ? V : sources.size();
+		uint64_t n_parts = bytes > ResultBudgetBytes() ? 2 * ((bytes + ResultBudgetBytes() - 1) / ResultBudgetBytes()) : 1;
+		n_parts = MaxValue<uint64_t>(1, MinValue<uint64_t>(n_parts, MaxValue<uint64_t>(units, 1)));
+		if (n_parts == 1 || units == 0) {
+			stream->parts.emplace_back(0, units);
+		} else if (all_sources) {
+			vector<uint64_t> bounds(n_parts + 1);
+			GGGraph::Check(gg_khop_partition(graph->ctx, graph->csr, (int)n_parts, bounds.data()), "gg_khop_partition");
+			for (uint64_t i = 0; i < n_parts; i++) {
+				if (bounds[i + 1] > bounds[i]) {
+					stream->parts.emplace_back(bounds[i], bounds[i + 1]);
+				}
+			}
+		} else {
+			for (uint64_t i = 0; i < n_parts; i++) {
+				const uint64_t lo = units * i / n_parts, hi = units * (i + 1) / n_parts;
+				if (hi > lo) {
+					stream->parts.emplace_back(lo, hi);
+				}
 			}
 		}
 	}
-	state->part = 0;
-	MaterialisePart(*state);
+	state->streams.push_back(move(stream));
 	state->max_threads = MaxValue<idx_t>(1, total / GGResultSlab::SLAB_ROWS);
 	return move(state);
 }
 
+//! Middle-vertex ranges of near-equal product work whose rows fit the budget (gg_khop_partition_mid): the parts of a
+//! 2-hop result from every vertex, each produced by the product kernel (k_mat_mid2) like the whole would be.
+void PhysicalGGPathExpand::PlanMiddleParts(GGExpandStream &stream, GGGraph &part, const gg_khop_stats &stats) const {
+	uint64_t bytes = 0, V = 0;
+	for (int h = k_min; h <= k_max; h++) {
+		bytes += stats.rows[h] * (uint64_t)(h + 1) * sizeof(int64_t);
+	}
+	GGGraph::Check(gg_csr_info(part.csr, &V, nullptr, nullptr), "gg_csr_info");
+	uint64_t n_parts = (bytes + ResultBudgetBytes() - 1) / ResultBudgetBytes();
+	n_parts = MaxValue<uint64_t>(1, MinValue<uint64_t>(n_parts, MaxValue<uint64_t>(V, 1)));
+	if (n_parts == 1 || V == 0) {
+		stream.parts.emplace_back(0, V);
+		return;
+	}
+	// (the split balances work, not bytes: a quarter more parts keep the largest under the budget)
+	n_parts += (n_parts + 3) / 4;
+	vector<uint64_t> bounds(n_parts + 1);
+	GGGraph::Check(gg_khop_partition_mid(part.ctx, part.csr, (int)n_parts, bounds.data()), "gg_khop_partition_mid");
+	for (uint64_t i = 0; i < n_parts; i++) {
+		if (bounds[i + 1] > bounds[i]) {
+			stream.parts.emplace_back(bounds[i], bounds[i + 1]);
+		}
+	}
+}
+
 unique_ptr<LocalSourceState> PhysicalGGPathExpand::GetLocalSourceState(ExecutionContext &context,
                                                                        GlobalSourceState &gstate) const {
-	return make_unique<GGResultSlab>(graph);
+	return make_unique<GGExpandLocalState>(graph);
 }
 
 void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
@@ -680,50 +759,71 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 	if (context.client.interrupted) { // cancellation is polled between device calls
 		throw InterruptException();
 	}
-	auto &slab = (GGResultSlab &)lstate;
-	if (slab.pos >= slab.rows) { // claim the next rows of the next non-empty hop-length table
+	auto &slab = (GGExpandLocalState &)lstate;
+	const idx_t n_streams = gstate.streams.size();
+	if (slab.stream == INVALID_INDEX) {
+		slab.stream = gstate.next_stream++ % n_streams;
+	}
+	idx_t exhausted = 0; // streams found done in a row
+	while (slab.pos >= slab.rows) { // claim the next rows of the next non-empty hop-length table of some stream
+		if (exhausted >= n_streams) {
+			return; // every part of every stream handed out
+		}
+		auto &stream = *gstate.streams[slab.stream];
 		idx_t offset, want;
-		gg_result *result;
+		gg_result *result = nullptr;
 		{
-			lock_guard<mutex> guard(gstate.lock);
-			while (true) {
-				while (gstate.hop <= k_max && gstate.offset >= gstate.stats.rows[gstate.hop]) {
-					gstate.hop++;
-					gstate.offset = 0;
+			lock_guard<mutex> guard(stream.lock);
+			while (!stream.done) {
+				if (!stream.started) {
+					if (stream.parts.empty()) {
+						stream.done = true;
+						break;
+					}
+					MaterialisePart(stream);
 				}
-				if (gstate.hop <= k_max) {
+				while (stream.hop <= k_max && stream.offset >= stream.stats.rows[stream.hop]) {
+					stream.hop++;
+					stream.offset = 0;
+				}
+				if (stream.hop <= k_max) {
 					break;
 				}
-				if (gstate.part + 1 >= gstate.parts.size()) {
-					return; // every part handed out
+				if (stream.part + 1 >= stream.parts.size()) {
+					stream.done = true;
+					break;
 				}
 				// this part is claimed completely: wait for the fetches still reading it, then replace it
-				while (gstate.fetching.load() != 0) {
+				while (stream.fetching.load() != 0) {
 					std::this_thread::yield();
 				}
-				gstate.part++;
-				lock_guard<mutex> device_guard(graph->lock);
-				MaterialisePart(gstate);
+				stream.part++;
+				MaterialisePart(stream);
 			}
-			slab.table = gstate.hop;
-			offset = gstate.offset;
-			want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, gstate.stats.rows[gstate.hop] - gstate.offset);
-			gstate.offset += want;
-			result = gstate.result;
-			gstate.fetching++;
+			if (!stream.done) {
+				slab.table = stream.hop;
+				offset = stream.offset;
+				want = MinValue<idx_t>(GGResultSlab::SLAB_ROWS, stream.stats.rows[stream.hop] - stream.offset);
+				stream.offset += want;
+				result = stream.result;
+				stream.fetching++;
+			}
 		}
+		if (!result) { // this stream has nothing left: try the next one
+			slab.stream = (slab.stream + 1) % n_streams;
+			exhausted++;
+			continue;
+		}
+		exhausted = 0;
 		uint32_t got = 0;
 		int rc;
 		{
-			FetchClaim claim(gstate.fetching, true); // released also when slab.Columns() throws (pinned allocation)
+			FetchClaim claim(stream.fetching, true); // released also when slab.Columns() throws (pinned allocation)
 			rc = gg_result_fetch(result, slab.table, offset, (uint32_t)want, slab.Columns(slab.table + 1), &got);
 		}
 		GGGraph::Check(rc, "gg_result_fetch");
 		slab.rows = got;
 		slab.pos = 0;
-		if (got == 0) {
-			return;
-		}
 	}
 	const int hop = slab.table;
 	const idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, slab.rows - slab.pos);
@@ -831,27 +931,100 @@ PhysicalGGPathEdges::PhysicalGGPathEdges(shared_ptr<GGGraph> graph_p, int hops_p
       edge_table(edge_table_p), payload(move(payload_p)) {
 }
 
+//! State of GG_PATH_EDGES: like the walks without edges, a result beyond the device-memory budget is produced part by
+//! part — slices of the source list (all sources: of the vertex ids) expanded, handed out and freed in turn.
+class GGPathEdgesGlobalState : public GlobalSourceState {
+public:
+	~GGPathEdgesGlobalState() override {
+		if (result) {
+			gg_result_destroy(result);
+		}
+	}
+	gg_result *result = nullptr;
+	idx_t rows = 0;
+	idx_t offset = 0;
+	vector<int64_t> ids; // the sources the parts slice (all sources: every vertex id)
+	vector<std::pair<uint64_t, uint64_t>> parts;
+	idx_t part = 0;
+};
+
+void PhysicalGGPathEdges::MaterialisePart(GlobalSourceState &gstate_p) const {
+	auto &state = (GGPathEdgesGlobalState &)gstate_p;
+	if (state.result) {
+		gg_result_destroy(state.result);
+		state.result = nullptr;
+	}
+	gg_khop_stats stats;
+	const auto range = state.parts[state.part];
+	const bool whole = all_sources && state.parts.size() == 1;
+	GGGraph::Check(gg_expand_khop_edges(graph->ctx, graph->csr, whole ? nullptr : state.ids.data() + range.first,
+	                                    whole ? 0 : range.second - range.first, hops, &stats, &state.result),
+	               "gg_expand_khop_edges");
+	uint64_t n = 0;
+	GGGraph::Check(gg_result_rows(state.result, hops, &n), "gg_result_rows");
+	state.rows = n;
+	state.offset = 0;
+}
+
 unique_ptr<GlobalSourceState> PhysicalGGPathEdges::GetGlobalSourceState(ClientContext &context) const {
-	auto state = make_unique<GGFilteredGlobalState>();
+	auto state = make_unique<GGPathEdgesGlobalState>();
 	lock_guard<mutex> guard(graph->lock);
 	if (!graph->csr) {
 		throw InternalException("GG_PATH_EDGES scheduled before the CSR was built");
 	}
-	gg_khop_stats stats;
-	GGGraph::Check(gg_expand_khop_edges(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(),
-	                                    all_sources ? 0 : sources.size(), hops, &stats, &state->result),
-	               "gg_expand_khop_edges");
-	uint64_t n = 0;
-	GGGraph::Check(gg_result_rows(state->result, hops, &n), "gg_result_rows");
-	state->rows = n;
+	// count first (from degrees: nothing is written) — the walks with their edges take (2 * hops + 1) int64 columns
+	// at the last level plus the level tables below it (dense u32 columns: about half as much again)
+	uint64_t rows[GG_MAX_HOPS + 1];
+	GGGraph::Check(gg_khop_count(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(), 1, hops,
+	                             rows),
+	               "gg_khop_count");
+	uint64_t bytes = rows[hops] * (uint64_t)(2 * hops + 1) * sizeof(int64_t);
+	for (int h = 1; h < hops; h++) {
+		bytes += rows[h] * (uint64_t)(2 * h + 1) * sizeof(uint32_t);
+	}
+	const uint64_t budget = ResultBudgetBytes();
+	uint64_t V = 0;
+	GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
+	const uint64_t units = all_sources ? V : sources.size();
+	// (slices of equal size, not of equal work: four times the parts the bytes ask for)
+	uint64_t n_parts = bytes > budget ? 4 * ((bytes + budget - 1) / budget) : 1;
+	n_parts = MaxValue<uint64_t>(1, MinValue<uint64_t>(n_parts, MaxValue<uint64_t>(units, 1)));
+	if (n_parts == 1) {
+		state->parts.emplace_back(0, units);
+		if (!all_sources) {
+			state->ids = sources;
+		}
+	} else {
+		if (all_sources) {
+			state->ids.resize(V);
+			GGGraph::Check(gg_csr_export(graph->csr, nullptr, nullptr, nullptr, state->ids.data()), "gg_csr_export");
+		} else {
+			state->ids = sources;
+		}
+		for (uint64_t i = 0; i < n_parts; i++) {
+			const uint64_t lo = units * i / n_parts, hi = units * (i + 1) / n_parts;
+			if (hi > lo) {
+				state->parts.emplace_back(lo, hi);
+			}
+		}
+	}
+	MaterialisePart(*state);
 	return move(state);
 }
 
 void PhysicalGGPathEdges::GetData(ExecutionContext &context, DataChunk &chunk, GlobalSourceState &gstate_p,
                                   LocalSourceState &lstate) const {
-	auto &gstate = (GGFilteredGlobalState &)gstate_p;
-	if (gstate.offset >= gstate.rows) {
-		return;
+	auto &gstate = (GGPathEdgesGlobalState &)gstate_p;
+	while (gstate.offset >= gstate.rows) { // this part is handed out: the next one, if any
+		if (gstate.part + 1 >= gstate.parts.size()) {
+			return;
+		}
+		if (context.client.interrupted) {
+			throw InterruptException();
+		}
+		gstate.part++;
+		lock_guard<mutex> guard(graph->lock);
+		MaterialisePart(gstate);
 	}
 	int64_t *cols[GG_MAX_HOPS + 1];
 	for (int c = 0; c <= hops; c++) {

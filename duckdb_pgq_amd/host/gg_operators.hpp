@@ -29,6 +29,7 @@
 
 namespace duckdb {
 class TableCatalogEntry;
+struct GGExpandStream;
 
 //! Device graph shared by the sinks that build it and the sources that query it.
 struct GGGraph {
@@ -172,8 +173,9 @@ public:
 	                     bool all_sources, idx_t estimated_cardinality, bool rows_only = false);
 
 	static vector<LogicalType> OutputTypes(int k_max, bool count_only);
-	//! expand the current part of a result that is produced part by part (see GetGlobalSourceState)
-	void MaterialisePart(GlobalSourceState &gstate) const;
+	//! expand the current part of a stream of a result that is produced part by part (see GetGlobalSourceState)
+	void MaterialisePart(GGExpandStream &stream) const;
+	void PlanMiddleParts(GGExpandStream &stream, GGGraph &part, const gg_khop_stats &stats) const;
 
 	shared_ptr<GGGraph> graph;
 	int k_min, k_max;
@@ -221,6 +223,9 @@ public:
 	bool all_sources;
 	TableCatalogEntry *edge_table;
 	vector<std::pair<idx_t, column_t>> payload;
+
+	//! expand the current part (slices of the sources under GG_RESULT_BUDGET_MB; caller holds graph->lock)
+	void MaterialisePart(GlobalSourceState &gstate) const;
 
 public:
 	unique_ptr<GlobalSourceState> GetGlobalSourceState(ClientContext &context) const override;

@@ -922,10 +922,11 @@ unique_ptr<PhysicalOperator> MakeExpandScan(const WalkPattern &pattern, bool cou
 	const int hops = (int)pattern.hops;
 	const auto sources = pattern.sources;
 	const bool all_sources = pattern.all_sources;
-	if (count_only && all_sources && hops == 2) {
-		// the one plan shape whose result adds over ownership shards of the graph: with GG_DEVICES=N the tables
-		// go to N device contexts (device p mod the devices present) and N CSR shards are built and counted side
-		// by side — bench.py's N ranks inside one process, for a host with several GPUs
+	if (all_sources && hops == 2) {
+		// the plan shape whose result adds (counts) or concatenates (rows) over ownership shards of the graph: with
+		// GG_DEVICES=N the tables go to N device contexts (device p mod the devices present), N CSR shards are built
+		// side by side, and every shard counts or materialises the walks whose middle vertex it owns — bench.py's N
+		// ranks inside one process, for a host with several GPUs; the rows of each shard cross its own PCIe link
 		spec.shards = GGGraph::ConfiguredParts();
 	}
 	auto data = make_unique<GGFunctionData>();

@@ -66,6 +66,9 @@ def combine(vec, dist=None, device=None) -> list:
     # device tensors: one page-locked staging tensor and one device tensor per vector length, kept across queries —
     # up, all-reduce and down are queued on torch's stream without a host synchronisation in between (building a
     # tensor from a list and reading it back with tolist() were two of them per query)
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     key = (len(halves), str(device))
     bufs = _combine_buffers.get(key)
     if bufs is None:
@@ -77,8 +80,37 @@ def combine(vec, dist=None, device=None) -> list:
     dev.copy_(host, non_blocking=True)
     dist.all_reduce(dev)
     host.copy_(dev, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    torch.cuda.current_stream(dev.device).synchronize()  # (the stream the copies and the collective were queued on)
     return join_halves(host_np.tolist())
+
+
+def combine_dev(gg, words, dist=None, device=None) -> list:
+    """The same combine with the rank's result vector already ON THE DEVICE (gg.expand_khop_dev: six uint64 words in
+    FIELDS order, left in library memory without a host synchronisation): torch's stream is ordered behind the library's
+    by an event (gg.stream_wait), the words are all-reduced IN PLACE (SUM; one collective on a view of that memory) and
+    cross to the host once — one round trip per query instead of three (down from the expansion, up as a tensor, down
+    again).  Counts stay far below 2^63; the two digests are 32-bit sums, masked here."""
+    import torch
+
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream(device)
+    gg.stream_wait(stream.cuda_stream, 0)
+    t = torch.as_tensor(words, device=device)
+    if dist is not None and dist.is_initialized():
+        dist.all_reduce(t)
+    key = ("dev", t.numel(), str(device))
+    host = _combine_buffers.get(key)
+    if host is None:
+        host = torch.empty(t.numel(), dtype=torch.int64).pin_memory()
+        _combine_buffers[key] = host
+    host.copy_(t, non_blocking=True)
+    stream.synchronize()
+    vec = [int(x) & MASK64 for x in host.tolist()]
+    for i in LANEWISE:
+        vec[i] &= MASK32
+    return vec
 
 
 _combine_buffers = {}

@@ -179,9 +179,22 @@ int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_h
 /* The same rows MATERIALISED (int64 id columns in HBM, fetched with gg_result_fetch): the 2-hop rows u -> x -> w of
  * all sources with x in [mid_lo, mid_hi) and, if k_min == 1, the 1-hop rows u -> x into the range.  Disjoint ranges
  * partition the materialised result of gg_expand_khop(all sources, k_min..2) — how a result larger than device
- * memory (SF100: 12.8 G rows, 306 GB) is produced part by part, each part through the product kernel. */
+ * memory (SF100: 12.8 G rows, 306 GB) is produced part by part, each part through the product kernel.  On a shard
+ * (gg_csr_build_shard) the rows are those whose middle vertex is owned AND in the range: N ranks that each materialise
+ * [0, V) of their shard — in gg_khop_partition_mid parts if need be — produce the whole result once, no exchange. */
 int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min,
                               gg_khop_stats *stats, gg_result **out_result);
+/* gg_expand_khop(all sources, k_min..2, count) with the result LEFT ON THE DEVICE and no host synchronisation: six
+ * uint64 words (rows of 1-hop walks, rows of 2-hop walks, digest 1, digest 2, traversed edges, frontier entries; the
+ * digests 32-bit sums in the low half) in a buffer owned by the context (*stats_dev; overwritten by the next such call).
+ * For the ranks of a sharded query (gg_csr_build_shard): each rank's words are added by ONE collective on the device
+ * (RCCL SUM through torch.distributed on a view of that memory — the library owns no communicator) and cross to the host
+ * once, instead of host -> device -> all-reduce -> host per rank.  Order the collective's stream behind the library's
+ * with gg_stream_wait. */
+int gg_expand_khop_dev(gg_ctx *ctx, gg_csr *csr, int k_min, void **stats_dev);
+/* Stream ordering without the host: direction 0 — everything queued on `other_stream` (a hipStream_t, e.g. torch's
+ * current stream) from now on waits for everything queued on the context's stream so far; direction 1 — the reverse. */
+int gg_stream_wait(gg_ctx *ctx, void *other_stream, int direction);
 /* Split [0,V) into n_parts contiguous middle-vertex ranges of near-equal product work. */
 int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bounds);
 

@@ -786,8 +786,8 @@ def test_several_substituted_scans_in_one_plan(db):
 
 @pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_the_count_of_two_hop_walks_over_an_ownership_sharded_graph(db, monkeypatch):
-    """GG_DEVICES=N: the one plan shape whose result adds over shards — count(*) of all 2-hop walks — has its
-    tables appended to N device contexts (device p mod the devices present: all on the one GPU here), N CSR shards
+    """GG_DEVICES=N: the plan shape whose result adds (count(*)) or concatenates (rows) over shards — all 2-hop walks —
+    has its tables appended to N device contexts (device p mod the devices present: all on the one GPU here), N CSR shards
     built by gg_csr_build_shard and counted side by side; the counts add.  bench.py's N ranks inside one process,
     reached from the reference's executor.  Every other plan keeps its single graph."""
     d, vid = db
@@ -813,8 +813,13 @@ def test_the_count_of_two_hop_walks_over_an_ownership_sharded_graph(db, monkeypa
                 else:
                     assert "shards" not in d.explain(q)
                 assert np.array_equal(d.execute(q), w), q
-            assert "shards" not in d.explain(rows_sql) and "shards" not in d.explain(_chain(3, "count(*)"))
+            # the ROWS of the 2-hop walks shard the same way (every part materialises the walks whose middle vertex it
+            # owns, the pipeline's threads drain the parts side by side) — also part by part under a tiny budget
+            assert f"shards: {parts}" in d.explain(rows_sql) and "shards" not in d.explain(_chain(3, "count(*)"))
             assert np.array_equal(sort_rows(d.execute(rows_sql)), sort_rows(want_rows))
+            monkeypatch.setenv("GG_RESULT_BUDGET_MB", "1")
+            assert np.array_equal(sort_rows(d.execute(rows_sql)), sort_rows(want_rows))
+            monkeypatch.delenv("GG_RESULT_BUDGET_MB")
             assert np.array_equal(d.execute(_chain(3, "count(*)")), want3)
         # the scan-function route builds the same shards from its own sink pipelines
         monkeypatch.setenv("GG_NO_PIPELINE_SINKS", "1")
