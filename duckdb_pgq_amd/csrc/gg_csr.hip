@@ -1031,13 +1031,10 @@ __global__ __launch_bounds__(256) void k_set_emit(const uint32_t *__restrict__ l
 
 }  // namespace gg
 
-extern "C" int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uint64_t *n_vertices) {
-  if (!ctx) return GG_ERR_INVALID_ARG;
-  if (n_vertices) *n_vertices = 0;
-  GG_TRY(gg_staging_sync(ctx));
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  ApiScope scope(ctx);
-  GG_HIP(hipSetDevice(ctx->device));
+// The general path: a table that grows by a factor of eight until it holds the ids (one host round trip per attempt),
+// three LSD rounds over the ids it found.  Taken when the two-stage table of the fast path overflows or a bucket of its
+// bucket sort is too large for a workgroup (ids clustered far from uniform).  start_cap: first capacity to try.
+static int vertices_from_edges_general(gg_ctx *ctx, int keep_staged_vertices, uint64_t *n_vertices, uint64_t start_cap) {
   hipStream_t s = ctx->stream;
   const uint64_t E = ctx->n_edges;
   const uint64_t n_old = keep_staged_vertices ? ctx->n_vertices : 0;  // ids already in the vertex table
@@ -1053,7 +1050,7 @@ extern "C" int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uin
   // the table starts small (graphs have far fewer vertices than edge rows) and is rebuilt larger when it
   // passes half full; at cap > 2E it cannot fill, so the probe bound is lifted and the loop ends
   uint64_t cap = 1u << 16;
-  while (cap < E / 8 + 2 * n_old) cap <<= 1;
+  while (cap < E / 8 + 2 * n_old || cap < start_cap) cap <<= 1;
   int64_t *set = nullptr;
   SetStatus host{};
   while (true) {
@@ -1108,6 +1105,461 @@ extern "C" int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uin
   GG_TRY(scan_error_fetch(ctx));
   GG_HIP(hipStreamSynchronize(s));
   GG_TRY(scan_error_test(ctx));
+  ctx->n_vertices = V;
+  if (n_vertices) *n_vertices = V;
+  return GG_OK;
+}
+
+namespace gg {
+
+// ---- the fast path of gg_vertices_from_edges ------------------------------------------------------------------------
+// One pass over the edge rows into a table sized for the graph (a vertex occurs ~2E/V times: E/64 slots hold the ids
+// of every LDBC scale at load <= 0.45; 8 MB at SF100 instead of the 64 MB a table sized from E/8 takes — the insert is a
+// random 8-byte probe per endpoint, and what a probe costs is decided by how far the table exceeds an XCD's L2), a
+// second table eight times larger that is only touched if the first overflows (the launch is made either way and
+// returns at once otherwise: no host round trip in between), then the ids are numbered by ONE bucket sort: buckets by
+// linear interpolation between the smallest and the largest id (monotone, so bucket order is id order), each bucket
+// ranked by counting inside a workgroup's LDS.  One synchronisation in all (count, overflow, largest bucket).
+struct SetStatus2 {
+  unsigned long long count[2];     // distinct ids inserted into table 0 / table 1 (atomics: a cache line of their own)
+  unsigned long long pad[14];
+  unsigned long long has_min;      // the id equal to the empty-slot sentinel occurs
+  unsigned long long overflow[2];  // table 0 / 1 got fuller than its limit or a probe sequence exceeded its bound
+  unsigned long long n;            // ids compacted (from whichever table holds them)
+  unsigned long long id_min_u, id_max_u;  // over the compacted ids, sign bit flipped (unsigned order = signed order)
+  unsigned long long max_bucket;   // largest bucket of the bucket sort
+};
+
+// The table is probed two slots at a time: a PAIR of adjacent 8-byte slots is one aligned 16-byte load (what a probe
+// costs is the request, not the bytes), a key's home is a pair, and linear probing moves from pair to pair — at load
+// 0.4 a lookup takes ~1.05 requests instead of the ~1.3 of single slots.
+typedef long long set_ll2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t set_home_pair(int64_t key, uint64_t pairs) {
+  return __umul64hi((uint64_t)key * DIG_GOLD, pairs);
+}
+
+// finish the probe chain of `key` that started at pair `pair` with the values `v` already loaded from it
+__device__ __forceinline__ void set_insert_chain(int64_t key, uint64_t pair, set_ll2 v, int64_t *__restrict__ set,
+                                                 uint64_t pairs, uint32_t max_probes, unsigned long long *overflow,
+                                                 uint32_t *inserted) {
+  uint32_t probes = 0;
+  while (true) {
+    int64_t k0 = v.x, k1 = v.y;
+    if (k0 == key || k1 == key) return;
+    if (k0 == HT_EMPTY) {
+      k0 = (int64_t)atomicCAS((unsigned long long *)&set[2 * pair], (unsigned long long)HT_EMPTY, (unsigned long long)key);
+      if (k0 == HT_EMPTY) {
+        *inserted += 1;
+        return;
+      }
+      if (k0 == key) return;
+      k1 = set[2 * pair + 1];  // (someone else took slot 0 meanwhile: slot 1 may have changed too)
+      if (k1 == key) return;
+    }
+    if (k1 == HT_EMPTY) {
+      k1 = (int64_t)atomicCAS((unsigned long long *)&set[2 * pair + 1], (unsigned long long)HT_EMPTY,
+                              (unsigned long long)key);
+      if (k1 == HT_EMPTY) {
+        *inserted += 1;
+        return;
+      }
+      if (k1 == key) return;
+    }
+    if (++probes > max_probes) {
+      *overflow = 1ULL;
+      return;
+    }
+    // (a table that has overflowed keeps filling under the threads already in flight: their probe runs grow towards
+    //  the bound, so they look at the flag now and then and give up with the others)
+    if ((probes & 15u) == 0 && *(volatile unsigned long long *)overflow != 0ULL) return;
+    pair = pair + 1 == pairs ? 0 : pair + 1;
+    v = *reinterpret_cast<const set_ll2 *>(set + 2 * pair);
+  }
+}
+
+// stage 0 or 1: every edge row's two endpoints and the `n_extra` ids already staged as vertices.  A fixed grid walks the
+// rows in tiles of ROWS x 256: a thread loads the ids of ROWS rows, issues their 2 x ROWS first probes back to back
+// (the kernel is bound by the latency of random 16-byte loads: what counts is how many are in flight) and then
+// finishes the chains.  Stage 1 runs only if stage 0 overflowed.
+// `rows_limit` < E + n_extra: the WARM-UP launch over the first rows with a small grid and one row per thread.  An empty
+// table under the full grid is a storm: the ~4 M probes in flight all find their slot empty and compare-and-swap it —
+// ten (SF100) to a hundred (SF10) device-scope atomics per slot, serialised, and each XCD's L2 keeps the empty lines
+// it fetched meanwhile.  A quarter of a million probes at a time over the first rows fill the table almost without
+// contention (a vertex of degree d is in the first s of E rows with probability 1 - (1 - s/E)^2d), and the full grid
+// then probes a table whose lines are what it reads.
+constexpr int SET_ROWS = 4;
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_set_insert2(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
+                                                     uint64_t E, const int64_t *__restrict__ extra, uint64_t n_extra,
+                                                     uint64_t rows_limit, int64_t *__restrict__ set, uint64_t pairs,
+                                                     uint64_t limit, uint32_t max_probes, int stage,
+                                                     SetStatus2 *__restrict__ st) {
+  __shared__ uint32_t s_new;
+  if (stage == 1 && st->overflow[0] == 0ULL) return;  // (set, if at all, by an earlier kernel: uniform over the grid)
+  if (threadIdx.x == 0) s_new = 0;
+  __syncthreads();
+  const uint64_t rows = E + n_extra < rows_limit ? E + n_extra : rows_limit, tile_rows = (uint64_t)ROWS * 256;
+  uint32_t inserted = 0, trip = 0;
+  bool saw_min = false;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * tile_rows; t0 < rows; t0 += (uint64_t)gridDim.x * tile_rows, trip++) {
+    // (the flag is ONE address read past every cache: polled by every wavefront on every trip it was most of the
+    //  kernel's time.  Every 64th trip will do: an overflowing table is the rare case, and the chains bound themselves)
+    if ((trip & 63u) == 63u && *(volatile unsigned long long *)&st->overflow[stage] != 0ULL) break;
+    int64_t key[2 * ROWS];
+    set_ll2 got[2 * ROWS];
+    uint64_t pair[2 * ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const uint64_t i = t0 + (uint64_t)j * 256 + threadIdx.x;
+      int64_t ka = HT_EMPTY, kb = HT_EMPTY;  // (HT_EMPTY: nothing to insert)
+      if (i >= rows) {
+      } else if (i < E) {
+        ka = src[i];
+        kb = dst[i];
+        saw_min = saw_min || ka == HT_EMPTY || kb == HT_EMPTY;
+        if (kb == ka) kb = HT_EMPTY;
+      } else {
+        ka = extra[i - E];
+        saw_min = saw_min || ka == HT_EMPTY;
+      }
+      key[2 * j] = ka;
+      key[2 * j + 1] = kb;
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * ROWS; q++) {
+      pair[q] = set_home_pair(key[q], pairs);
+      if (key[q] != HT_EMPTY) got[q] = *reinterpret_cast<const set_ll2 *>(set + 2 * pair[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * ROWS; q++)
+      if (key[q] != HT_EMPTY && got[q].x != key[q] && got[q].y != key[q])
+        set_insert_chain(key[q], pair[q], got[q], set, pairs, max_probes, &st->overflow[stage], &inserted);
+    if (ROWS > 1) {
+      // the full grid: new ids are counted per wavefront and tile (behind the warm-up hardly any wavefront has one), so
+      // that a table about to pass its limit is noticed while it still has room
+      uint32_t wave_new = inserted;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wave_new += __shfl_xor(wave_new, o, 64);
+      if ((threadIdx.x & 63) == 0 && wave_new) {
+        const unsigned long long before = atomicAdd(&st->count[stage], (unsigned long long)wave_new);
+        if (before + wave_new > limit) st->overflow[stage] = 1ULL;
+      }
+      inserted = 0;
+    }
+  }
+  if (saw_min) st->has_min = 1ULL;  // benign race: every writer stores the same value
+  if (ROWS == 1) {
+    // the warm-up: nearly every wavefront inserts on nearly every trip, and one counter cannot take an atomic from
+    // each of them (0.4 ms for 2.5 M rows); it is over quickly and bounded (2 x the table's slots in rows), so its
+    // workgroups count in registers and report once
+    uint32_t wave_new = inserted;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wave_new += __shfl_xor(wave_new, o, 64);
+    if ((threadIdx.x & 63) == 0 && wave_new) atomicAdd(&s_new, wave_new);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_new) {
+      const unsigned long long before = atomicAdd(&st->count[stage], (unsigned long long)s_new);
+      if (before + s_new > limit) st->overflow[stage] = 1ULL;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_set_init2(int64_t *__restrict__ set0, uint64_t cap0, SetStatus2 *__restrict__ st) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap0) set0[i] = HT_EMPTY;
+  if (i == 0) {
+    st->count[0] = st->count[1] = st->has_min = st->overflow[0] = st->overflow[1] = st->n = st->max_bucket = 0ULL;
+    st->id_min_u = ~0ull;
+    st->id_max_u = 0ull;
+  }
+}
+
+// the second table is cleared only if it is going to be used
+__global__ __launch_bounds__(256) void k_set_init_stage1(int64_t *__restrict__ set1, uint64_t cap1,
+                                                         const SetStatus2 *__restrict__ st) {
+  if (st->overflow[0] == 0ULL) return;  // (written, if at all, by an earlier kernel: a plain load)
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap1; i += (uint64_t)gridDim.x * blockDim.x)
+    set1[i] = HT_EMPTY;
+}
+
+// non-empty slots of the table that holds the ids -> keys[] (slot order: arbitrary, the sort fixes it), their number,
+// smallest and largest.  Launched once per table; only the launch over the table in use does anything.  A workgroup
+// owns a contiguous range of slots: it counts the live ones, reserves its piece of keys[] with ONE atomic (an atomic
+// per 256 slots on one counter was most of an earlier form's 160 us) and reads the range again (L2-hot) to write.
+__global__ __launch_bounds__(256) void k_set_compact2(const int64_t *__restrict__ set, uint64_t cap, int stage,
+                                                      SetStatus2 *__restrict__ st, int64_t *__restrict__ keys,
+                                                      uint64_t keys_cap) {
+  __shared__ uint32_t s_cnt[4];
+  __shared__ unsigned long long s_base, s_lo[4], s_hi[4];
+  // (the flags were written by earlier kernels: plain loads — read past the caches, one address under 4 096 workgroups,
+  //  they were most of this kernel's 280 us)
+  const bool second = st->overflow[0] != 0ULL;
+  if ((int)second != stage) return;
+  if (second && st->overflow[1] != 0ULL) return;  // nothing usable: the host retries
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t per = ((cap + gridDim.x - 1) / gridDim.x + 255) & ~255ull;  // slots per workgroup, whole trips
+  const uint64_t r_lo = per * blockIdx.x, r_hi = r_lo + per < cap ? r_lo + per : cap;
+  // smallest / largest id: sign-flipped to unsigned order (native 64-bit atomics; the signed forms are CAS loops, and
+  // ten thousand waves on one address took 3 ms in them), reduced over the workgroup first
+  unsigned long long lo = ~0ull, hi = 0ull;
+  uint32_t mine = 0;
+  for (uint64_t i = r_lo + threadIdx.x; i < r_hi; i += 256) {
+    const int64_t k = set[i];
+    if (k != HT_EMPTY) {
+      const unsigned long long u = (unsigned long long)k ^ 0x8000000000000000ull;
+      lo = u < lo ? u : lo;
+      hi = u > hi ? u : hi;
+      mine++;
+    }
+  }
+  uint32_t wsum = mine;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long lo2 = __shfl_xor(lo, o, 64), hi2 = __shfl_xor(hi, o, 64);
+    lo = lo2 < lo ? lo2 : lo;
+    hi = hi2 > hi ? hi2 : hi;
+    wsum += __shfl_xor(wsum, o, 64);
+  }
+  if (lane == 0) {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+    s_cnt[wave] = wsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = tot ? atomicAdd(&st->n, (unsigned long long)tot) : 0ULL;
+    unsigned long long l = s_lo[0], h = s_hi[0];
+    for (int w = 1; w < 4; w++) {
+      l = s_lo[w] < l ? s_lo[w] : l;
+      h = s_hi[w] > h ? s_hi[w] : h;
+    }
+    if (tot) {
+      atomicMin(&st->id_min_u, l);
+      atomicMax(&st->id_max_u, h);
+    }
+  }
+  __syncthreads();
+  uint64_t pos = s_base;
+  for (uint64_t i0 = r_lo; i0 < r_hi; i0 += 256) {  // (uniform trip count)
+    const uint64_t i = i0 + threadIdx.x;
+    const int64_t k = i < r_hi ? set[i] : HT_EMPTY;
+    const bool live = k != HT_EMPTY;
+    const uint64_t m = __ballot(live);
+    __syncthreads();  // (the trip before is done with s_cnt)
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) before += s_cnt[w];
+      all += s_cnt[w];
+    }
+    if (live) {
+      const uint64_t p = pos + before + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+      if (p < keys_cap) keys[p] = k;
+    }
+    pos += all;
+  }
+}
+
+// bucket of an id: floor((id - min) * B / (span + 1)) in double arithmetic — conversions, the product with a positive
+// constant and the floor are all monotone, so a larger id never lands in a smaller bucket; clamped to B - 1
+__device__ __forceinline__ uint32_t id_bucket(int64_t id, unsigned long long id_min_u, double scale, uint32_t B) {
+  const double x = (double)(((unsigned long long)id ^ 0x8000000000000000ull) - id_min_u) * scale;
+  const unsigned long long b = (unsigned long long)x;
+  return b >= B ? B - 1 : (uint32_t)b;
+}
+
+// SET_WG workgroups, each over a contiguous slice of the ids: bucket sizes in LDS, then ONE returning atomic per
+// (workgroup, bucket) reserves the workgroup's range inside the bucket (base[wg][b]) — 448 k atomics onto 1 200
+// addresses took 90 us, 64 x 1 200 take none to speak of
+constexpr uint32_t SET_WG = 64, SET_MAX_B = 8192;
+__global__ __launch_bounds__(1024) void k_set_bucket_hist(const int64_t *__restrict__ keys, const SetStatus2 *__restrict__ st,
+                                                          uint32_t B, uint32_t *__restrict__ hist,
+                                                          uint32_t *__restrict__ base) {
+  __shared__ uint32_t s_cnt[SET_MAX_B];
+  const uint64_t n = st->n, per = (n + SET_WG - 1) / SET_WG;
+  const uint64_t lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  const unsigned long long id_min_u = st->id_min_u;
+  const double scale = (double)B / ((double)(st->id_max_u - id_min_u) + 1.0);
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) s_cnt[b] = 0;
+  __syncthreads();
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) atomicAdd(&s_cnt[id_bucket(keys[i], id_min_u, scale, B)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) {
+    const uint32_t c = s_cnt[b];
+    base[(size_t)blockIdx.x * B + b] = c ? atomicAdd(&hist[b], c) : 0u;
+  }
+}
+
+// one workgroup: exclusive scan of the B bucket sizes into start[0..B], largest bucket -> status
+__global__ __launch_bounds__(1024) void k_set_bucket_scan(const uint32_t *__restrict__ hist, uint32_t B,
+                                                          uint32_t *__restrict__ start, SetStatus2 *__restrict__ st) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry, s_max;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0, s_max = 0;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (uint32_t b0 = 0; b0 < B; b0 += 1024) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < B ? hist[i] : 0;
+    mx = v > mx ? v : mx;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = s_carry;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    if (i < B) start[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = before + incl;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if (lane == 0) atomicMax(&s_max, mx);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    start[B] = s_carry;
+    st->max_bucket = s_max;
+  }
+}
+
+// the same slices: an id goes to start[b] + base[wg][b] + its rank among the workgroup's ids of that bucket (an LDS
+// counter; order inside a bucket is whatever — it is sorted next)
+__global__ __launch_bounds__(1024) void k_set_bucket_scatter(const int64_t *__restrict__ keys,
+                                                             const SetStatus2 *__restrict__ st, uint32_t B,
+                                                             const uint32_t *__restrict__ start,
+                                                             const uint32_t *__restrict__ base, int64_t *__restrict__ out) {
+  __shared__ uint32_t s_cnt[SET_MAX_B];
+  const uint64_t n = st->n, per = (n + SET_WG - 1) / SET_WG;
+  const uint64_t lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  const unsigned long long id_min_u = st->id_min_u;
+  const double scale = (double)B / ((double)(st->id_max_u - id_min_u) + 1.0);
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) s_cnt[b] = 0;
+  __syncthreads();
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    const int64_t k = keys[i];
+    const uint32_t b = id_bucket(k, id_min_u, scale, B);
+    out[(uint64_t)start[b] + base[(size_t)blockIdx.x * B + b] + atomicAdd(&s_cnt[b], 1u)] = k;
+  }
+}
+
+// one workgroup per bucket: the ids are distinct, so the rank of an id is the number of smaller ids in its bucket
+constexpr uint32_t SET_BUCKET_CAP = 4096;
+__global__ __launch_bounds__(256) void k_set_bucket_sort(const int64_t *__restrict__ in, const uint32_t *__restrict__ start,
+                                                         uint32_t has_min, int64_t *__restrict__ vid) {
+  __shared__ int64_t s_key[SET_BUCKET_CAP];
+  const uint32_t lo = start[blockIdx.x], m = start[blockIdx.x + 1] - lo;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && has_min) vid[0] = HT_EMPTY;  // INT64_MIN sorts first
+  for (uint32_t i = threadIdx.x; i < m; i += 256) s_key[i] = in[lo + i];
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < m; i += 256) {
+    const int64_t k = s_key[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < m; j++) rank += s_key[j] < k;  // (LDS broadcast reads)
+    vid[(uint64_t)has_min + lo + rank] = k;
+  }
+}
+
+}  // namespace gg
+
+extern "C" int gg_vertices_from_edges(gg_ctx *ctx, int keep_staged_vertices, uint64_t *n_vertices) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  if (n_vertices) *n_vertices = 0;
+  GG_TRY(gg_staging_sync(ctx));
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ApiScope scope(ctx);
+  GG_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t E = ctx->n_edges;
+  const uint64_t n_old = keep_staged_vertices ? ctx->n_vertices : 0;  // ids already in the vertex table
+  if (E == 0 || ctx->legacy_build) return vertices_from_edges_general(ctx, keep_staged_vertices, n_vertices, 0);
+
+  // two tables: E/48 slots (at least 2^16) and eight times that; they may fill to 7/8 and 3/4 (probes look at a PAIR
+  // of slots per request: ~1.2 requests per lookup at that load).  What a probe costs is decided by how far the table
+  // exceeds an XCD's 4 MB of L2 (profiles/r03_ubench_gather_sizes.txt: 546 / 650 / 785 us for 80 M probes of a 4 / 6.4 /
+  // 8 MB table), so the first table is cut for graphs like LDBC's knows at the large scales (64+ rows per person: 6.6 MB
+  // at SF100, load 0.54) and sparser ones pay for the second attempt — made on the device, without the host.
+  uint64_t cap0 = 1u << 16;
+  if (cap0 < E / 48 + 2 * n_old) cap0 = (E / 48 + 2 * n_old + 1) & ~1ull;  // (slots come in pairs)
+  const uint64_t cap1 = 8 * cap0;
+  const uint64_t lim0 = cap0 / 8 * 7, lim1 = cap1 / 4 * 3;  // (LDBC SF10 has 58 rows per person: load 0.82 of the first table)
+  const uint64_t keys_cap = lim1 + 2048;
+  const uint32_t B = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap0 / 512, 64), SET_MAX_B);  // ~<= 320 ids per bucket
+  SetStatus2 *st = nullptr;
+  int64_t *set0 = nullptr, *set1 = nullptr, *keys = nullptr, *sorted_in = nullptr;
+  uint32_t *hist = nullptr, *start = nullptr, *base = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&st, sizeof(SetStatus2)));
+  GG_TRY(ctx->dev_alloc((void **)&set0, cap0 * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&set1, cap1 * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&keys, keys_cap * sizeof(int64_t)));
+  GG_TRY(ctx->dev_alloc((void **)&hist, (size_t)B * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&start, ((size_t)B + 1) * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&base, (size_t)SET_WG * B * sizeof(uint32_t)));
+  GG_HIP(hipMemsetAsync(hist, 0, (size_t)B * sizeof(uint32_t), s));
+  const unsigned rows_grid = (unsigned)std::min<uint64_t>((E + n_old + SET_ROWS * 256 - 1) / (SET_ROWS * 256), 256 * 16);
+  // (probe runs are bounded at 64: at load <= 0.625 a longer one means the hash clusters these ids — the next stage,
+  //  or the general path with its unbounded probes, takes over)
+  GG_LAUNCH(ctx, "set_init", k_set_init2, dim3((unsigned)((cap0 + 255) / 256)), dim3(256), 0, set0, cap0, st);
+  const uint64_t warm_rows = std::min<uint64_t>(E, cap0 + cap0 / 2);
+  GG_LAUNCH(ctx, "set_warm", k_set_insert2<1>, dim3(1024), dim3(256), 0, (const int64_t *)ctx->c_src.dev,
+            (const int64_t *)ctx->c_dst.dev, E, (const int64_t *)ctx->c_vid.dev, n_old, warm_rows, set0, cap0 / 2, lim0, 64u, 0, st);
+  GG_LAUNCH(ctx, "set_insert", k_set_insert2<SET_ROWS>, dim3(rows_grid), dim3(256), 0, (const int64_t *)ctx->c_src.dev,
+            (const int64_t *)ctx->c_dst.dev, E, (const int64_t *)ctx->c_vid.dev, n_old, ~0ull, set0, cap0 / 2, lim0, 64u, 0, st);
+  GG_LAUNCH(ctx, "set_init", k_set_init_stage1, dim3(2048), dim3(256), 0, set1, cap1, (const SetStatus2 *)st);
+  GG_LAUNCH(ctx, "set_warm", k_set_insert2<1>, dim3(1024), dim3(256), 0, (const int64_t *)ctx->c_src.dev,
+            (const int64_t *)ctx->c_dst.dev, E, (const int64_t *)ctx->c_vid.dev, n_old, cap1 + cap1 / 2, set1, cap1 / 2, lim1, 64u, 1, st);
+  GG_LAUNCH(ctx, "set_insert", k_set_insert2<SET_ROWS>, dim3(rows_grid), dim3(256), 0, (const int64_t *)ctx->c_src.dev,
+            (const int64_t *)ctx->c_dst.dev, E, (const int64_t *)ctx->c_vid.dev, n_old, ~0ull, set1, cap1 / 2, lim1, 64u, 1, st);
+  GG_LAUNCH(ctx, "set_compact", k_set_compact2, dim3((unsigned)std::min<uint64_t>((cap0 + 255) / 256, 1024)), dim3(256), 0,
+            (const int64_t *)set0, cap0, 0, st, keys, keys_cap);
+  GG_LAUNCH(ctx, "set_compact", k_set_compact2, dim3((unsigned)std::min<uint64_t>((cap1 + 255) / 256, 1024)), dim3(256), 0,
+            (const int64_t *)set1, cap1, 1, st, keys, keys_cap);
+  GG_LAUNCH(ctx, "set_bucket_hist", k_set_bucket_hist, dim3(SET_WG), dim3(1024), 0, (const int64_t *)keys,
+            (const SetStatus2 *)st, B, hist, base);
+  GG_LAUNCH(ctx, "set_bucket_scan", k_set_bucket_scan, dim3(1), dim3(1024), 0, (const uint32_t *)hist, B, start, st);
+  GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(SetStatus2), hipMemcpyDeviceToHost, s));
+  GG_HIP(hipStreamSynchronize(s));
+  SetStatus2 host;
+  memcpy(&host, ctx->pin_scratch, sizeof(SetStatus2));
+  const bool second = host.overflow[0] != 0;
+  if ((second && host.overflow[1]) || host.max_bucket > SET_BUCKET_CAP) {
+    // more ids than both tables hold, or ids too clustered for the bucket sort: the general path
+    ctx->dev_free(set0);
+    ctx->dev_free(set1);
+    ctx->dev_free(keys);
+    return vertices_from_edges_general(ctx, keep_staged_vertices, n_vertices, second && host.overflow[1] ? 8 * cap1 : 0);
+  }
+  const uint64_t n = host.n, has_min = host.has_min ? 1 : 0, V = n + has_min;
+  if (!keep_staged_vertices) ctx->n_vertices = 0;
+  ctx->fill_v = 0;
+  if (V >= (uint64_t)INVALID_U32) {
+    set_error("more than 2^32-2 distinct endpoint ids are not supported");
+    return GG_ERR_TOO_LARGE;
+  }
+  GG_TRY(grow_column(ctx, ctx->c_vid, 0, V));
+  if (n) {
+    GG_TRY(ctx->dev_alloc((void **)&sorted_in, n * sizeof(int64_t)));
+    GG_LAUNCH(ctx, "set_bucket_scatter", k_set_bucket_scatter, dim3(SET_WG), dim3(1024), 0, (const int64_t *)keys,
+              (const SetStatus2 *)st, B, (const uint32_t *)start, (const uint32_t *)base, sorted_in);
+    GG_LAUNCH(ctx, "set_bucket_sort", k_set_bucket_sort, dim3(B), dim3(256), 0, (const int64_t *)sorted_in,
+              (const uint32_t *)start, (uint32_t)has_min, (int64_t *)ctx->c_vid.dev);
+  } else if (has_min) {
+    const int64_t only = HT_EMPTY;  // has_min with nothing else
+    memcpy(ctx->pin_scratch, &only, sizeof(only));
+    GG_HIP(hipMemcpyAsync(ctx->c_vid.dev, ctx->pin_scratch, sizeof(only), hipMemcpyHostToDevice, s));
+    GG_HIP(hipStreamSynchronize(s));  // (pin_scratch is reused by the next call)
+  }
+  // no synchronisation: the build that follows is queued on the same stream behind these kernels
   ctx->n_vertices = V;
   if (n_vertices) *n_vertices = V;
   return GG_OK;

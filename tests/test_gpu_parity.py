@@ -736,7 +736,10 @@ def test_build_without_edge_rowid(gg, orc):
         gg.set_edge_rowid(True)
 
 
-@pytest.mark.parametrize("V,E,seed", [(1, 3, 1), (7, 30, 2), (500, 9000, 3), (70000, 300000, 4), (200000, 150000, 5)])
+# (the last three: more ids than the first table holds — the second one takes them; more than both — the general path;
+#  an LDBC shape, where the first table is sized to be just enough)
+@pytest.mark.parametrize("V,E,seed", [(1, 3, 1), (7, 30, 2), (500, 9000, 3), (70000, 300000, 4), (200000, 150000, 5),
+                                      (600000, 1000000, 6), (65645, 3877032, 7)])
 def test_vertices_from_edges_is_the_sorted_distinct_endpoint_set(gg, orc, V, E, seed):
     """Join chains over an edge table alone: vertex table := distinct endpoints, ascending (gg.h)."""
     _, src, dst = datagen.small_graph(V, E, seed)
@@ -752,6 +755,31 @@ def test_vertices_from_edges_is_the_sorted_distinct_endpoint_set(gg, orc, V, E, 
     assert csr.dropped == 0 and csr.E == src.size
     k_max = 3 if E <= 30000 else 2
     assert gg.expand_khop(csr, 1, k_max) == g.khop(1, k_max)
+    csr.close()
+    g.close()
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_vertices_from_edges_with_clustered_ids_and_on_the_general_path(gg, orc, legacy):
+    """Ids far from uniform — 100 000 consecutive ones and two outliers 2^62 apart — put nearly every id into one bucket
+    of the interpolating bucket sort: the call must notice and take the general path (LSD rounds).  With the multi-pass
+    build forced the general path is taken from the start.  Same vertex table either way."""
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([np.arange(100_000, dtype=np.int64) * 3 + 17, np.array([-(1 << 62), 1 << 62], np.int64)])
+    src = ids[rng.integers(0, ids.size, 400_000)]
+    dst = ids[rng.integers(0, ids.size, 400_000)]
+    src[:2], dst[:2] = ids[-2:], ids[-2:][::-1]
+    gg.staging_clear()
+    gg.force_legacy_build(legacy)
+    gg.append_edges(src, dst)
+    n = gg.vertices_from_edges()
+    expect = np.unique(np.concatenate([src, dst]))
+    assert n == expect.size
+    csr = gg.build_csr()
+    _, _, _, vid = csr.export()
+    assert np.array_equal(vid, expect)
+    rc, g = orc.csr_build(expect, src, dst, None)
+    assert rc == 0 and gg.expand_khop(csr, 1, 2) == g.khop(1, 2)
     csr.close()
     g.close()
 
