@@ -543,13 +543,19 @@ PhysicalGGPathExpand::PhysicalGGPathExpand(shared_ptr<GGGraph> graph_p, int k_mi
       all_sources(all_sources_p), rows_only(rows_only_p && count_only_p) {
 }
 
+//! A source list for the C-ABI: an EMPTY list must not arrive as a null pointer (gg.h: null means every vertex).
+static const int64_t *SourceIds(const vector<int64_t> &sources) {
+	static const int64_t none = 0;
+	return sources.empty() ? &none : sources.data();
+}
+
 //! Row counts per walk length from degrees (gg_khop_count) in the shape the counting expansion reports them:
 //! digests 0, traversed edges = the rows of every length up to k_max (one adjacency entry per row).
 static void CountRowsFromDegrees(gg_ctx *ctx, const gg_csr *csr, const vector<int64_t> &sources, bool all_sources,
                                  int k_min, int k_max, gg_khop_stats &stats) {
 	memset(&stats, 0, sizeof(stats));
 	uint64_t rows[GG_MAX_HOPS + 1];
-	GGGraph::Check(gg_khop_count(ctx, csr, all_sources ? nullptr : sources.data(), sources.size(), 1, k_max, rows),
+	GGGraph::Check(gg_khop_count(ctx, csr, all_sources ? nullptr : SourceIds(sources), sources.size(), 1, k_max, rows),
 	               "gg_khop_count");
 	for (int h = 1; h <= k_max; h++) {
 		stats.traversed_edges += rows[h];
@@ -657,7 +663,7 @@ unique_ptr<GlobalSourceState> PhysicalGGPathExpand::GetGlobalSourceState(ClientC
 	// count first: cheap (nothing is written), and it tells how much HBM the walks would take — from degrees when
 	// the rows are wanted (their digest is nobody's business then), by the counting expansion for gg_path_count
 	if (count_only) {
-		GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(),
+		GGGraph::Check(gg_expand_khop(graph->ctx, graph->csr, all_sources ? nullptr : SourceIds(sources), sources.size(),
 		                              k_min, k_max, 0, &state->stats, nullptr),
 		               "gg_expand_khop");
 		state->hop = k_min;
@@ -875,7 +881,7 @@ unique_ptr<GlobalSourceState> PhysicalGGFilteredPaths::GetGlobalSourceState(Clie
 	}
 	gg_khop_stats stats;
 	gg_result *paths = nullptr;
-	GGGraph::Check(gg_expand_khop_result(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(),
+	GGGraph::Check(gg_expand_khop_result(graph->ctx, graph->csr, all_sources ? nullptr : SourceIds(sources),
 	                                     all_sources ? 0 : sources.size(), hops, hops, &stats, &paths),
 	               "gg_expand_khop_result");
 	int rc = gg_result_filter_common_neighbour(graph->ctx, paths, hops, graph->filter_csr, &state->result);
@@ -975,7 +981,7 @@ unique_ptr<GlobalSourceState> PhysicalGGPathEdges::GetGlobalSourceState(ClientCo
 	// count first (from degrees: nothing is written) — the walks with their edges take (2 * hops + 1) int64 columns
 	// at the last level plus the level tables below it (dense u32 columns: about half as much again)
 	uint64_t rows[GG_MAX_HOPS + 1];
-	GGGraph::Check(gg_khop_count(graph->ctx, graph->csr, all_sources ? nullptr : sources.data(), sources.size(), 1, hops,
+	GGGraph::Check(gg_khop_count(graph->ctx, graph->csr, all_sources ? nullptr : SourceIds(sources), sources.size(), 1, hops,
 	                             rows),
 	               "gg_khop_count");
 	uint64_t bytes = rows[hops] * (uint64_t)(2 * hops + 1) * sizeof(int64_t);

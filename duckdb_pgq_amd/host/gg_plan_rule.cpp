@@ -84,11 +84,17 @@
 #include "gg_pipeline.hpp"
 #include "gg_plan_hook.h"
 // The rule needs the ClientContext a plan is made for (the switches are per connection), and the generator keeps
-// it private.  Included last, so that only this one class definition is read with the access specifier widened;
-// the layout does not change.
+// it private.  A reference with oracle/callout.patch hands it to the call-out (PlanCallouts::plan_fn), so the build
+// for that reference (-DGG_REFERENCE_CALLOUTS) reads the class as it is.  Behind the interposition shim — a stock
+// reference — there is nobody to hand it over: the header is included last, so that only this one class definition
+// is read with the access specifier widened; the layout does not change.
+#ifdef GG_REFERENCE_CALLOUTS
+#include "duckdb/execution/physical_plan_generator.hpp"
+#else
 #define private public
 #include "duckdb/execution/physical_plan_generator.hpp"
 #undef private
+#endif
 
 namespace duckdb {
 
@@ -1446,6 +1452,61 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 	return move(projection);
 }
 
+//! count(*) over ONE inner equi-join of two base tables on an integer key, `probe.x = build.y` with duplicates on
+//! either side (test/sql/join/inner/test_join_duplicates.test:14-24: 10 240 build rows under one key): the build table
+//! is the adjacency index keyed on y (every row an entry under its key), the probe table's x column is the source
+//! list, and the join's cardinality is the number of 1-hop walks from it — the sum over the probe rows of the degree
+//! of their key (gg_khop_count), as PhysicalHashJoin's probe would emit and count them
+//! (src/execution/join_hashtable.cpp:304-476).  NULL keys join nothing on either side (the sinks skip them).
+unique_ptr<PhysicalOperator> MakeKeyJoinCountScan(PatternInput &in) {
+	if (in.leaves.size() != 2 || in.equalities.size() != 1 || !in.constants.empty() || !in.filters.empty() ||
+	    !in.aliases.empty()) {
+		return nullptr;
+	}
+	auto a = in.equalities[0].first, b = in.equalities[0].second;
+	if (a.leaf == b.leaf) {
+		return nullptr;
+	}
+	if (a.leaf != 0) {
+		std::swap(a, b);
+	}
+	auto probe_table = in.leaves[a.leaf].table, build_table = in.leaves[b.leaf].table;
+	if (!ColumnIsIntegerKey(*probe_table, a.column) || !ColumnIsIntegerKey(*build_table, b.column)) {
+		return nullptr;
+	}
+	GGGraphSpec spec;
+	spec.edges = TableColumns(build_table, {b.column, b.column}); // (key -> key: only the degree of a key matters)
+	const auto probe = TableColumns(probe_table, {a.column});
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = GGBuildGraph(context, spec);
+		opened.source = make_unique<PhysicalGGPathExpand>(opened.graph, 1, 1, true, GGScanInt64Column(context, probe), false,
+		                                                  0, true);
+	};
+	data->description = build_table->name + "." + build_table->columns[b.column].name + "\nprobed with " +
+	                    probe_table->name + "." + probe_table->columns[a.column].name + "\n1 hop";
+	data->parallel_result = false;
+	auto types = PhysicalGGPathExpand::OutputTypes(1, true);
+	g_rules_fired++;
+	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {
+		return GGMakeGraphScan(
+		    spec, move(types), "GG_JOIN_COUNT", data->description, false,
+		    [=](ClientContext &context, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+			    return make_unique<PhysicalGGPathExpand>(move(graph), 1, 1, true, GGScanInt64Column(context, probe), false, 0,
+			                                             true);
+		    },
+		    1);
+	}
+	vector<column_t> column_ids;
+	vector<string> names;
+	for (idx_t c = 0; c < types.size(); c++) {
+		column_ids.push_back(c);
+		names.push_back("c" + to_string(c));
+	}
+	return make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_join_count"), move(data), move(column_ids),
+	                                      move(names), nullptr, 1);
+}
+
 //! Aggregate rule: ungrouped count(*) over a walk pattern.
 unique_ptr<PhysicalOperator> PlanCountOverJoinChain(LogicalAggregate &op) {
 	if (!op.groups.empty() || !op.grouping_functions.empty() || op.grouping_sets.size() > 1 || op.expressions.empty() ||
@@ -1471,7 +1532,11 @@ unique_ptr<PhysicalOperator> PlanCountOverJoinChain(LogicalAggregate &op) {
 	}
 	PatternInput in;
 	WalkPattern pattern;
-	if (!CollectJoinTree(*child, in) || !SolveWalkPattern(in, pattern) || !pattern.residual.empty()) {
+	if (!CollectJoinTree(*child, in)) {
+		return nullptr;
+	}
+	const bool is_walk = SolveWalkPattern(in, pattern);
+	if (is_walk && !pattern.residual.empty()) {
 		return nullptr; // (with a residual predicate the walks must be looked at: the join rule takes the join)
 	}
 	// scan columns: (hops, rows, digest, traversed_edges), one row; every count(*) is `rows`
@@ -1485,7 +1550,10 @@ unique_ptr<PhysicalOperator> PlanCountOverJoinChain(LogicalAggregate &op) {
 	if (op.types.size() != op.expressions.size()) {
 		return nullptr;
 	}
-	auto scan = MakeExpandScan(pattern, true, 1);
+	auto scan = is_walk ? MakeExpandScan(pattern, true, 1) : MakeKeyJoinCountScan(in);
+	if (!scan) {
+		return nullptr;
+	}
 	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), 1);
 	projection->children.push_back(move(scan));
 	return move(projection);
@@ -2202,14 +2270,16 @@ unique_ptr<PhysicalOperator> PlanAggregate(LogicalAggregate &op) {
 	return PlanShortestPath(op);
 }
 
+//! The rule RULE offered the logical operator, for the connection `context` (dependencies and rec_ctes are public
+//! members of the generator).
 template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
-int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
-	if (!GGGetConnectionFlags(((PhysicalPlanGenerator *)generator)->context).rules) {
+int RuleEntryFor(ClientContext &context, void *ret_slot, void *generator, void *logical_operator) {
+	if (!GGGetConnectionFlags(context).rules) {
 		return 0; // PRAGMA enable_gpu_graph was not issued on THIS connection
 	}
 	unique_ptr<PhysicalOperator> plan;
 	g_plan_tables.clear();
-	g_plan_context = &((PhysicalPlanGenerator *)generator)->context;
+	g_plan_context = &context;
 	try {
 		plan = RULE(*(OP *)logical_operator);
 	} catch (std::exception &) {
@@ -2231,12 +2301,20 @@ int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
 	return 1;
 }
 
-//! The same rules behind the call-outs of a patched reference (oracle/callout.patch, INTEGRATION.md §3):
-//! unique_ptr<PhysicalOperator> (*)(PhysicalPlanGenerator &, LogicalOperator &), null = not taken over
+#ifndef GG_REFERENCE_CALLOUTS
+//! Behind the interposition shim (gg_plan_hook.c): the generator is all there is, its connection read past `private`
 template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
-unique_ptr<PhysicalOperator> CalloutEntry(PhysicalPlanGenerator &generator, LogicalOperator &op) {
+int RuleEntry(void *ret_slot, void *generator, void *logical_operator) {
+	return RuleEntryFor<OP, RULE>(((PhysicalPlanGenerator *)generator)->context, ret_slot, generator, logical_operator);
+}
+#endif
+
+//! The same rules behind the call-outs of a patched reference (oracle/callout.patch, INTEGRATION.md §3):
+//! unique_ptr<PhysicalOperator> (*)(ClientContext &, PhysicalPlanGenerator &, LogicalOperator &), null = not taken over
+template <class OP, unique_ptr<PhysicalOperator> (*RULE)(OP &)>
+unique_ptr<PhysicalOperator> CalloutEntry(ClientContext &context, PhysicalPlanGenerator &generator, LogicalOperator &op) {
 	typename std::aligned_storage<sizeof(unique_ptr<PhysicalOperator>), alignof(unique_ptr<PhysicalOperator>)>::type slot;
-	if (!RuleEntry<OP, RULE>(&slot, &generator, &op)) {
+	if (!RuleEntryFor<OP, RULE>(context, &slot, &generator, &op)) {
 		return nullptr;
 	}
 	auto made = reinterpret_cast<unique_ptr<PhysicalOperator> *>(&slot);
@@ -2297,7 +2375,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 	// A reference built with oracle/callout.patch exports the registration of its call-outs: the maintainers' route —
 	// no interposition, no access to private members (the BuildPipelines case and the write observation are then the
 	// executor's own code, src/parallel/executor.cpp as patched)
-	using plan_fn = unique_ptr<PhysicalOperator> (*)(PhysicalPlanGenerator &, LogicalOperator &);
+	using plan_fn = unique_ptr<PhysicalOperator> (*)(ClientContext &, PhysicalPlanGenerator &, LogicalOperator &);
 	using write_fn = void (*)(idx_t);
 	auto callouts = (void (*)(plan_fn, plan_fn, plan_fn, write_fn))dlsym(RTLD_DEFAULT, "duckdb_register_plan_callouts");
 	if (callouts) {
@@ -2307,6 +2385,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 		GGPipelineSinksNative();
 		return;
 	}
+#ifndef GG_REFERENCE_CALLOUTS
 	// otherwise the interposition shim, if it was loaded before libduckdb; without either the extension only offers
 	// its table functions
 	auto reg = (int (*)(int, gg_plan_rule_fn))dlsym(RTLD_DEFAULT, "gg_plan_hook_register");
@@ -2321,6 +2400,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 	reg(GG_PLAN_HOOK_DELETE, WriteObserver<LogicalDelete>);
 	reg(GG_PLAN_HOOK_UPDATE, WriteObserver<LogicalUpdate>);
 	// GG_PLAN_RULE=1 in the environment is the default of connections that issue no pragma (gg_duckdb_extension.cpp)
+#endif
 }
 
 } // namespace duckdb

@@ -35,3 +35,54 @@ extern "C" int ggref_append_int64_columns(void *c_api_connection, const char *ta
     return 1;
   }
 }
+
+// A query's result as text, whatever its column types (the C API of this reference cannot return DECIMAL or HUGEINT
+// columns): values by Value::ToString(), NULL as an empty field flagged in `nulls`, booleans as 1 / 0 — the
+// conversion of the reference's own sqllogictest runner (test/sqlite/test_sqllogictest.cpp:306-336), for
+// tests/test_reference_vectors.py.  Layout of *out (malloc'd, the caller frees it with ggref_free): fields separated
+// by '\x1f', rows by '\x1e'; a NULL field is the single byte '\x00'.  Returns 0, or 1 with the error text in err.
+#include <cstdlib>
+#include <cstring>
+
+extern "C" int ggref_query_text(void *c_api_connection, const char *sql, char **out, uint64_t *out_len, uint64_t *n_rows,
+                                uint64_t *n_cols, char *err, int errlen) {
+  auto fail = [&](const std::string &m) {
+    if (err && errlen > 0) {
+      size_t n = m.size() < (size_t)errlen - 1 ? m.size() : (size_t)errlen - 1;
+      m.copy(err, n);
+      err[n] = 0;
+    }
+    return 1;
+  };
+  try {
+    auto *con = (duckdb::Connection *)c_api_connection;
+    auto result = con->Query(sql);
+    if (!result->success) return fail(result->error);
+    std::string buf;
+    const duckdb::idx_t rows = result->collection.Count(), cols = result->ColumnCount();
+    for (duckdb::idx_t r = 0; r < rows; r++) {
+      for (duckdb::idx_t c = 0; c < cols; c++) {
+        auto value = result->GetValue(c, r);
+        if (value.is_null) {
+          buf.push_back('\0');
+        } else if (result->types[c].id() == duckdb::LogicalTypeId::BOOLEAN) {
+          buf += value.value_.boolean ? "1" : "0";
+        } else {
+          buf += value.ToString();
+        }
+        buf.push_back(c + 1 < cols ? '\x1f' : '\x1e');
+      }
+    }
+    *out = (char *)malloc(buf.size() + 1);
+    memcpy(*out, buf.data(), buf.size());
+    (*out)[buf.size()] = 0;
+    *out_len = buf.size();
+    *n_rows = rows;
+    *n_cols = cols;
+    return 0;
+  } catch (std::exception &e) {
+    return fail(e.what());
+  }
+}
+
+extern "C" void ggref_free(void *p) { free(p); }

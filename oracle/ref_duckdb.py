@@ -134,6 +134,28 @@ class RefDuckDB:
         self.L.duckdb_destroy_result(C.byref(r))
         return rows
 
+    def query_text(self, sql: str) -> list:
+        """Run sql through the reference's C++ API (oracle/ref_driver.cpp: every column type, DECIMAL and HUGEINT
+        included, which its C API of this vintage cannot return); rows as tuples of strings, None for NULL,
+        booleans as 1 / 0 — the value conversion of the reference's own sqllogictest runner."""
+        out, n, rows, cols = C.c_char_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        err = C.create_string_buffer(1024)
+        self.G.ggref_query_text.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
+        self.G.ggref_free.argtypes = [C.c_void_p]
+        raw = C.c_void_p()
+        rc = self.G.ggref_query_text(self.con, sql.encode(), C.cast(C.byref(raw), C.POINTER(C.c_char_p)), C.byref(n),
+                                     C.byref(rows), C.byref(cols), err, 1024)
+        if rc != 0:
+            raise RuntimeError(f"reference query failed: {err.value.decode(errors='replace')}")
+        data = C.string_at(raw, n.value)
+        self.G.ggref_free(raw)
+        result = []
+        if rows.value:
+            for line in data.split(b"\x1e")[:-1]:
+                result.append(tuple(None if f == b"\x00" else f.decode(errors="replace") for f in line.split(b"\x1f")))
+        return result
+
     def explain(self, sql: str) -> str:
         """Physical plan of sql as text (EXPLAIN's second column)."""
         r = _Result()

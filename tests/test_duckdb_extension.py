@@ -785,6 +785,43 @@ def test_several_substituted_scans_in_one_plan(db):
 
 
 @pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
+def test_count_of_a_single_key_join_is_a_sum_of_degrees(db):
+    """count(*) over ONE inner equi-join on an integer key — duplicates on both sides, NULL keys, INTEGER and BIGINT
+    columns, an empty side, the same table on both sides — planned as GG_JOIN_COUNT (build side = adjacency index keyed
+    on its column, probe side = source list, rows = 1-hop walks counted from degrees); the reference's own vector for
+    it is test/sql/join/inner/test_join_duplicates.test:14-24 (tests/test_reference_vectors.py replays it)."""
+    d, vid = db
+    d.execute("CREATE TABLE IF NOT EXISTS jl (a INTEGER, b BIGINT)")
+    d.execute("CREATE TABLE IF NOT EXISTS jr (b BIGINT, c INTEGER)")
+    d.execute("CREATE TABLE IF NOT EXISTS jempty (b BIGINT)")
+    if int(d.execute("SELECT count(*) FROM jl")[0, 0]) == 0:
+        d.execute("INSERT INTO jl VALUES (11, 1), (12, 2), (13, 3), (14, 1), (15, NULL), (16, 7), (NULL, 2)")
+        d.execute("INSERT INTO jr SELECT (i % 5)::BIGINT, i::INTEGER FROM range(10240) t(i)")
+        d.execute("INSERT INTO jr VALUES (NULL, 1), (NULL, 2), (2, NULL)")
+    stmts = ["SELECT count(*) FROM jl INNER JOIN jr ON jl.b = jr.b",
+             "SELECT count(*) FROM jr, jl WHERE jl.b = jr.b",
+             "SELECT count(*) FROM jl, jr WHERE jl.a = jr.c",
+             "SELECT count(*) FROM jl x, jl y WHERE x.b = y.b",
+             "SELECT count(*) FROM jl JOIN jempty USING (b)",
+             "SELECT count(*) FROM jempty JOIN jr USING (b)",
+             "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person2id",
+             "SELECT count(*) FROM person p JOIN knows k ON p.p_personid = k.k_person1id"]
+    d.execute("PRAGMA disable_gpu_graph")
+    want = [d.execute(q) for q in stmts]
+    d.execute("PRAGMA enable_gpu_graph")
+    try:
+        for q, w in zip(stmts, want):
+            assert "GG_JOIN_COUNT" in d.explain(q), d.explain(q)
+            assert np.array_equal(d.execute(q), w), (q, d.execute(q), w)
+        # rows of such a join, other aggregates and joins with a further predicate stay with the reference
+        assert "GG_" not in d.explain("SELECT jl.a, jr.c FROM jl, jr WHERE jl.b = jr.b")
+        assert "GG_" not in d.explain("SELECT count(*) FROM jl, jr WHERE jl.b = jr.b AND jr.c > 5")
+        assert "GG_" not in d.explain("SELECT sum(jr.c) FROM jl, jr WHERE jl.b = jr.b")
+    finally:
+        d.execute("PRAGMA disable_gpu_graph")
+
+
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
 def test_the_count_of_two_hop_walks_over_an_ownership_sharded_graph(db, monkeypatch):
     """GG_DEVICES=N: the plan shape whose result adds (count(*)) or concatenates (rows) over shards — all 2-hop walks —
     has its tables appended to N device contexts (device p mod the devices present: all on the one GPU here), N CSR shards

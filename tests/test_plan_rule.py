@@ -44,6 +44,12 @@ def chain(h, table="knows", a="k_person1id", b="k_person2id", select="count(*)")
 
 
 TAKEN = [
+    # count(*) of ONE equi-join on an integer key that is not a walk (common neighbour, same-source fan, two tables):
+    # the build side's degrees summed over the probe side's keys (test/sql/join/inner/test_join_duplicates.test)
+    ("SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person2id", "GG_JOIN_COUNT", "1 hop"),
+    ("SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person1id = k2.k_person1id", "GG_JOIN_COUNT", "1 hop"),
+    ("SELECT count(*) FROM person p JOIN knows k ON p.p_personid = k.k_person2id", "GG_JOIN_COUNT", "1 hop"),
+    (chain(2, table="knows_nullable", a="a", b="b"), "GG_JOIN_COUNT", "1 hop"),
     # edge-only chains (interactive-complex-3.sql:9-11 idiom)
     (chain(2), "GG_PATH_COUNT", "2 hops"),
     (chain(4), "GG_PATH_COUNT", "4 hops"),
@@ -72,17 +78,19 @@ TAKEN = [
 ]
 
 LEFT_ALONE = [
-    # not a walk: common neighbour, same-source fan, self-loop filter, cycle
-    "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person2id",
-    "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person1id = k2.k_person1id",
+    # not a walk: self-loop filter, cycle (the ROWS of a common-neighbour or same-source join are not walks either;
+    # their count(*) alone is one equi-join's cardinality: GG_JOIN_COUNT, in TAKEN)
+    "SELECT k1.k_person1id, k2.k_person1id FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person2id",
     "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id AND k2.k_person2id = k1.k_person1id",
     # only part of the walk is validated against the vertex table
     "SELECT count(*) FROM knows k1, knows k2, person p WHERE k1.k_person2id = k2.k_person1id AND p.p_personid = k2.k_person2id",
     # vertex key without a uniqueness constraint: a duplicate id would multiply rows on the CPU side
     "SELECT count(*) FROM person_nokey p0, knows k1, person_nokey p1 "
     "WHERE p0.p_personid = k1.k_person1id AND k1.k_person2id = p1.p_personid",
-    # nullable edge columns in an edge-only chain: the outer ends are not join keys
-    chain(2, table="knows_nullable", a="a", b="b"),
+    # nullable edge columns in an edge-only chain: the outer ends are not join keys (the count of the two-table form,
+    # chain(2), is one equi-join's cardinality and NULL-safe: GG_JOIN_COUNT takes it)
+    chain(3, table="knows_nullable", a="a", b="b"),
+    chain(2, table="knows_nullable", a="a", b="b", select="k1.a, k2.b"),
     # non-equality predicates, outer joins, other filters; a predicate on an edge's payload column
     "SELECT k1.k_weight FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id AND k2.k_weight > 0",
     "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id < k2.k_person1id",

@@ -41,16 +41,27 @@ def test_the_rules_register_through_the_call_outs_without_the_shim():
 
 
 def test_no_private_access_in_the_call_out_build_of_the_extension():
-    """The -DGG_REFERENCE_CALLOUTS build compiles neither `#define private public` nor the interposed rule: checked
-    on the preprocessed source where the reference's headers are present."""
+    """The -DGG_REFERENCE_CALLOUTS build compiles neither `#define private public` nor the interposed rules: checked
+    on the preprocessed text of ALL FIVE host sources where the reference's headers are present.  (The planner rules
+    get the connection they plan for from the call-out's first argument, oracle/callout.patch: PlanCallouts::plan_fn.)"""
     ref = "/root/reference/src/include"
+    patched = os.path.join(ROOT, "oracle", "_ref_patched", "src", "include")
     if not os.path.isdir(ref):
         pytest.skip("reference headers not present")
-    src = os.path.join(ROOT, "duckdb_pgq_amd", "host", "gg_pipeline.cpp")
-    out = subprocess.run(["g++", "-std=c++11", "-E", "-dD", "-DGG_REFERENCE_CALLOUTS", "-DNDEBUG", "-I" + ref,
-                          "-I" + os.path.join(ROOT, "include"), src], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "#define private public" not in out.stdout and "GGBuildPipelinesRule" not in out.stdout
+    host = os.path.join(ROOT, "duckdb_pgq_amd", "host")
+    for name in ("gg_operators.cpp", "gg_duckdb_extension.cpp", "gg_plan_rule.cpp", "gg_ingest.cpp", "gg_pipeline.cpp"):
+        out = subprocess.run(["g++", "-std=c++11", "-E", "-dD", "-DGG_REFERENCE_CALLOUTS", "-DNDEBUG", "-I" + patched, "-I" + ref,
+                              "-I" + os.path.join(ROOT, "include"), os.path.join(host, name)], capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "#define private public" not in out.stdout, name
+        assert "#define protected public" not in out.stdout, name
+        # (the shim's header may still declare its entry points; nothing looks them up or defines a rule for them)
+        assert "GGBuildPipelinesRule" not in out.stdout and '"gg_plan_hook_register"' not in out.stdout, name
+    # ... and the plain build (for a stock reference behind the shim) is the one that does widen the access
+    plain = subprocess.run(["g++", "-std=c++11", "-E", "-dD", "-DNDEBUG", "-I" + ref, "-I" + os.path.join(ROOT, "include"),
+                            os.path.join(host, "gg_plan_rule.cpp")], capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and "#define private public" in plain.stdout
 
 
 def test_planner_rule_tests_pass_on_the_patched_reference():
