@@ -1642,6 +1642,39 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
   return GG_OK;
 }
 
+// ---- probe of a batch of keys (the device side of a generic single-key inner join) ---------------------------------
+// matches of probe key i = the CSR row of its dense index; deg[i] entries (0 for a key that is not a vertex)
+__global__ __launch_bounds__(256) void k_join_deg(const uint32_t *__restrict__ dense, uint64_t n,
+                                                  const uint32_t *__restrict__ off, uint64_t *__restrict__ deg) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t d = dense[i];
+    deg[i] = d == INVALID_U32 ? 0ull : (uint64_t)(off[d + 1] - off[d]);
+  }
+}
+
+// output row r: probe position i = upper_bound(poff, r) - 1, the (r - poff[i])-th entry of that key's row, and the
+// rowid the build side's Sink passed with it
+__global__ __launch_bounds__(256) void k_join_emit(const uint64_t *__restrict__ poff, uint64_t n, uint64_t M,
+                                                   const uint32_t *__restrict__ dense, const uint32_t *__restrict__ off,
+                                                   const int64_t *__restrict__ eid, const uint32_t *__restrict__ epos,
+                                                   int64_t *__restrict__ out_pos, int64_t *__restrict__ out_rowid) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  uint64_t lo = 0, hi = n;  // first i in [0, n] with poff[i] > r
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (poff[mid] <= r)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const uint64_t i = lo - 1;
+  const uint64_t e = (uint64_t)off[dense[i]] + (r - poff[i]);
+  out_pos[r] = (int64_t)i;
+  out_rowid[r] = eid ? eid[e] : (int64_t)epos[e];
+}
+
 // ---- walk COUNTS from degrees ---------------------------------------------------------------------------------------
 // count(*) over a join chain needs no row and no digest (the reference's aggregate above the joins only counts the
 // chunks' cardinalities): with w_0(v) = how often v is a source and w_h(v) = sum over the in-neighbours u of v of
@@ -1886,6 +1919,62 @@ extern "C" int gg_expand_khop(gg_ctx *ctx, const gg_csr *csr, const int64_t *src
   ctx->dev_free(cursor);
   free_frontier(ctx, f0);
   return rc;
+}
+
+extern "C" int gg_join_probe(gg_ctx *ctx, const gg_csr *csr, const int64_t *keys, uint64_t n, uint64_t *n_matches,
+                            gg_result **out_result) {
+  ApiScope scope(ctx);
+  if (!ctx || !csr || csr->ctx != ctx || !n_matches || !out_result || (n && !keys)) return GG_ERR_INVALID_ARG;
+  *out_result = nullptr;
+  *n_matches = 0;
+  if (csr->n_parts > 1 || !csr->has_rowid) {
+    set_error("gg_join_probe needs a whole CSR built with edge rowids (gg_ctx_set_edge_rowid(ctx, 1))");
+    return GG_ERR_STATE;
+  }
+  GG_HIP(hipSetDevice(ctx->device));
+  gg_result *res = new gg_result();
+  res->ctx = ctx;
+  res->k_min = res->k_max = 1;
+  uint64_t M = 0;
+  int64_t *ids_dev = nullptr;
+  uint32_t *dense = nullptr;
+  uint64_t *poff = nullptr;
+  int rc = GG_OK;
+  if (n && csr->V) {
+    rc = ctx->dev_alloc((void **)&ids_dev, n * sizeof(int64_t));
+    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&dense, n * sizeof(uint32_t));
+    if (rc == GG_OK) rc = ctx->dev_alloc((void **)&poff, (n + 1) * sizeof(uint64_t));
+    if (rc == GG_OK) {
+      hipError_t e = hipMemcpyAsync(ids_dev, keys, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // keys is caller memory: consumed before return
+      if (e != hipSuccess) {
+        set_error("gg_join_probe: %s", hipGetErrorString(e));
+        rc = GG_ERR_HIP;
+      }
+    }
+    if (rc == GG_OK) rc = lookup_ids(ctx, csr, ids_dev, n, dense);
+    if (rc == GG_OK) {
+      hipLaunchKernelGGL(k_join_deg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)dense, n,
+                         (const uint32_t *)csr->off, poff);
+      rc = offsets_from_deg(ctx, poff, n, &M);
+    }
+  }
+  for (int c = 0; c < 2 && rc == GG_OK; c++) {
+    rc = ctx->dev_alloc((void **)&res->cols[1][c], (M ? M : 1) * sizeof(int64_t));
+    if (rc == GG_OK) ctx->keep(res->cols[1][c]);
+  }
+  if (rc == GG_OK && M)
+    hipLaunchKernelGGL(k_join_emit, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t *)poff, n, M,
+                       (const uint32_t *)dense, (const uint32_t *)csr->off, (const int64_t *)csr->eid,
+                       (const uint32_t *)csr->epos, res->cols[1][0], res->cols[1][1]);
+  if (rc != GG_OK) {
+    gg_result_destroy(res);
+    return rc;
+  }
+  res->rows[1] = M;
+  *n_matches = M;
+  *out_result = res;
+  return GG_OK;
 }
 
 extern "C" int gg_khop_count(gg_ctx *ctx, const gg_csr *csr, const int64_t *src_ids, uint64_t n_src, int k_min, int k_max,

@@ -17,7 +17,7 @@ SYMBOLS = [
     "gg_version", "gg_last_error", "gg_device_count", "gg_ctx_create", "gg_ctx_destroy",
     "gg_vertices_append", "gg_edges_append", "gg_staging_sync", "gg_staging_counts", "gg_staging_clear",
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
-    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_count", "gg_expand_khop_dev", "gg_stream_wait", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
+    "gg_expand_khop", "gg_expand_khop_range", "gg_khop_count", "gg_expand_khop_dev", "gg_stream_wait", "gg_join_probe", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
     "gg_debug_max_grid_tiles", "gg_debug_reset",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
@@ -94,6 +94,7 @@ def load_library(path: str | None = None):
     lib.gg_khop_count.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(u64)]
     lib.gg_expand_khop_dev.argtypes = [P, P, C.c_int, C.POINTER(C.c_void_p)]
     lib.gg_stream_wait.argtypes = [P, C.c_void_p, C.c_int]
+    lib.gg_join_probe.argtypes = [P, P, i64p, u64, C.POINTER(u64), C.POINTER(P)]
     lib.gg_expand_khop_mid.argtypes = [P, P, u64, u64, C.c_int, C.c_int, C.POINTER(KhopStats)]
     lib.gg_khop_partition_mid.argtypes = [P, P, C.c_int, C.POINTER(u64)]
     lib.gg_expand_khop_mid_result.argtypes = [P, P, u64, u64, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
@@ -402,6 +403,25 @@ class GG:
         """direction 0: `other_stream` (raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) waits for the
         library's stream; 1: the library's stream waits for it.  No host synchronisation."""
         self._chk(self.lib.gg_stream_wait(self.ctx, C.c_void_p(other_stream), direction))
+
+    def join_probe(self, csr: Csr, keys) -> np.ndarray:
+        """(position in `keys`, rowid) for every edge row whose source equals keys[position] (gg_join_probe)."""
+        a, p = _i64(keys)
+        m, res = C.c_uint64(), C.c_void_p()
+        self._chk(self.lib.gg_join_probe(self.ctx, csr.handle, p, a.size, C.byref(m), C.byref(res)))
+        out = np.empty((m.value, 2), np.int64)
+        bufs = [np.empty(GG_CHUNK_ROWS, np.int64) for _ in range(2)]
+        ptrs = (C.POINTER(C.c_int64) * 2)(*[b.ctypes.data_as(C.POINTER(C.c_int64)) for b in bufs])
+        got, o = C.c_uint32(), 0
+        try:
+            while o < m.value:
+                self._chk(self.lib.gg_result_fetch(res, 1, o, GG_CHUNK_ROWS, ptrs, C.byref(got)))
+                out[o:o + got.value, 0] = bufs[0][:got.value]
+                out[o:o + got.value, 1] = bufs[1][:got.value]
+                o += got.value
+        finally:
+            self.lib.gg_result_destroy(res)
+        return out
 
     def khop_count(self, csr: Csr, k_min: int, k_max: int, sources=None) -> list:
         """Number of h-hop walks per length (index h), from degrees: no row, no digest (gg_khop_count)."""

@@ -71,6 +71,7 @@ shared_ptr<GGGraph> GGBuildGraph(ClientContext &context, const GGGraphSpec &spec
 struct GGConnectionFlags {
 	bool rules = false;        // PRAGMA enable_gpu_graph / disable_gpu_graph
 	bool pinned_graphs = false; // PRAGMA gg_use_pinned_graphs / gg_ignore_pinned_graphs
+	bool joins = false;         // PRAGMA enable_gpu_joins / disable_gpu_joins: ANY single-key inner join over a table scan
 };
 GGConnectionFlags GGGetConnectionFlags(ClientContext &context);
 void GGSetConnectionFlags(ClientContext &context, const GGConnectionFlags &flags);

@@ -849,6 +849,188 @@ void PhysicalGGPathExpand::GetData(ExecutionContext &context, DataChunk &chunk, 
 }
 
 //===--------------------------------------------------------------------===//
+// Generic single-key inner join: build side sunk into a device index, probe side streamed through it
+//===--------------------------------------------------------------------===//
+class GGKeyJoinGlobalState : public GlobalSinkState {
+public:
+	shared_ptr<GGGraph> graph;                 // context + the index keyed on the build key (edge rows key -> key, rowid)
+	unique_ptr<PhysicalGGEdgeSink> sink;       // does the staging and the build
+	unique_ptr<GlobalSinkState> sink_state;
+};
+
+class GGKeyJoinOperatorState : public OperatorState {
+public:
+	~GGKeyJoinOperatorState() override {
+		if (result) {
+			gg_result_destroy(result);
+		}
+	}
+	gg_result *result = nullptr; // matches of the probe chunk in hand: (position among its valid keys, build rowid)
+	idx_t matches = 0, offset = 0;
+	vector<sel_t> valid_rows;     // position among the valid keys -> row of the probe chunk
+	vector<vector<int64_t>> scratch;
+	vector<const int64_t *> keys;
+	vector<int64_t> positions;    // fetched slice
+};
+
+PhysicalGGKeyJoin::PhysicalGGKeyJoin(vector<LogicalType> types, unique_ptr<PhysicalOperator> probe,
+                                     unique_ptr<PhysicalOperator> build_scan, idx_t probe_key_p,
+                                     vector<idx_t> probe_columns_p, TableCatalogEntry *build_table_p,
+                                     column_t build_key_p, vector<column_t> build_columns_p, idx_t estimated_cardinality)
+    : PhysicalOperator(PhysicalOperatorType::HASH_JOIN, move(types), estimated_cardinality), probe_key(probe_key_p),
+      probe_columns(move(probe_columns_p)), build_table(build_table_p), build_key(build_key_p),
+      build_columns(move(build_columns_p)) {
+	children.push_back(move(probe));
+	children.push_back(move(build_scan));
+}
+
+string PhysicalGGKeyJoin::ParamsToString() const {
+	return "INNER\n" + build_table->name + "." + build_table->columns[build_key].name + " = #" + to_string(probe_key);
+}
+
+unique_ptr<GlobalSinkState> PhysicalGGKeyJoin::GetGlobalSinkState(ClientContext &context) const {
+	auto state = make_unique<GGKeyJoinGlobalState>();
+	state->graph = make_shared<GGGraph>(0, true /* the matches are handed back as rowids */);
+	// input chunks: (key, key, rowid) — an edge table whose rows point from their key to their key; the vertex set is
+	// the distinct keys (derive_vertices)
+	state->sink = make_unique<PhysicalGGEdgeSink>(state->graph, children[1]->types, 0, false, true);
+	state->sink_state = state->sink->GetGlobalSinkState(context);
+	return move(state);
+}
+
+unique_ptr<LocalSinkState> PhysicalGGKeyJoin::GetLocalSinkState(ExecutionContext &context) const {
+	auto &gstate = (GGKeyJoinGlobalState &)*sink_state;
+	return gstate.sink->GetLocalSinkState(context);
+}
+
+SinkResultType PhysicalGGKeyJoin::Sink(ExecutionContext &context, GlobalSinkState &gstate_p, LocalSinkState &lstate,
+                                       DataChunk &input) const {
+	auto &gstate = (GGKeyJoinGlobalState &)gstate_p;
+	return gstate.sink->Sink(context, *gstate.sink_state, lstate, input);
+}
+
+void PhysicalGGKeyJoin::Combine(ExecutionContext &context, GlobalSinkState &gstate_p, LocalSinkState &lstate) const {
+	auto &gstate = (GGKeyJoinGlobalState &)gstate_p;
+	gstate.sink->Combine(context, *gstate.sink_state, lstate);
+}
+
+SinkFinalizeType PhysicalGGKeyJoin::Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+                                             GlobalSinkState &gstate_p) const {
+	auto &gstate = (GGKeyJoinGlobalState &)gstate_p;
+	return gstate.sink->Finalize(pipeline, event, context, *gstate.sink_state);
+}
+
+unique_ptr<OperatorState> PhysicalGGKeyJoin::GetOperatorState(ClientContext &context) const {
+	return make_unique<GGKeyJoinOperatorState>();
+}
+
+OperatorResultType PhysicalGGKeyJoin::Execute(ExecutionContext &context, DataChunk &input, DataChunk &chunk,
+                                              OperatorState &state_p) const {
+	auto &state = (GGKeyJoinOperatorState &)state_p;
+	auto &gstate = (GGKeyJoinGlobalState &)*sink_state;
+	auto &graph = *gstate.graph;
+	if (!state.result) {
+		// a new probe chunk: its valid keys go to the device, the matches stay there until they are handed out
+		if (!graph.csr || input.size() == 0) {
+			return OperatorResultType::NEED_MORE_INPUT;
+		}
+		// rows whose key is NULL join nothing (JoinHashTable::PrepareKeys, join_hashtable.cpp:126-148)
+		VectorData kdata;
+		input.data[probe_key].Orrify(input.size(), kdata);
+		const bool narrow = input.data[probe_key].GetType().InternalType() == PhysicalType::INT32;
+		state.valid_rows.clear();
+		state.scratch.resize(1);
+		state.scratch[0].clear();
+		for (idx_t r = 0; r < input.size(); r++) {
+			const auto idx = kdata.sel->get_index(r);
+			if (!kdata.validity.RowIsValid(idx)) {
+				continue;
+			}
+			state.valid_rows.push_back((sel_t)r);
+			state.scratch[0].push_back(narrow ? (int64_t)((const int32_t *)kdata.data)[idx] : ((const int64_t *)kdata.data)[idx]);
+		}
+		if (state.valid_rows.empty()) {
+			return OperatorResultType::NEED_MORE_INPUT;
+		}
+		uint64_t matches = 0;
+		{
+			lock_guard<mutex> guard(graph.lock); // (device calls on one context are serialised, gg.h)
+			GGGraph::Check(gg_join_probe(graph.ctx, graph.csr, state.scratch[0].data(), state.scratch[0].size(), &matches,
+			                             &state.result),
+			               "gg_join_probe");
+		}
+		state.matches = matches;
+		state.offset = 0;
+		if (matches == 0) {
+			gg_result_destroy(state.result);
+			state.result = nullptr;
+			return OperatorResultType::NEED_MORE_INPUT;
+		}
+	}
+	if (context.client.interrupted) {
+		throw InterruptException();
+	}
+	// the next <= 1024 matches: (position, rowid)
+	Vector rowids(LOGICAL_ROW_TYPE);
+	state.positions.resize(STANDARD_VECTOR_SIZE);
+	int64_t *cols[2] = {state.positions.data(), (int64_t *)FlatVector::GetData<row_t>(rowids)};
+	uint32_t n = 0;
+	{
+		lock_guard<mutex> guard(graph.lock);
+		GGGraph::Check(gg_result_fetch(state.result, 1, state.offset, STANDARD_VECTOR_SIZE, cols, &n), "gg_result_fetch");
+	}
+	state.offset += n;
+	SelectionVector sel(STANDARD_VECTOR_SIZE);
+	auto ids = FlatVector::GetData<row_t>(rowids);
+	for (uint32_t r = 0; r < n; r++) {
+		sel.set_index(r, state.valid_rows[(idx_t)state.positions[r]]);
+		if (ids[r] < 0 || ids[r] >= MAX_ROW_ID) {
+			throw NotImplementedException("GG_KEY_JOIN: build rows that this transaction has not committed yet cannot be "
+			                              "fetched by rowid (PRAGMA disable_gpu_joins for this statement)");
+		}
+	}
+	// probe columns: the chunk's rows by position (dictionary vectors over the input, as result.Slice(left, sel) in
+	// ScanStructure::NextInnerJoin, join_hashtable.cpp:466); build columns: fetched by rowid
+	const idx_t left_columns = probe_columns.size();
+	for (idx_t c = 0; c < left_columns; c++) {
+		chunk.data[c].Slice(input.data[probe_columns[c]], sel, n);
+	}
+	vector<column_t> fetch_ids;
+	vector<LogicalType> fetch_types;
+	for (auto column : build_columns) {
+		if (column != COLUMN_IDENTIFIER_ROW_ID) {
+			fetch_ids.push_back(column);
+			fetch_types.push_back(build_table->columns[column].type);
+		}
+	}
+	DataChunk fetched;
+	if (!fetch_ids.empty()) {
+		fetched.Initialize(fetch_types);
+		ColumnFetchState fetch_state;
+		auto &transaction = Transaction::GetTransaction(context.client);
+		build_table->storage->Fetch(transaction, fetched, fetch_ids, rowids, n, fetch_state);
+		if (fetched.size() != n) {
+			throw InternalException("GG_KEY_JOIN: a build row of the join is not visible to the statement any more");
+		}
+	}
+	idx_t f = 0;
+	for (idx_t c = 0; c < build_columns.size(); c++) {
+		if (build_columns[c] == COLUMN_IDENTIFIER_ROW_ID) {
+			chunk.data[left_columns + c].Reference(rowids);
+		} else {
+			chunk.data[left_columns + c].Reference(fetched.data[f++]);
+		}
+	}
+	chunk.SetCardinality(n);
+	if (state.offset >= state.matches) {
+		gg_result_destroy(state.result);
+		state.result = nullptr;
+		return OperatorResultType::NEED_MORE_INPUT;
+	}
+	return OperatorResultType::HAVE_MORE_OUTPUT;
+}
+
+//===--------------------------------------------------------------------===//
 // Filtered paths source (ConnectedSegments)
 //===--------------------------------------------------------------------===//
 class GGFilteredGlobalState : public GlobalSourceState {

@@ -201,6 +201,60 @@ public:
 	}
 };
 
+//! Streaming operator + sink: a generic INNER hash join on ONE integer key whose build side is a base-table scan —
+//! the reference's PhysicalHashJoin in both of its roles (src/execution/operator/join/physical_hash_join.cpp:128-254):
+//!   children[1] (a scan of the build table's key column and rowid) is SUNK into a device index keyed on the key
+//!               (Sink / Combine / Finalize = the hash-join build, concurrent Sink calls; gg_edges_append, gg_csr_build);
+//!   children[0] (any plan) is PROBED chunk by chunk: Execute sends the chunk's keys to the device (gg_join_probe: for
+//!               every probe position the rowids of the build rows under its key), slices the probe chunk by position
+//!               and fetches the build table's columns by rowid (DataTable::Fetch, as the index join does) —
+//!               HAVE_MORE_OUTPUT while one probe chunk's matches exceed a DataChunk, like ScanStructure::Next.
+//! Its PhysicalOperatorType is HASH_JOIN, so the reference's executor schedules it with the code it has for joins
+//! (Executor::BuildPipelines, src/parallel/executor.cpp:424-442: the operator is all it looks at), also inside the
+//! arms of a recursive CTE.  Output columns: `probe_columns` of the probe child's, then `build_columns` of the build table.
+class PhysicalGGKeyJoin : public PhysicalOperator {
+public:
+	PhysicalGGKeyJoin(vector<LogicalType> types, unique_ptr<PhysicalOperator> probe, unique_ptr<PhysicalOperator> build_scan,
+	                  idx_t probe_key, vector<idx_t> probe_columns, TableCatalogEntry *build_table, column_t build_key,
+	                  vector<column_t> build_columns, idx_t estimated_cardinality);
+
+	idx_t probe_key;                 // column of the probe child's chunks that holds the key
+	vector<idx_t> probe_columns;     // columns of the probe child's chunks that go out, in output order
+	TableCatalogEntry *build_table;
+	column_t build_key;
+	vector<column_t> build_columns;  // of the build table, in output order (COLUMN_IDENTIFIER_ROW_ID allowed)
+
+public:
+	// sink (build side)
+	unique_ptr<GlobalSinkState> GetGlobalSinkState(ClientContext &context) const override;
+	unique_ptr<LocalSinkState> GetLocalSinkState(ExecutionContext &context) const override;
+	SinkResultType Sink(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate,
+	                    DataChunk &input) const override;
+	void Combine(ExecutionContext &context, GlobalSinkState &gstate, LocalSinkState &lstate) const override;
+	SinkFinalizeType Finalize(Pipeline &pipeline, Event &event, ClientContext &context,
+	                          GlobalSinkState &gstate) const override;
+	bool IsSink() const override {
+		return true;
+	}
+	bool ParallelSink() const override {
+		return true;
+	}
+	// operator (probe side)
+	unique_ptr<OperatorState> GetOperatorState(ClientContext &context) const override;
+	OperatorResultType Execute(ExecutionContext &context, DataChunk &input, DataChunk &chunk,
+	                           OperatorState &state) const override;
+	bool ParallelOperator() const override {
+		return true;
+	}
+	bool RequiresCache() const override {
+		return true;
+	}
+	string GetName() const override {
+		return "GG_KEY_JOIN";
+	}
+	string ParamsToString() const override;
+};
+
 //! Source: `hops`-hop walks WITH payload columns of the edge table (a join chain that projects columns of its edge
 //! instances other than the two keys).  The device returns every walk with the rowid of each edge taken
 //! (gg_expand_khop_edges); the payload columns are then fetched from the base table by rowid, in the statement's

@@ -204,7 +204,7 @@ string PhysicalGGGraphScan::ParamsToString() const {
 }
 
 //! PhysicalTableScan of the given columns of a base table (what plan_get.cpp:47-60 builds for a seq_scan)
-static unique_ptr<PhysicalOperator> BaseTableScan(const GGScanSource &source) {
+unique_ptr<PhysicalOperator> GGBaseTableScan(const GGScanSource &source) {
 	auto &table = *source.table;
 	vector<LogicalType> types;  // of the scanned columns
 	vector<string> names;       // of ALL columns: PhysicalTableScan indexes them by column id (as LogicalGet::names)
@@ -236,7 +236,7 @@ unique_ptr<PhysicalOperator> GGMakeGraphScan(const vector<GGSinkSpec> &sinks, ve
 	auto scan = make_unique<PhysicalGGGraphScan>(move(types), move(name), move(description), slot, move(factory),
 	                                             parallel_result, estimated_cardinality);
 	for (auto &spec : sinks) {
-		auto rows = BaseTableScan(spec.rows);
+		auto rows = GGBaseTableScan(spec.rows);
 		auto sink = make_unique<PhysicalGGLazySink>(slot, spec.options, rows->types, rows->estimated_cardinality);
 		sink->children.push_back(move(rows));
 		scan->children.push_back(move(sink));
@@ -253,13 +253,13 @@ unique_ptr<PhysicalOperator> GGMakeGraphScan(const GGGraphSpec &spec, vector<Log
 	                                             parallel_result, estimated_cardinality);
 	const bool derive = spec.vertices.Empty();
 	if (!derive) {
-		auto rows = BaseTableScan(spec.vertices);
+		auto rows = GGBaseTableScan(spec.vertices);
 		auto sink = make_unique<PhysicalGGLazySink>(slot, PhysicalGGLazySink::VERTICES, rows->types,
 		                                            rows->estimated_cardinality);
 		sink->children.push_back(move(rows));
 		scan->children.push_back(move(sink));
 	}
-	auto rows = BaseTableScan(spec.edges);
+	auto rows = GGBaseTableScan(spec.edges);
 	auto sink = make_unique<PhysicalGGLazySink>(
 	    slot, derive ? PhysicalGGLazySink::EDGES_DERIVE_VERTICES : PhysicalGGLazySink::EDGES, rows->types,
 	    rows->estimated_cardinality);

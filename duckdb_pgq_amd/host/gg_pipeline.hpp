@@ -102,6 +102,8 @@ struct GGSinkSpec {
 unique_ptr<PhysicalOperator> GGMakeGraphScan(const vector<GGSinkSpec> &sinks, vector<LogicalType> types, string name,
                                              string description, bool parallel_result,
                                              PhysicalGGGraphScan::Factory factory, idx_t estimated_cardinality);
+//! PhysicalTableScan of the given columns of a base table (what plan_get.cpp:47-60 builds for a seq_scan)
+unique_ptr<PhysicalOperator> GGBaseTableScan(const GGScanSource &source);
 void GGRegisterPipelineRule();
 //! the hosting reference has the BuildPipelines case itself (oracle/callout.patch): pipeline sinks without a rule
 void GGPipelineSinksNative();

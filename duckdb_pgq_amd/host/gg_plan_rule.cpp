@@ -904,6 +904,8 @@ bool SolveWalkPattern(PatternInput &in, WalkPattern &out) {
 thread_local vector<CatalogEntry *> g_plan_tables;
 //! the connection whose statement is being planned (set by RuleEntry)
 thread_local ClientContext *g_plan_context = nullptr;
+//! its plan generator: the key-join rule plans the probe side with it (CreatePlan(unique_ptr<LogicalOperator>), public)
+static thread_local PhysicalPlanGenerator *g_plan_generator = nullptr;
 
 GGScanSource TableColumns(TableCatalogEntry *table, vector<column_t> columns) {
 	g_plan_tables.push_back(table);
@@ -1505,6 +1507,104 @@ unique_ptr<PhysicalOperator> MakeKeyJoinCountScan(PatternInput &in) {
 	}
 	return make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_join_count"), move(data), move(column_ids),
 	                                      move(names), nullptr, 1);
+}
+
+//! Join rule 3 (PRAGMA enable_gpu_joins): ANY inner join on one equality of two integer columns whose build side —
+//! the right child, as the reference's own planner has it (plan_comparison_join.cpp:146-220) — is a plain scan of a
+//! base table.  The build side is sunk into a device index keyed on its column, the probe side (any plan: the
+//! generator plans it) streams through PhysicalGGKeyJoin.  This is the reference's PhysicalHashJoin role for role, at
+//! one device round trip per probe chunk — what makes the operators a drop-in for joins that are not walks (the
+//! reference's own join vectors, a hash join in the arm of a recursive CTE), not a fast path: off unless asked for.
+unique_ptr<PhysicalOperator> PlanKeyJoin(LogicalComparisonJoin &op) {
+	if (!g_plan_context || !g_plan_generator || !GGGetConnectionFlags(*g_plan_context).joins) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 1\n");
+		return nullptr;
+	}
+	if (op.join_type != JoinType::INNER || op.conditions.size() != 1 || op.children.size() != 2) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 2\n");
+		return nullptr;
+	}
+	auto &cond = op.conditions[0];
+	if (cond.comparison != ExpressionType::COMPARE_EQUAL || cond.null_values_are_equal ||
+	    cond.left->type != ExpressionType::BOUND_REF || cond.right->type != ExpressionType::BOUND_REF) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 3\n");
+		return nullptr;
+	}
+	if (op.children[1]->type != LogicalOperatorType::LOGICAL_GET) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 4\n");
+		return nullptr;
+	}
+	auto &get = (LogicalGet &)*op.children[1];
+	if (!get.children.empty() || get.function.name != "seq_scan" || !get.bind_data || !get.table_filters.filters.empty()) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 5\n");
+		return nullptr;
+	}
+	auto &bind = (TableScanBindData &)*get.bind_data;
+	if (bind.is_index_scan || !bind.table) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 6\n");
+		return nullptr;
+	}
+	auto table = bind.table;
+	const idx_t probe_key = ((BoundReferenceExpression &)*cond.left).index;
+	const idx_t build_ref = ((BoundReferenceExpression &)*cond.right).index;
+	if (build_ref >= get.column_ids.size() || get.column_ids[build_ref] == COLUMN_IDENTIFIER_ROW_ID ||
+	    probe_key >= op.children[0]->types.size()) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 7\n");
+		return nullptr;
+	}
+	const column_t build_key = get.column_ids[build_ref];
+	const auto key_type = cond.left->return_type;
+	if (!ColumnIsIntegerKey(*table, build_key) || key_type != table->columns[build_key].type ||
+	    (key_type != LogicalType::BIGINT && key_type != LogicalType::INTEGER)) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 8\n");
+		return nullptr;
+	}
+	// rows this transaction appended itself have no fetchable rowid yet (DataTable::Fetch): its own hash join then
+	if (Transaction::GetTransaction(*g_plan_context).ChangesMade()) {
+		if (std::getenv("GG_RULE_TRACE")) fprintf(stderr, "[gg] key join declined at check 9\n");
+		return nullptr;
+	}
+	const auto types = op.types;
+	const auto cardinality = op.estimated_cardinality;
+	// the join's output: the probe child's columns, then the scan's — each through its projection map if column
+	// pruning left one (LogicalComparisonJoin::ResolveTypes: an empty map keeps every column)
+	vector<idx_t> probe_columns = op.left_projection_map;
+	if (probe_columns.empty()) {
+		for (idx_t c = 0; c < op.children[0]->types.size(); c++) {
+			probe_columns.push_back(c);
+		}
+	}
+	vector<column_t> build_columns;
+	if (op.right_projection_map.empty()) {
+		build_columns = get.column_ids;
+	} else {
+		for (auto c : op.right_projection_map) {
+			if (c >= get.column_ids.size()) {
+				return nullptr;
+			}
+			build_columns.push_back(get.column_ids[c]);
+		}
+	}
+	if (probe_columns.size() + build_columns.size() != op.types.size()) {
+		return nullptr;
+	}
+	auto build_scan = GGBaseTableScan(TableColumns(table, {build_key, build_key, COLUMN_IDENTIFIER_ROW_ID}));
+	// (from here on the logical join is spent: its probe child moves into the generator — which may come back into
+	//  these rules for joins further down, with the per-plan bookkeeping of its own)
+	auto generator = g_plan_generator;
+	auto probe = generator->CreatePlan(move(op.children[0]));
+	g_plan_generator = generator;
+	g_plan_tables.push_back(table);
+	g_rules_fired++;
+	return make_unique<PhysicalGGKeyJoin>(types, move(probe), move(build_scan), probe_key, move(probe_columns), table,
+	                                      build_key, move(build_columns), cardinality);
+}
+
+unique_ptr<PhysicalOperator> PlanJoin(LogicalComparisonJoin &op) {
+	if (auto plan = PlanJoinChain(op)) {
+		return plan;
+	}
+	return PlanKeyJoin(op);
 }
 
 //! Aggregate rule: ungrouped count(*) over a walk pattern.
@@ -2280,6 +2380,7 @@ int RuleEntryFor(ClientContext &context, void *ret_slot, void *generator, void *
 	unique_ptr<PhysicalOperator> plan;
 	g_plan_tables.clear();
 	g_plan_context = &context;
+	g_plan_generator = (PhysicalPlanGenerator *)generator;
 	try {
 		plan = RULE(*(OP *)logical_operator);
 	} catch (std::exception &) {
@@ -2335,6 +2436,18 @@ void PragmaDisableGpuGraph(ClientContext &context, const FunctionParameters &par
 	GGSetConnectionFlags(context, flags);
 }
 
+void PragmaEnableGpuJoins(ClientContext &context, const FunctionParameters &parameters) {
+	auto flags = GGGetConnectionFlags(context);
+	flags.joins = true;
+	GGSetConnectionFlags(context, flags);
+}
+
+void PragmaDisableGpuJoins(ClientContext &context, const FunctionParameters &parameters) {
+	auto flags = GGGetConnectionFlags(context);
+	flags.joins = false;
+	GGSetConnectionFlags(context, flags);
+}
+
 void PragmaUsePinnedGraphs(ClientContext &context, const FunctionParameters &parameters) {
 	auto flags = GGGetConnectionFlags(context);
 	flags.pinned_graphs = true;
@@ -2371,6 +2484,10 @@ void GGRegisterPlanRules(ClientContext &context) {
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &disable);
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &use_pins);
 	Catalog::GetCatalog(context).CreatePragmaFunction(context, &no_pins);
+	CreatePragmaFunctionInfo joins_on(PragmaFunction::PragmaStatement("enable_gpu_joins", PragmaEnableGpuJoins));
+	CreatePragmaFunctionInfo joins_off(PragmaFunction::PragmaStatement("disable_gpu_joins", PragmaDisableGpuJoins));
+	Catalog::GetCatalog(context).CreatePragmaFunction(context, &joins_on);
+	Catalog::GetCatalog(context).CreatePragmaFunction(context, &joins_off);
 
 	// A reference built with oracle/callout.patch exports the registration of its call-outs: the maintainers' route —
 	// no interposition, no access to private members (the BuildPipelines case and the write observation are then the
@@ -2379,7 +2496,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 	using write_fn = void (*)(idx_t);
 	auto callouts = (void (*)(plan_fn, plan_fn, plan_fn, write_fn))dlsym(RTLD_DEFAULT, "duckdb_register_plan_callouts");
 	if (callouts) {
-		callouts(CalloutEntry<LogicalComparisonJoin, PlanJoinChain>, CalloutEntry<LogicalAggregate, PlanAggregate>,
+		callouts(CalloutEntry<LogicalComparisonJoin, PlanJoin>, CalloutEntry<LogicalAggregate, PlanAggregate>,
 		         CalloutEntry<LogicalDistinct, PlanDistinctUnion>, GGDropPinsOfTable);
 		g_callouts_registered = true;
 		GGPipelineSinksNative();
@@ -2392,7 +2509,7 @@ void GGRegisterPlanRules(ClientContext &context) {
 	if (!reg) {
 		return;
 	}
-	reg(GG_PLAN_HOOK_JOIN, RuleEntry<LogicalComparisonJoin, PlanJoinChain>);
+	reg(GG_PLAN_HOOK_JOIN, RuleEntry<LogicalComparisonJoin, PlanJoin>);
 	reg(GG_PLAN_HOOK_AGGREGATE, RuleEntry<LogicalAggregate, PlanAggregate>);
 	reg(GG_PLAN_HOOK_DISTINCT, RuleEntry<LogicalDistinct, PlanDistinctUnion>);
 	GGRegisterPipelineRule();

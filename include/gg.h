@@ -133,6 +133,15 @@ void gg_csr_destroy(gg_csr *csr);
  * reference (JoinHashTable::Probe, src/execution/join_hashtable.cpp:304-330). */
 int gg_csr_lookup(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids, uint64_t n, uint32_t *dense_out);
 int gg_csr_info(const gg_csr *csr, uint64_t *n_vertices, uint64_t *n_edges_kept, uint64_t *n_edges_dropped);
+/* Probe of a batch of keys against the index keyed on the edge rows' source column, with the matches' rowids: for the
+ * n keys (host memory; a key that is no vertex matches nothing) table 1 of *out_result gets one row (i, rowid) per
+ * edge row whose source equals keys[i] — i the position in `keys` — in ascending i, a key's rows in rowid order; fetch
+ * with gg_result_rows(res, 1, &m) / gg_result_fetch(res, 1, offset, max, cols[2], &got).  This is the device side of a
+ * generic single-key inner hash join: JoinHashTable::Probe + ScanStructure::NextInnerJoin for one probe chunk
+ * (src/execution/join_hashtable.cpp:304-476); the host operator (PhysicalGGKeyJoin) slices the probe chunk by i and
+ * fetches the build side's columns by rowid.  The CSR must have been built with edge rowids kept. */
+int gg_join_probe(gg_ctx *ctx, const gg_csr *csr, const int64_t *keys, uint64_t n, uint64_t *n_matches,
+                  gg_result **out_result);
 /* Parity export.  off: V+1 entries; nbr: E_kept dense neighbour indices; eid: E_kept edge rowids
  * (may be NULL); vid: V vertex ids by dense index (may be NULL). */
 int gg_csr_export(const gg_csr *csr, int64_t *off, int64_t *nbr, int64_t *eid, int64_t *vid);

@@ -343,6 +343,30 @@ def test_walk_counts_from_degrees_equal_the_counting_expansion(gg, orc, V, E, se
     g.close()
 
 
+def test_join_probe_returns_every_matching_build_row_per_probe_key(gg, orc):
+    """gg_join_probe: the device side of a generic single-key hash join — for a batch of probe keys the rowids of the
+    build rows under each key, in probe order (JoinHashTable::Probe + NextInnerJoin for one chunk).  Duplicate probe
+    keys, keys that match nothing, a 10 240-long duplicate chain (test_join_duplicates.test), an empty batch."""
+    rng = np.random.default_rng(11)
+    build_key = np.concatenate([rng.integers(-50, 50, 5000), np.full(10240, 7), np.array([1 << 40, -(1 << 40)])]).astype(np.int64)
+    rowid = (np.arange(build_key.size, dtype=np.int64) * 3 + 1000)
+    gg.staging_clear()
+    gg.set_edge_rowid(True)
+    gg.append_edges(build_key, build_key, rowid)
+    gg.vertices_from_edges()
+    csr = gg.build_csr()
+    keys = np.concatenate([rng.integers(-60, 60, 3000), np.array([7, 7, 1 << 40, 12345, -(1 << 40)])]).astype(np.int64)
+    got = gg.join_probe(csr, keys)
+    order = np.argsort(build_key, kind="stable")
+    sk, sr = build_key[order], rowid[order]
+    lo, hi = np.searchsorted(sk, keys, "left"), np.searchsorted(sk, keys, "right")
+    want = np.concatenate([np.stack([np.full(h - l, i, np.int64), sr[l:h]], axis=1) for i, (l, h) in enumerate(zip(lo, hi))])
+    assert got.shape == want.shape and np.array_equal(got, want)  # (row order included: ascending position, rowid order)
+    assert gg.join_probe(csr, np.zeros(0, np.int64)).shape == (0, 2)
+    assert gg.join_probe(csr, np.array([99999], np.int64)).shape == (0, 2)
+    csr.close()
+
+
 def test_khop_ranges_partition_the_result(gg, orc):
     """Sharding entry point: per-range counts/digests add up to the whole (what the multi-GPU path sums)."""
     vid, src, dst = datagen.ldbc_knows(5000, 200_000, 17)
