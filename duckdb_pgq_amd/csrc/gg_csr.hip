@@ -621,6 +621,34 @@ int radix_sort_stable(gg_ctx *ctx, const RadixIO &io, uint64_t n, bool has_b, bo
 
 }  // namespace
 
+namespace gg {
+// (key, value) pairs sorted by key < 2^key_bits, stable (gg_internal.h): the LSD passes of the multi-pass build
+int sort_pairs_by_key(gg_ctx *ctx, const uint32_t *key, const uint32_t *val, uint64_t n, int key_bits, uint32_t *key_out,
+                      uint32_t *val_out) {
+  if (n == 0) return GG_OK;
+  unsigned long long *tot = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(unsigned long long)));
+  const unsigned long long n_host = n;  // (pageable source: staged by the runtime before the call returns)
+  GG_HIP(hipMemcpyAsync(tot, &n_host, sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  RadixIO io{key, val, nullptr, key_out, val_out, nullptr};
+  GG_TRY(radix_sort_stable(ctx, io, n, false, false, key_bits < 1 ? 1 : key_bits, nullptr, 0, tot, true));
+  ctx->dev_free(tot);
+  return GG_OK;
+}
+int sort_triples_by_key(gg_ctx *ctx, const uint32_t *key, const uint32_t *a, const uint32_t *b, uint64_t n, int key_bits,
+                        uint32_t *key_out, uint32_t *a_out, uint32_t *b_out) {
+  if (n == 0) return GG_OK;
+  unsigned long long *tot = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(unsigned long long)));
+  const unsigned long long n_host = n;
+  GG_HIP(hipMemcpyAsync(tot, &n_host, sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  RadixIO io{key, a, b, key_out, a_out, b_out};
+  GG_TRY(radix_sort_stable(ctx, io, n, true, false, key_bits < 1 ? 1 : key_bits, nullptr, 0, tot, true));
+  ctx->dev_free(tot);
+  return GG_OK;
+}
+}  // namespace gg
+
 extern "C" void gg_csr_destroy(gg_csr *csr) {
   if (!csr) return;
   gg_ctx *ctx = csr->ctx;

@@ -173,7 +173,7 @@ struct gg_ctx {
   size_t bytes_allocated = 0;
 
   // ---- profiling ----
-  bool force_frontier = false;  // gg_debug_force_frontier
+  int force_frontier = 0;  // gg_debug_force_frontier: 1 frontier kernels only, 2 product form of the last hop at any size
   bool rank_mode_forced = false;  // rank_mode was set by gg_debug_rank_mode, not decided by the probe
   int rank_mode = 0;            // gg_debug_rank_mode: 0 probe the LDS atomic order once, 1 ds_add_rtn ranks, 2 match masks
   bool legacy_build = false;    // gg_debug_force_legacy_build: the multi-pass LSD build (also taken for > 2^22 vertices)
@@ -296,6 +296,11 @@ int scan_exclusive_u64(gg_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t 
 
 // id -> dense lookup of n host ids; writes dense (uint32, INVALID_U32 if absent) to out_dev
 int lookup_ids(gg_ctx *ctx, const gg_csr *csr, const int64_t *ids_dev, uint64_t n, uint32_t *out_dev);
+// n (key, value) pairs of u32 sorted by key < 2^key_bits, stably, into (key_out, val_out) — device arrays (gg_csr.hip)
+int sort_pairs_by_key(gg_ctx *ctx, const uint32_t *key, const uint32_t *val, uint64_t n, int key_bits, uint32_t *key_out,
+                      uint32_t *val_out);
+int sort_triples_by_key(gg_ctx *ctx, const uint32_t *key, const uint32_t *a, const uint32_t *b, uint64_t n, int key_bits,
+                        uint32_t *key_out, uint32_t *a_out, uint32_t *b_out);
 // make a staged column hold need_rows rows, keeping the first live_rows (gg_runtime.hip; caller holds mu)
 int grow_column(gg_ctx *ctx, Column &c, size_t live_rows, size_t need_rows);
 // GG_STAGING_TRACE=1: print and reset the edge staging's waiting-time counters (gg_runtime.hip)

@@ -29,6 +29,9 @@ constexpr int XT = 256;  // child positions per tile == threads per workgroup
 // The runtime takes a grid as gridDim.x * blockDim.x threads in 32 bits: at most this many XT-thread workgroups per
 // launch (about 1.3e10 3-hop tile rows; SF100's 12.8 G 2-hop rows are 16.6 M tiles of 768, just below it).
 constexpr uint64_t MAX_GRID_TILES = 0xFFFFFFFFull / XT;
+// second-to-last frontiers of at least this many entries take the product form of the last hop (pairs + sort by last
+// vertex + fold); smaller ones are over before three sort passes have been launched
+constexpr uint64_t FRONT_PRODUCT_MIN = 1u << 16;
 
 // tile t starts in entry  upper_bound(foff, foff[0] + t*XT) - 1
 template <typename OffT>
@@ -531,6 +534,119 @@ __global__ __launch_bounds__(XT) void k_expand_mid2(const uint32_t *__restrict__
   block_store_partials(mid_sum, total, rows_last, sm.red, partial);
 }
 
+// ---- the last TWO hops of an explicit frontier through k_expand_mid3 --------------------------------------------------
+// identity frontier [base, base + n) as explicit arrays
+__global__ __launch_bounds__(256) void k_front_ident(uint32_t base, uint64_t n, uint32_t *__restrict__ fv,
+                                                     uint32_t *__restrict__ qlo, uint32_t *__restrict__ qhi) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t v = base + (uint32_t)i;
+    const uint64_t q = dig_q((uint64_t)v, 0);
+    fv[i] = v;
+    qlo[i] = (uint32_t)q;
+    qhi[i] = (uint32_t)(q >> 32);
+  }
+}
+__global__ __launch_bounds__(256) void k_front_split(const uint64_t *__restrict__ fq, uint64_t n, uint32_t *__restrict__ qlo,
+                                                     uint32_t *__restrict__ qhi) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    qlo[i] = (uint32_t)fq[i];
+    qhi[i] = (uint32_t)(fq[i] >> 32);
+  }
+}
+// sorted last vertices -> where each vertex's entries start (froff[0..V]), and the states joined again
+__global__ __launch_bounds__(256) void k_front_offsets(const uint32_t *__restrict__ sv, const uint32_t *__restrict__ qlo,
+                                                       const uint32_t *__restrict__ qhi, uint64_t n, uint64_t V,
+                                                       uint32_t *__restrict__ froff, uint64_t *__restrict__ fq) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const uint64_t cur = i < n ? (uint64_t)sv[i] : V, prev = i ? (uint64_t)sv[i - 1] + 1 : 0;
+  for (uint64_t v = prev; v <= cur; v++) froff[v] = (uint32_t)i;  // (vertices without an entry: empty ranges)
+  if (i < n) fq[i] = ((uint64_t)qhi[i] << 32) | (uint64_t)qlo[i];
+}
+// children of reverse entry e = (a -> b): the frontier entries that end in a
+__global__ __launch_bounds__(256) void k_front3_prepare(const uint32_t *__restrict__ froff, const uint32_t *__restrict__ rnbr,
+                                                        uint64_t n, uint64_t *__restrict__ foff2) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) {
+    const uint32_t a = rnbr[e];
+    foff2[e] = (uint64_t)(froff[a + 1] - froff[a]);
+  }
+}
+
+// ---- the last hop of an EXPLICIT frontier as a product (source lists, source ranges, k >= 4) -------------------------
+// The walks of the last hop are {prefixes that end in x} x out(x) for every vertex x, whatever the prefixes are: the
+// fused kernel above hashes every walk of the last two hops (a full dig_leaf per walk, out(x) re-read per prefix);
+// here the second-to-last hop is written out as PAIRS (last vertex x, low half of the prefix's hash state) —
+// k_expand_pairs —, the pairs are sorted by x (sort_pairs_by_key: the frontier grouped by its last vertex), and the
+// last hop is k_expand_mid2's fold with the states loaded instead of computed: out(x) once per run of equal x, one
+// v_xad_u32 per walk (k_expand_front).  Only the low 32 bits of a state reach the 32-bit digest of the last hop.
+template <typename OffT>
+__global__ __launch_bounds__(XT) void k_expand_pairs(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                     const OffT *__restrict__ foff, Frontier f, uint64_t M,
+                                                     const uint32_t *__restrict__ tile_entry, int emit,
+                                                     uint32_t *__restrict__ nv, uint32_t *__restrict__ nq32,
+                                                     unsigned long long *__restrict__ partial) {
+  __shared__ uint64_t s_foff[XT + 1];
+  __shared__ uint64_t s_red[12];
+  const uint64_t fbase = (uint64_t)foff[0];
+  const uint64_t p = fbase + (uint64_t)blockIdx.x * XT + threadIdx.x;
+  const uint64_t i0 = tile_entry[blockIdx.x];
+  load_window(s_foff, foff, f.n_entries, i0);
+  __syncthreads();
+  uint64_t sum = 0, rows_last = 0;
+  if (p < fbase + M) {
+    uint64_t k;
+    uint64_t i = locate_entry(s_foff, foff, f.n_entries, i0, p, &k);
+    uint32_t v;
+    uint64_t q;
+    entry_vertex_q(f, i, &v, &q);
+    const uint32_t x = nbr[(uint64_t)off[v] + k];
+    const uint64_t P = dig_leaf(q, x);
+    if (emit) sum = P;
+    const uint64_t o = p - fbase;
+    nv[o] = x;
+    nq32[o] = (uint32_t)dig_q(P, f.j + 1);
+    rows_last = (uint64_t)(off[x + 1] - off[x]);
+  }
+  block_store_partials(sum, 0, rows_last, s_red, partial);
+}
+
+__global__ __launch_bounds__(XT) void k_expand_front(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                     const uint32_t *__restrict__ fv, const uint32_t *__restrict__ fq32,
+                                                     uint64_t M, unsigned long long *__restrict__ partial) {
+  __shared__ MidShared sm;
+  uint32_t corr = 0;
+  uint32_t acc[MID_R];
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) acc[r] = 0;
+  MidRows rows;
+  MidPrep prep;
+#pragma unroll
+  for (int e = 0; e < MID_EPT; e++) {
+    const uint64_t i = (uint64_t)blockIdx.x * MT + (uint64_t)(e * XT) + threadIdx.x;
+    rows.valid[e] = i < M;
+    rows.x[e] = INVALID_U32;
+    rows.u[e] = 0;
+    prep.q[e] = 0;
+    prep.st[e] = prep.dout[e] = 0;
+    if (rows.valid[e]) {
+      rows.x[e] = fv[i];
+      prep.q[e] = (uint64_t)fq32[i];
+      prep.st[e] = off[rows.x[e]];
+      prep.dout[e] = off[rows.x[e] + 1] - prep.st[e];
+    }
+  }
+  const uint32_t nruns = mid_stage(sm, rows, prep, M, blockIdx.x);
+  mid_fold_tile(sm, nruns, nbr, acc, corr);
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int r = 0; r < MID_R; r++) tsum += acc[r];
+  const uint64_t total = (uint64_t)(uint32_t)(tsum - corr);
+  block_store_partials(0, total, 0, sm.red, partial);
+}
+
 // ---- 3-hop as a product around the LAST inner vertex ----------------------------------------------------------
 // Every 3-hop walk u -> a -> b -> w from every vertex is one pair (2-hop row u -> a -> b, out-edge of b).  The
 // 2-hop rows that end in b are, for every reverse-CSR entry e = (a -> b) of b, the reverse row of a: a two-level
@@ -575,7 +691,13 @@ __global__ __launch_bounds__(XT) void k_expand_mid3(const uint32_t *__restrict__
                                                     uint64_t n_entries, uint64_t M2,
                                                     const uint32_t *__restrict__ tile_entry, int emit_mid,
                                                     unsigned long long *__restrict__ partial /* of tile0 */,
-                                                    uint64_t tile0 /* first tile of this launch */) {
+                                                    uint64_t tile0 /* first tile of this launch */,
+                                                    const uint64_t *__restrict__ fq /* explicit frontier, or nullptr */,
+                                                    int level) {
+  // fq != nullptr: the last TWO hops of an EXPLICIT frontier F_level (source lists, source ranges, k >= 4) in the same
+  // product form — `roff` then holds, per vertex a, where the frontier entries that END in a start in `fq` (the
+  // frontier sorted by its last vertex: their hash states q_level), so the prefixes one hop longer that end in b are,
+  // for every reverse entry (a -> b), those entries; their states are dig_q(dig_leaf(q, b), level + 1).
   __shared__ MidShared sm;
   __shared__ uint64_t s_foff[MT + 1];
   uint64_t mid_sum = 0, rows_last = 0;
@@ -621,12 +743,17 @@ __global__ __launch_bounds__(XT) void k_expand_mid3(const uint32_t *__restrict__
         start = foff2[ent];
       }
       const uint32_t a = rnbr[ent], b = rrow[ent];
-      const uint32_t u = rnbr[(uint64_t)roff[a] + (p - start)];
-      const uint64_t q1 = dig_q(dig_leaf(dig_q((uint64_t)u, 0), a), 1);
+      uint64_t q1;
+      if (fq) {
+        q1 = fq[(uint64_t)roff[a] + (p - start)];
+      } else {
+        const uint32_t u = rnbr[(uint64_t)roff[a] + (p - start)];
+        q1 = dig_q(dig_leaf(dig_q((uint64_t)u, 0), a), 1);
+      }
       const uint64_t P2 = dig_leaf(q1, b);
       if (emit_mid) mid_sum = dsum_add(mid_sum, P2);
       rows.x[e] = b;
-      prep.q[e] = dig_q(P2, 2);
+      prep.q[e] = dig_q(P2, fq ? level + 1 : 2);
       prep.st[e] = off[b];
       prep.dout[e] = off[b + 1] - prep.st[e];
       rows_last += (uint64_t)prep.dout[e];
@@ -1025,7 +1152,126 @@ int khop_count(gg_ctx *ctx, const gg_csr *csr, bool ident, uint32_t lo, uint64_t
   }
 
   // last one or two hops
-  if (M > 0) {
+  // Two hops left and a frontier whose children are a good part of the edge table: the frontier itself (small: one
+  // level below its children) is sorted by last vertex, and the last two hops run through k_expand_mid3's tiles with
+  // the frontier's entries in place of the reverse rows.  (One pass over all reverse entries to size the tiles: not for
+  // small frontiers.)
+  if (k_max - j == 2 && ctx->force_frontier != 1 && csr->n_parts <= 1 && csr->V > 1 &&
+      ((ctx->force_frontier == 0 && M >= csr->E / 8 + 1) || ctx->force_frontier == 3) && M > 0 &&
+      (cur_ident ? n0 : cur.n) < 0xFFFFFFFFull) {
+    gg_csr *mcsr = const_cast<gg_csr *>(csr);
+    GG_TRY(ensure_reverse(ctx, mcsr));
+    const uint64_t nf = cur_ident ? n0 : cur.n, E = csr->E_rev, V = csr->V;
+    uint32_t *fv = nullptr, *qlo = nullptr, *qhi = nullptr, *sv = nullptr, *slo = nullptr, *shi = nullptr, *froff = nullptr;
+    uint64_t *fqs = nullptr, *foff2 = nullptr;
+    for (uint32_t **b : {&qlo, &qhi, &sv, &slo, &shi}) GG_TRY(ctx->dev_alloc((void **)b, nf * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&froff, (V + 1) * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&fqs, nf * sizeof(uint64_t)));
+    const unsigned fgrid = (unsigned)((nf + 255) / 256);
+    const uint32_t *keys = cur.fv;
+    if (cur_ident) {
+      GG_TRY(ctx->dev_alloc((void **)&fv, nf * sizeof(uint32_t)));
+      hipLaunchKernelGGL(k_front_ident, dim3(fgrid), dim3(256), 0, ctx->stream, lo, nf, fv, qlo, qhi);
+      keys = fv;
+    } else {
+      hipLaunchKernelGGL(k_front_split, dim3(fgrid), dim3(256), 0, ctx->stream, (const uint64_t *)cur.fq, nf, qlo, qhi);
+    }
+    int key_bits = 1;
+    while ((1ull << key_bits) < V) key_bits++;
+    GG_TRY(sort_triples_by_key(ctx, keys, qlo, qhi, nf, key_bits, sv, slo, shi));
+    hipLaunchKernelGGL(k_front_offsets, dim3((unsigned)((nf + 256) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)sv,
+                       (const uint32_t *)slo, (const uint32_t *)shi, nf, V, froff, fqs);
+    GG_TRY(ctx->dev_alloc((void **)&foff2, (E + 1) * sizeof(uint64_t)));
+    if (E)
+      hipLaunchKernelGGL(k_front3_prepare, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (const uint32_t *)froff, (const uint32_t *)csr->rnbr, E, foff2);
+    uint64_t M2 = 0;
+    GG_TRY(offsets_from_deg(ctx, foff2, E, &M2));
+    if (M2 != M) {
+      set_error("frontier product: %llu prefixes located through the reverse rows, %llu expected",
+                (unsigned long long)M2, (unsigned long long)M);
+      return GG_ERR_HIP;
+    }
+    const uint64_t n_tiles = (M2 + MT - 1) / MT;
+    if (n_tiles > 0xFFFFFFFFull) {
+      set_error("expansion over %llu prefixes exceeds 2^32 tiles", (unsigned long long)M2);
+      return GG_ERR_TOO_LARGE;
+    }
+    uint32_t *tile_entry = nullptr;
+    unsigned long long *partial = nullptr, *tmp = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&tile_entry, n_tiles * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+    GG_TRY(ctx->dev_alloc((void **)&tmp, 3 * sizeof(unsigned long long)));
+    GG_LAUNCH(ctx, "tile_partition", k_tile_partition_mt, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
+              (const uint64_t *)foff2, E, n_tiles, tile_entry);
+    const uint64_t per_launch =
+        ctx->max_grid_tiles && ctx->max_grid_tiles < MAX_GRID_TILES ? ctx->max_grid_tiles : MAX_GRID_TILES;
+    for (uint64_t t0 = 0; t0 < n_tiles; t0 += per_launch) {
+      const uint64_t nt = n_tiles - t0 < per_launch ? n_tiles - t0 : per_launch;
+      GG_LAUNCH(ctx, "expand_front3", k_expand_mid3, dim3((unsigned)nt), dim3(XT), 0, csr->off, csr->nbr,
+                (const uint32_t *)froff, csr->rrow, csr->rnbr, (const uint64_t *)foff2, E, M2, (const uint32_t *)tile_entry,
+                (int)(j + 1 >= k_min), partial + t0 * 4, t0, (const uint64_t *)fqs, j);
+    }
+    GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    digests[j + 1] = ctx->pin_scratch[0];
+    digests[j + 2] = ctx->pin_scratch[1];
+    walks[j + 2] = ctx->pin_scratch[2];
+    for (void *b : {(void *)fv, (void *)qlo, (void *)qhi, (void *)sv, (void *)slo, (void *)shi, (void *)froff, (void *)fqs,
+                    (void *)foff2, (void *)tile_entry, (void *)partial, (void *)tmp})
+      ctx->dev_free(b);
+  } else
+  // (two hops left and a frontier worth the three sort passes: the product form — pairs, sort by last vertex, fold)
+  if (((ctx->force_frontier == 0 && M >= FRONT_PRODUCT_MIN) || (ctx->force_frontier == 2 && M > 0)) && k_max - j == 2 &&
+      csr->V > 1) {
+    uint32_t *tile_entry = nullptr, *pv = nullptr, *pq = nullptr, *sv = nullptr, *sq = nullptr;
+    uint64_t n_tiles = 0;
+    unsigned long long *partial = nullptr, *tmp = nullptr;
+    GG_TRY(ctx->dev_alloc((void **)&pv, M * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&pq, M * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&tmp, 6 * sizeof(unsigned long long)));
+    Frontier fr;
+    fr.j = j;
+    if (cur_ident) {
+      fr.fv = nullptr;
+      fr.fq = nullptr;
+      fr.n_entries = n0;
+      fr.ident_base = lo;
+      GG_TRY(make_tiles<uint32_t>(ctx, csr->off + lo, n0, M, &tile_entry, &n_tiles));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      GG_LAUNCH(ctx, "expand_pairs", (k_expand_pairs<uint32_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
+                csr->off + lo, fr, M, tile_entry, (int)(j + 1 >= k_min), pv, pq, partial);
+    } else {
+      fr.fv = cur.fv;
+      fr.fq = cur.fq;
+      fr.n_entries = cur.n;
+      fr.ident_base = 0;
+      GG_TRY(make_tiles<uint64_t>(ctx, cur.foff, cur.n, M, &tile_entry, &n_tiles));
+      GG_TRY(ctx->dev_alloc((void **)&partial, n_tiles * 4 * sizeof(unsigned long long)));
+      GG_LAUNCH(ctx, "expand_pairs", (k_expand_pairs<uint64_t>), dim3((unsigned)n_tiles), dim3(XT), 0, csr->off, csr->nbr,
+                cur.foff, fr, M, tile_entry, (int)(j + 1 >= k_min), pv, pq, partial);
+    }
+    GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));  // [0] digest of hop j + 1, [2] rows of the last hop
+    ctx->dev_free(partial);
+    ctx->dev_free(tile_entry);
+    GG_TRY(ctx->dev_alloc((void **)&sv, M * sizeof(uint32_t)));
+    GG_TRY(ctx->dev_alloc((void **)&sq, M * sizeof(uint32_t)));
+    int key_bits = 1;
+    while ((1ull << key_bits) < csr->V) key_bits++;
+    GG_TRY(sort_pairs_by_key(ctx, pv, pq, M, key_bits, sv, sq));
+    const uint64_t f_tiles = (M + MT - 1) / MT;
+    GG_TRY(ctx->dev_alloc((void **)&partial, f_tiles * 4 * sizeof(unsigned long long)));
+    GG_LAUNCH(ctx, "expand_front", k_expand_front, dim3((unsigned)f_tiles), dim3(XT), 0, csr->off, csr->nbr,
+              (const uint32_t *)sv, (const uint32_t *)sq, M, partial);
+    GG_TRY(reduce_partials(ctx, partial, f_tiles, tmp + 3));  // [1] digest of the last hop
+    GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    GG_HIP(hipStreamSynchronize(ctx->stream));
+    digests[j + 1] = ctx->pin_scratch[0];
+    walks[j + 2] = ctx->pin_scratch[2];
+    digests[j + 2] = ctx->pin_scratch[4];
+    for (void *b : {(void *)partial, (void *)tmp, (void *)pv, (void *)pq, (void *)sv, (void *)sq}) ctx->dev_free(b);
+  } else if (M > 0) {
     uint32_t *tile_entry = nullptr;
     uint64_t n_tiles = 0;
     unsigned long long *partial = nullptr;
@@ -1215,7 +1461,7 @@ int khop_count_mid3(gg_ctx *ctx, gg_csr *csr, int k_min, gg_khop_stats *st) {
         const uint64_t nt = n_tiles - t0 < per_launch ? n_tiles - t0 : per_launch;
         GG_LAUNCH(ctx, "expand_mid3", k_expand_mid3, dim3((unsigned)nt), dim3(XT), 0, csr->off, csr->nbr, csr->roff,
                   csr->rrow, csr->rnbr, (const uint64_t *)foff2, E, M2, (const uint32_t *)tile_entry,
-                  (int)(k_min <= 2), partial + t0 * 4, t0);
+                  (int)(k_min <= 2), partial + t0 * 4, t0, (const uint64_t *)nullptr, 0);
       }
       GG_TRY(reduce_partials(ctx, partial, n_tiles, tmp));
       GG_HIP(hipMemcpyAsync(ctx->pin_scratch, tmp, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -1821,10 +2067,10 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
     set_error("a CSR shard (gg_csr_build_shard) only supports all-source 2-hop count expansion");
     return GG_ERR_STATE;
   }
-  if (k_max == 2 && src_lo == 0 && src_hi == csr->V && (!ctx->force_frontier || csr->n_parts > 1)) {
+  if (k_max == 2 && src_lo == 0 && src_hi == csr->V && (ctx->force_frontier == 0 || csr->n_parts > 1)) {
     // every vertex is a source: the 2-hop walks are the per-vertex products in(x) x out(x)
     GG_TRY(khop_count_mid(ctx, const_cast<gg_csr *>(csr), 0, csr->V, k_min, stats));
-  } else if (k_max == 3 && src_lo == 0 && src_hi == csr->V && !ctx->force_frontier && csr->n_parts <= 1) {
+  } else if (k_max == 3 && src_lo == 0 && src_hi == csr->V && ctx->force_frontier == 0 && csr->n_parts <= 1) {
     // ... and the 3-hop walks the products {2-hop rows ending in b} x out(b)
     GG_TRY(khop_count_mid3(ctx, const_cast<gg_csr *>(csr), k_min, stats));
   } else {
@@ -1838,7 +2084,7 @@ extern "C" int gg_expand_khop_range(gg_ctx *ctx, const gg_csr *csr, uint64_t src
     uint32_t *fv = nullptr;
     uint64_t *fdeg = nullptr;
     int rc = GG_OK;
-    if (k_max == 2 && src_lo == 0 && src_hi == csr->V && !ctx->force_frontier) {
+    if (k_max == 2 && src_lo == 0 && src_hi == csr->V && ctx->force_frontier == 0) {
       // every vertex is a source: the rows are the per-vertex products in(x) x out(x), grouped by x (k_mat_mid2)
       rc = khop_materialise_mid2(ctx, const_cast<gg_csr *>(csr), 0, csr->V, k_min, res);
     } else {

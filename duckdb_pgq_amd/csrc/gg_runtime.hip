@@ -377,7 +377,7 @@ extern "C" int gg_ctx_set_edge_rowid(gg_ctx *ctx, int keep) {
 
 extern "C" int gg_debug_force_frontier(gg_ctx *ctx, int on) {
   if (!ctx) return GG_ERR_INVALID_ARG;
-  ctx->force_frontier = on != 0;
+  ctx->force_frontier = on < 0 || on > 3 ? 1 : on;
   return GG_OK;
 }
 
@@ -409,7 +409,7 @@ extern "C" int gg_debug_max_grid_tiles(gg_ctx *ctx, uint64_t max_tiles) {
 
 extern "C" int gg_debug_reset(gg_ctx *ctx) {
   if (!ctx) return GG_ERR_INVALID_ARG;
-  ctx->force_frontier = false;
+  ctx->force_frontier = 0;
   ctx->legacy_build = false;
   if (ctx->rank_mode_forced) ctx->rank_mode = 0;  // (a mode the probe decided is kept: it does not change)
   ctx->rank_mode_forced = false;

@@ -509,7 +509,9 @@ class GG:
         self._chk(self.lib.gg_khop_partition_mid(self.ctx, csr.handle, n_parts, b))
         return list(b)
 
-    def force_frontier(self, on: bool):
+    def force_frontier(self, on):
+        """False / 0: normal; True / 1: frontier kernels only; 2 / 3: the product form of an explicit frontier's last hop /
+        last two hops at any size (and no all-sources product kernels)."""
         self._chk(self.lib.gg_debug_force_frontier(self.ctx, int(on)))
 
     def scan_fault(self, spin_limit: int = 0, mute_tile: int = (1 << 64) - 1):

@@ -322,8 +322,12 @@ int gg_bfs_sharded_levels(const gg_bfs_run *run, uint64_t *push_levels, uint64_t
 void gg_bfs_sharded_end(gg_bfs_run *run);
 
 /* ---- in-library kernel timing (HIP events on the library's own stream) ---------------------- */
-/* Testing knob: force gg_expand_khop to use the frontier kernels even where the product kernel
- * applies (both must give identical results). */
+/* Testing knob: 1 forces gg_expand_khop onto the frontier kernels even where a product kernel applies; 2 and 3 keep
+ * the all-sources product kernels out of it (as 1) but take a product form of an explicit frontier's last hops at any
+ * size — 2: the last hop (pairs, sort by last vertex, fold; by itself from 65 536 frontier entries on), 3: the last two
+ * hops (the frontier sorted by last vertex, k_expand_mid3's tiles over the reverse entries; by itself when the
+ * frontier's children are an eighth of the edge table or more); 0 restores normal operation.  All must give identical
+ * results. */
 int gg_debug_force_frontier(gg_ctx *ctx, int on);
 /* Testing knob: force gg_csr_build onto the multi-pass LSD build that graphs of more than 2^22 vertices
  * (and shard builds) take; both builds must export identical arrays. */

@@ -468,6 +468,56 @@ def test_khop_product_kernel_equals_frontier_kernel(gg, orc, V, E, seed, danglin
     g.close()
 
 
+@pytest.mark.parametrize("V,E,seed,dangling,dup", CASES[3:] + [(64, 6000, 41, 0, 200), (1000, 300000, 42, 0, 0)])
+def test_last_hop_of_an_explicit_frontier_as_a_product(gg, orc, V, E, seed, dangling, dup):
+    """Source lists, source ranges and walks of four hops end in a product form: k_expand_pairs + sort + k_expand_front
+    (the second-to-last frontier as pairs grouped by last vertex: from 65 536 entries on; knob 2 at any size) or the
+    frontier itself sorted by last vertex and k_expand_mid3's tiles over the reverse entries for the last TWO hops (when
+    its children are an eighth of the edge table or more; knob 3 at any size).  Counts and digests must equal the
+    frontier kernels' (knob 1) and the oracle's."""
+    vid, src, dst = datagen.small_graph(V, E, seed, dangling=dangling, dup_edges=dup)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = np.concatenate([vid[: max(1, V // 2)], vid[:3], np.array([-9], np.int64)])
+    dense = g.lookup(sources)
+    dense = dense[dense >= 0].astype(np.uint32)
+    small = lambda k: E * (max(E, 1) / max(V, 1)) ** (k - 1) <= 1e8  # noqa: E731
+    try:
+        for kmin, kmax in [(1, 2), (2, 2), (1, 3), (3, 3), (2, 4)]:
+            if not small(kmax):
+                continue
+            ref_all, ref_list = g.khop(kmin, kmax), g.khop(kmin, kmax, sources_dense=dense)
+            lo, hi = V // 4, V - V // 5
+            ref_range = g.khop(kmin, kmax, lo=lo, hi=hi)
+            for knob in (3, 2, 1):
+                gg.force_frontier(knob)
+                assert gg.expand_khop(csr, kmin, kmax) == ref_all, (knob, kmin, kmax)
+                assert gg.expand_khop(csr, kmin, kmax, sources=sources) == ref_list, (knob, kmin, kmax)
+                assert gg.expand_khop_range(csr, lo, hi, kmin, kmax) == ref_range, (knob, kmin, kmax)
+    finally:
+        gg.force_frontier(0)
+    csr.close()
+    g.close()
+
+
+def test_a_large_source_list_takes_the_product_form_by_itself(gg, orc):
+    """65 536 frontier entries and more: no knob.  3 000 sources of a graph with mean degree 60 have ~180 k 1-hop rows."""
+    vid, src, dst = datagen.ldbc_knows(5000, 300_000, 77)
+    csr, g = build_both(gg, orc, vid, src, dst)
+    sources = vid[:3000]
+    dense = g.lookup(sources).astype(np.uint32)
+    got = gg.expand_khop(csr, 1, 2, sources=sources)
+    assert got == g.khop(1, 2, sources_dense=dense)
+    gg.profile_reset()
+    gg.profile_select(None)
+    gg.profile(True)
+    gg.expand_khop(csr, 1, 2, sources=sources)
+    gg.profile(False)
+    prof = gg.profile_get()
+    assert ("expand_front" in prof or "expand_front3" in prof) and "expand_fused2" not in prof
+    csr.close()
+    g.close()
+
+
 def test_three_hop_product_kernel_on_a_skewed_graph(gg):
     """3-hop product kernel against the frontier kernels on a graph with hubs, isolated vertices and runs of
     reverse entries without 2-hop rows (windows of the flattened index that hold no children)."""
