@@ -32,6 +32,8 @@ constexpr uint64_t MAX_GRID_TILES = 0xFFFFFFFFull / XT;
 // second-to-last frontiers of at least this many entries take the product form of the last hop (pairs + sort by last
 // vertex + fold); smaller ones are over before three sort passes have been launched
 constexpr uint64_t FRONT_PRODUCT_MIN = 1u << 16;
+// last levels of at least this many rows are materialised in the product form (k_mat_front)
+constexpr uint64_t MAT_FRONT_MIN = 1u << 20;
 
 // tile t starts in entry  upper_bound(foff, foff[0] + t*XT) - 1
 template <typename OffT>
@@ -1680,6 +1682,188 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
   }
 }
 
+// ---- the LAST level of any materialised walk as a product (source lists, k >= 3) -----------------------------------
+// k_mat_last translates every child to its id with a gather per OUTPUT row.  The rows of the last level are
+// {rows of level k - 1 that end in x} x out(x): with the level k - 1 table sorted by its last column (a permutation:
+// sort_pairs_by_key of (last vertex, row number)) the ids of out(x) are gathered once per run of equal x, the P prefix
+// ids once per level-(k-1) row, and the rest is k_mat_mid2's line-aligned stores — P + 2 columns instead of 3.
+struct MatFrontArgs {
+  const uint32_t *pcol[GG_MAX_HOPS];  // the P prefix columns of level k - 1 (dense indices), in walk order
+  int64_t *out[GG_MAX_HOPS + 1];      // the P + 2 id columns of level k
+};
+constexpr int MAT_FRONT_MAX_P = 3;    // walks of up to 4 hops (P = k - 1); longer ones keep k_mat_last
+
+template <int P>
+__device__ __forceinline__ void mat_write_rows_p(uint64_t S, uint32_t r_lo, uint32_t r_hi, uint32_t d, uint32_t ib,
+                                                 long long xid, const int64_t (*uid)[256 + 1], const int64_t *oid,
+                                                 const MatFrontArgs &a) {
+  const uint64_t A0 = (S + r_lo) & ~(uint64_t)(MAT_ALIGN - 1);
+  const uint32_t head = (uint32_t)(S + r_lo - A0), total = head + (r_hi - r_lo);
+  const uint32_t m = d >= 2 ? 0xFFFFFFFFu / d + 1u : 0u;  // r / d = umulhi(r, m) for r < 2^32 / d
+  mat_ll2 xx;
+  xx.x = xx.y = xid;
+  for (uint32_t q = threadIdx.x; 2 * q < total; q += 256) {
+    const uint32_t hi = 2 * q + 1;
+    if (hi < head) continue;
+    const uint32_t rh = r_lo + (hi - head);
+    const bool lo_ok = hi > head, hi_ok = rh < r_hi;
+    const uint32_t ih = d >= 2 ? __umulhi(rh, m) : rh, jh = rh - ih * d;
+    const uint32_t il = jh ? ih : ih - 1u, jl = jh ? jh - 1u : d - 1u;
+    mat_ll2 w;
+    w.y = oid[jh];
+    w.x = lo_ok ? oid[jl] : 0;
+    const uint64_t o = A0 + 2 * (uint64_t)q;
+#pragma unroll
+    for (int c = 0; c < P; c++) {
+      mat_ll2 uu;
+      uu.y = uid[c][ib + ih];
+      uu.x = lo_ok ? uid[c][ib + il] : 0;
+      if (lo_ok && hi_ok)
+        __builtin_nontemporal_store(uu, reinterpret_cast<mat_ll2 *>(a.out[c] + o));
+      else if (lo_ok)
+        a.out[c][o] = uu.x;
+      else if (hi_ok)
+        a.out[c][o + 1] = uu.y;
+    }
+    if (lo_ok && hi_ok) {
+      __builtin_nontemporal_store(xx, reinterpret_cast<mat_ll2 *>(a.out[P] + o));
+      __builtin_nontemporal_store(w, reinterpret_cast<mat_ll2 *>(a.out[P + 1] + o));
+    } else if (lo_ok) {
+      a.out[P][o] = xid;
+      a.out[P + 1][o] = w.x;
+    } else if (hi_ok) {
+      a.out[P][o + 1] = xid;
+      a.out[P + 1][o + 1] = w.y;
+    }
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_mat_front(const uint32_t *__restrict__ off, const uint32_t *__restrict__ nbr,
+                                                   const uint32_t *__restrict__ skey, const uint32_t *__restrict__ perm,
+                                                   const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
+                                                   const uint32_t *__restrict__ tile_entry, uint64_t n, uint64_t M2,
+                                                   MatFrontArgs a, uint32_t n_tiles) {
+  __shared__ int64_t s_uid[P ? P : 1][256 + 1];
+  __shared__ int64_t s_oid[MAT_CAP + 1];
+  __shared__ uint64_t s_base[256];
+  __shared__ uint32_t s_x[256], s_run[257], s_wcnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint64_t t_lo = mat_tile_start(tile, n_tiles, M2), t_hi = mat_tile_start(tile + 1ull, n_tiles, M2);
+  const uint64_t e_lo = tile_entry[tile];
+  uint64_t e_hi = (uint64_t)tile_entry[tile + 1] + 1;
+  e_hi = e_hi < n ? e_hi : n;
+  for (uint64_t eb = e_lo; eb < e_hi; eb += 256) {
+    const uint64_t p = eb + threadIdx.x;
+    const bool valid = p < e_hi;
+    uint32_t x = INVALID_U32;
+    __syncthreads();
+    if (valid) {
+      x = skey[p];
+      const uint32_t row = perm[p];
+#pragma unroll
+      for (int c = 0; c < P; c++) s_uid[c][threadIdx.x] = vid[a.pcol[c][row]];
+      s_base[threadIdx.x] = foff[p];
+    }
+    s_x[threadIdx.x] = x;
+    __syncthreads();
+    const bool head = valid && (threadIdx.x == 0 || s_x[threadIdx.x - 1] != x);
+    const uint64_t hm = __ballot(head);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(hm);
+    __syncthreads();
+    uint32_t before = 0, nruns = 0;
+    for (int q = 0; q < 4; q++) {
+      if (q < wave) before += s_wcnt[q];
+      nruns += s_wcnt[q];
+    }
+    if (head) s_run[before + __popcll(hm & ((1ULL << lane) - 1ULL))] = threadIdx.x;
+    if (threadIdx.x == 0) s_run[nruns] = e_hi - eb < 256 ? (uint32_t)(e_hi - eb) : 256u;
+    __syncthreads();
+    for (uint32_t r = 0; r < nruns; r++) {
+      const uint32_t i0 = s_run[r], i1 = s_run[r + 1];
+      const uint32_t xr = s_x[i0], st = off[xr], dout = off[xr + 1] - st;
+      if (dout == 0) continue;
+      const uint64_t Bs = s_base[i0], Be = Bs + (uint64_t)(i1 - i0) * dout;
+      const uint64_t lo = Bs > t_lo ? Bs : t_lo, hi = Be < t_hi ? Be : t_hi;
+      if (lo >= hi) continue;
+      const long long xid = vid[xr];
+      for (uint32_t jc = 0; jc < dout; jc += MAT_CAP) {
+        const uint32_t clen = dout - jc < MAT_CAP ? dout - jc : MAT_CAP;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < clen; j += 256) s_oid[j] = vid[nbr[st + jc + j]];
+        __syncthreads();
+        if (dout <= MAT_CAP) {
+          mat_write_rows_p<P>(Bs, (uint32_t)(lo - Bs), (uint32_t)(hi - Bs), dout, i0, xid, s_uid, s_oid, a);
+        } else {
+          for (uint32_t i = i0; i < i1; i++) {
+            const uint64_t S = s_base[i] + jc, slo = S > t_lo ? S : t_lo, shi = S + clen < t_hi ? S + clen : t_hi;
+            if (slo < shi) mat_write_rows_p<P>(S, (uint32_t)(slo - S), (uint32_t)(shi - S), clen, i, xid, s_uid, s_oid, a);
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_iota_u32(uint64_t n, uint32_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint32_t)i;
+}
+
+// children of the sorted level-(k-1) row p: the out-degree of its last vertex
+__global__ __launch_bounds__(256) void k_mat_front_prepare(const uint32_t *__restrict__ off, const uint32_t *__restrict__ skey,
+                                                           uint64_t n, uint64_t *__restrict__ foff) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) foff[i] = (uint64_t)(off[skey[i] + 1] - off[skey[i]]);
+}
+
+// the last level (h = P + 1 hops, h + 1 id columns in out_cols) of a materialisation as a product; M: its rows
+int khop_materialise_front(gg_ctx *ctx, const gg_csr *csr, const std::vector<uint32_t *> &prev_cols, uint64_t n_prev,
+                           uint64_t M, int64_t *const *out_cols) {
+  const int P = (int)prev_cols.size() - 1;
+  uint32_t *iota = nullptr, *skey = nullptr, *perm = nullptr, *tile_entry = nullptr;
+  uint64_t *foff = nullptr;
+  GG_TRY(ctx->dev_alloc((void **)&iota, n_prev * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&skey, n_prev * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&perm, n_prev * sizeof(uint32_t)));
+  GG_TRY(ctx->dev_alloc((void **)&foff, (n_prev + 1) * sizeof(uint64_t)));
+  const unsigned grid = (unsigned)((n_prev + 255) / 256);
+  hipLaunchKernelGGL(k_iota_u32, dim3(grid), dim3(256), 0, ctx->stream, n_prev, iota);
+  int key_bits = 1;
+  while ((1ull << key_bits) < csr->V) key_bits++;
+  GG_TRY(sort_pairs_by_key(ctx, prev_cols[P], iota, n_prev, key_bits, skey, perm));
+  hipLaunchKernelGGL(k_mat_front_prepare, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t *)csr->off,
+                     (const uint32_t *)skey, n_prev, foff);
+  uint64_t M2 = 0;
+  GG_TRY(offsets_from_deg(ctx, foff, n_prev, &M2));
+  if (M2 != M) {
+    set_error("materialisation: %llu rows behind the sorted level, %llu expected", (unsigned long long)M2,
+              (unsigned long long)M);
+    return GG_ERR_HIP;
+  }
+  const uint64_t n_tiles = (M2 + MAT_ROWS - 1) / MAT_ROWS;
+  GG_TRY(ctx->dev_alloc((void **)&tile_entry, (n_tiles + 1) * sizeof(uint32_t)));
+  GG_LAUNCH(ctx, "mat_tile_entries", k_mat_tile_entries, dim3((unsigned)((n_tiles + 256) / 256)), dim3(256), 0,
+            (const uint64_t *)foff, n_prev, n_tiles, M2, tile_entry);
+  MatFrontArgs a;
+  for (int c = 0; c < GG_MAX_HOPS; c++) a.pcol[c] = c < P ? prev_cols[c] : nullptr;
+  for (int c = 0; c <= GG_MAX_HOPS; c++) a.out[c] = c <= P + 1 ? out_cols[c] : nullptr;
+#define GG_MAT_FRONT(PP)                                                                                              \
+  GG_LAUNCH(ctx, "mat_front", (k_mat_front<PP>), dim3((unsigned)n_tiles), dim3(256), 0, csr->off, csr->nbr,           \
+            (const uint32_t *)skey, (const uint32_t *)perm, csr->vid, (const uint64_t *)foff,                        \
+            (const uint32_t *)tile_entry, n_prev, M2, a, (uint32_t)n_tiles)
+  switch (P) {
+  case 0: GG_MAT_FRONT(0); break;
+  case 1: GG_MAT_FRONT(1); break;
+  case 2: GG_MAT_FRONT(2); break;
+  default: GG_MAT_FRONT(3); break;
+  }
+#undef GG_MAT_FRONT
+  for (void *b : {(void *)iota, (void *)skey, (void *)perm, (void *)foff, (void *)tile_entry}) ctx->dev_free(b);
+  return GG_OK;
+}
+
 // 2-hop rows (and, with k_min == 1, the 1-hop rows) whose MIDDLE vertex lies in [mid_lo, mid_hi), through
 // k_mat_mid2; the whole graph for [0, V).  The 1-hop table of a middle range holds the edges INTO the range.
 int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min, gg_result *res) {
@@ -1793,8 +1977,14 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
       res->rows[h] = M;
       IdCols oc;
       for (int c = 0; c <= GG_MAX_HOPS; c++) oc.c[c] = nullptr;
+      if (h == 2) {  // three columns written in lockstep: a placed set when they are large (gg_runtime.hip "Placement")
+        void *three[3] = {nullptr, nullptr, nullptr};
+        GG_TRY(ctx->dev_alloc_columns(three, (M ? M : 1) * sizeof(int64_t)));
+        for (int c = 0; c <= h; c++) res->cols[h][c] = reinterpret_cast<int64_t *>(three[c]);
+      } else {
+        for (int c = 0; c <= h; c++) GG_TRY(ctx->dev_alloc((void **)&res->cols[h][c], (M ? M : 1) * sizeof(int64_t)));
+      }
       for (int c = 0; c <= h; c++) {
-        GG_TRY(ctx->dev_alloc((void **)&res->cols[h][c], (M ? M : 1) * sizeof(int64_t)));
         ctx->keep(res->cols[h][c]);
         oc.c[c] = res->cols[h][c];
       }
@@ -1820,6 +2010,10 @@ int khop_materialise(gg_ctx *ctx, const gg_csr *csr, const uint32_t *fv0, uint64
                   csr->nbr, csr->vid, (const int64_t *)csr->eid, (const uint32_t *)csr->epos, (const uint64_t *)foff, n_prev, M,
                   (const uint32_t *)tile_entry, h - 1, d_in, e_in, ec);
         ctx->dev_free(tile_entry);
+      } else if (M && (int)cols_prev.size() - 1 <= MAT_FRONT_MAX_P && n_prev < 0xFFFFFFFFull && csr->V > 1 &&
+                 ((ctx->force_frontier == 0 && M >= MAT_FRONT_MIN) || ctx->force_frontier >= 2)) {
+        // the product form: level h - 1 sorted by its last vertex, out-rows' ids gathered once per run
+        GG_TRY(khop_materialise_front(ctx, csr, cols_prev, n_prev, M, res->cols[h]));
       } else if (M) {
         GG_HIP(hipMemcpyAsync(d_in, cols_prev.data(), cols_prev.size() * sizeof(void *), hipMemcpyHostToDevice,
                               ctx->stream));

@@ -493,6 +493,17 @@ def test_last_hop_of_an_explicit_frontier_as_a_product(gg, orc, V, E, seed, dang
                 assert gg.expand_khop(csr, kmin, kmax) == ref_all, (knob, kmin, kmax)
                 assert gg.expand_khop(csr, kmin, kmax, sources=sources) == ref_list, (knob, kmin, kmax)
                 assert gg.expand_khop_range(csr, lo, hi, kmin, kmax) == ref_range, (knob, kmin, kmax)
+        # the same walks MATERIALISED: the last level through k_mat_front (knobs 2, 3: level k - 1 sorted by last
+        # vertex, P + 2 id columns) against k_mat_last (knob 1) and the oracle's rows
+        for kmin, kmax in [(1, 2), (2, 3), (4, 4)]:
+            if not small(kmax) or E * (max(E, 1) / max(V, 1)) ** (kmax - 1) > 3e6:
+                continue
+            want = g.khop_rows(kmin, kmax, sources_dense=dense)
+            for knob in (2, 1):
+                gg.force_frontier(knob)
+                got = gg.expand_khop(csr, kmin, kmax, sources=sources, materialise=True)["tables"]
+                for h in range(kmin, kmax + 1):
+                    assert np.array_equal(sort_rows(got[h]), sort_rows(want[h])), (knob, h)
     finally:
         gg.force_frontier(0)
     csr.close()
