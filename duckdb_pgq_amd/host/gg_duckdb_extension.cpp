@@ -607,14 +607,34 @@ static void LoadInternal(DatabaseInstance &db) {
 } // namespace duckdb
 
 // GG_CRASH_TRACE=1: a backtrace on stderr when the process dies of SIGSEGV / SIGBUS / SIGABRT (diagnostic: the boxes
-// this runs on have no debugger)
-static void GGCrashHandler(int sig) {
+// this runs on have no debugger).  Installed with sigaction and SA_RESETHAND (the handler runs once, then the default
+// action or whatever the application had takes over); the handlers that were installed before are kept and chained to;
+// backtrace() is called once at load, so that its lazy dlopen of libgcc (which allocates) does not happen inside a signal
+// handler.  A diagnostic all the same: off unless the variable is set.
+static struct sigaction g_previous_action[3];
+static const int g_crash_signals[3] = {SIGSEGV, SIGBUS, SIGABRT};
+
+static void GGCrashHandler(int sig, siginfo_t *info, void *ucontext) {
 	void *frames[64];
 	const int n = backtrace(frames, 64);
 	const char msg[] = "\n=== gg crash trace ===\n";
 	(void)!write(2, msg, sizeof(msg) - 1);
 	backtrace_symbols_fd(frames, n, 2);
-	signal(sig, SIG_DFL);
+	for (int i = 0; i < 3; i++) {
+		if (g_crash_signals[i] != sig) {
+			continue;
+		}
+		auto &old = g_previous_action[i];
+		if ((old.sa_flags & SA_SIGINFO) && old.sa_sigaction) {
+			old.sa_sigaction(sig, info, ucontext); // the embedding application's own handler
+			return;
+		}
+		if (old.sa_handler != SIG_DFL && old.sa_handler != SIG_IGN && old.sa_handler) {
+			old.sa_handler(sig);
+			return;
+		}
+	}
+	// (SA_RESETHAND put the default action back: re-raising ends the process the way it would have ended)
 	raise(sig);
 }
 
@@ -622,8 +642,15 @@ extern "C" {
 
 void gg_duckdb_init(duckdb::DatabaseInstance &db) {
 	if (std::getenv("GG_CRASH_TRACE")) {
-		for (int sig : {SIGSEGV, SIGBUS, SIGABRT}) {
-			signal(sig, GGCrashHandler);
+		void *warm[2];
+		(void)backtrace(warm, 2); // (loads libgcc's unwinder now, not in the handler)
+		for (int i = 0; i < 3; i++) {
+			struct sigaction action;
+			memset(&action, 0, sizeof(action));
+			action.sa_sigaction = GGCrashHandler;
+			action.sa_flags = SA_SIGINFO | SA_RESETHAND;
+			sigemptyset(&action.sa_mask);
+			sigaction(g_crash_signals[i], &action, &g_previous_action[i]);
 		}
 	}
 	duckdb::LoadInternal(db);

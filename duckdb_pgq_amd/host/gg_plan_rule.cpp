@@ -2234,7 +2234,114 @@ unique_ptr<PhysicalOperator> PlanShortestPath(LogicalAggregate &op) {
 // under the edge relation (gg_walk_endpoints): one row per endpoint with a flag per walk length, so the UNION
 // is a filter — in the 1-hop set, or in the 2-hop set and passing the second branch's own predicates on the endpoint —
 // and nothing is left to dedupe.
+//! Distinct rule 2 (round 4): `SELECT DISTINCT <end vertex> FROM` a walk of h >= 2 edges over one edge table pinned at
+//! its first vertex — the dedupe the reference plans as a hash aggregate above the projection of its joins
+//! (src/execution/physical_plan/plan_distinct.cpp:12-78) is the SET IMAGE of h hops from the source: gg_walk_endpoints
+//! keeps, per vertex, a flag for every walk length that ends there; the rule keeps the vertices whose flag h is set
+//! (and that pass the predicates the statement puts on the end vertex).
+unique_ptr<PhysicalOperator> PlanDistinctEndpoints(LogicalDistinct &op) {
+	if (op.children.size() != 1 || op.types.size() != 1 || op.children[0]->type != LogicalOperatorType::LOGICAL_PROJECTION) {
+		return nullptr;
+	}
+	if (op.distinct_targets.size() > 1 ||
+	    (op.distinct_targets.size() == 1 && (op.distinct_targets[0]->type != ExpressionType::BOUND_REF ||
+	                                         ((BoundReferenceExpression &)*op.distinct_targets[0]).index != 0))) {
+		return nullptr;
+	}
+	auto &projection_op = *op.children[0];
+	if (projection_op.children.size() != 1 || projection_op.expressions.size() != 1 ||
+	    projection_op.expressions[0]->type != ExpressionType::BOUND_REF ||
+	    projection_op.children[0]->type != LogicalOperatorType::LOGICAL_COMPARISON_JOIN) {
+		return nullptr;
+	}
+	auto &join = *projection_op.children[0];
+	PatternInput in;
+	WalkPattern pattern;
+	if (!CollectJoinTree(join, in) || !SolveWalkPattern(in, pattern) || pattern.hops < 2 || pattern.hops > GG_MAX_HOPS ||
+	    pattern.all_sources || pattern.sources.size() != 1 || pattern.vertex_table) {
+		return nullptr;
+	}
+	const idx_t hops = pattern.hops;
+	for (auto &entry : pattern.residual) {
+		if (entry.first != hops) {
+			return nullptr; // a predicate on an inner vertex changes which walks exist
+		}
+	}
+	{
+		auto bindings = join.GetColumnBindings();
+		const auto index = ((BoundReferenceExpression &)*projection_op.expressions[0]).index;
+		LeafColumn column;
+		if (index >= bindings.size() || !ResolveLeafColumn(in, bindings[index], column) ||
+		    pattern.edge_position[column.leaf] != hops || column.column != pattern.dst_column) {
+			return nullptr;
+		}
+	}
+	auto &table = *pattern.edge_table;
+	if (!ColumnIsNotNull(table, pattern.dst_column) || table.columns[pattern.dst_column].type != op.types[0]) {
+		return nullptr; // a NULL endpoint is a row of the reference's DISTINCT; the vertex set has no NULL
+	}
+	const auto spec = GraphSpecOf(pattern);
+	const auto sources = pattern.sources;
+	const int k_max = (int)hops;
+	auto data = make_unique<GGFunctionData>();
+	data->open = [=](ClientContext &context, GGOpened &opened) {
+		opened.graph = GGBuildGraph(context, spec);
+		opened.source = make_unique<PhysicalGGWalkEndpoints>(opened.graph, sources, k_max, 0);
+	};
+	data->description = table.name + ": " + table.columns[pattern.src_column].name + " -> " +
+	                    table.columns[pattern.dst_column].name + "\ndistinct endpoints of " + to_string(hops) +
+	                    " hops\nfrom " + to_string(sources[0]);
+	auto types = PhysicalGGWalkEndpoints::OutputTypes(k_max);
+	g_rules_fired++;
+	unique_ptr<PhysicalOperator> scan;
+	if (g_plan_context && GGPipelineSinksAvailable(*g_plan_context, spec)) {
+		scan = GGMakeGraphScan(
+		    spec, move(types), "GG_WALK_ENDPOINTS", data->description, false,
+		    [=](ClientContext &, shared_ptr<GGGraph> graph) -> unique_ptr<PhysicalOperator> {
+			    return make_unique<PhysicalGGWalkEndpoints>(move(graph), sources, k_max, 0);
+		    },
+		    op.estimated_cardinality);
+	} else {
+		vector<column_t> column_ids;
+		vector<string> names;
+		for (idx_t c = 0; c < types.size(); c++) {
+			column_ids.push_back(c);
+			names.push_back("c" + to_string(c));
+		}
+		scan = make_unique<PhysicalTableScan>(move(types), GGScanFunction("gg_walk_endpoints"), move(data),
+		                                      move(column_ids), move(names), nullptr, op.estimated_cardinality);
+	}
+	// scan columns: (id, h1, ..., hk).  keep: hk = 1 AND the statement's predicates on the end vertex
+	unique_ptr<Expression> keep = make_unique<BoundComparisonExpression>(
+	    ExpressionType::COMPARE_EQUAL, make_unique<BoundReferenceExpression>(LogicalType::BIGINT, hops),
+	    make_unique<BoundConstantExpression>(Value::BIGINT(1)));
+	if (!pattern.residual.empty()) {
+		auto both = make_unique<BoundConjunctionExpression>(ExpressionType::CONJUNCTION_AND);
+		both->children.push_back(move(keep));
+		for (auto &entry : pattern.residual) {
+			both->children.push_back(FilterToExpression(*entry.second, 0));
+		}
+		keep = move(both);
+	}
+	vector<unique_ptr<Expression>> predicates;
+	predicates.push_back(move(keep));
+	auto filter = make_unique<PhysicalFilter>(scan->types, move(predicates), op.estimated_cardinality);
+	filter->children.push_back(move(scan));
+	vector<unique_ptr<Expression>> select_list;
+	unique_ptr<Expression> ref = make_unique<BoundReferenceExpression>(LogicalType::BIGINT, 0);
+	if (op.types[0] != LogicalType::BIGINT) {
+		ref = make_unique<BoundCastExpression>(move(ref), op.types[0]);
+	}
+	select_list.push_back(move(ref));
+	auto projection = make_unique<PhysicalProjection>(op.types, move(select_list), op.estimated_cardinality);
+	projection->children.push_back(move(filter));
+	return move(projection);
+}
+
 unique_ptr<PhysicalOperator> PlanDistinctUnion(LogicalDistinct &op) {
+	if (op.children.size() == 1 && op.children[0]->type == LogicalOperatorType::LOGICAL_PROJECTION) {
+		return PlanDistinctEndpoints(op);
+	}
 	if (op.children.size() != 1 || op.types.size() != 1 || op.children[0]->type != LogicalOperatorType::LOGICAL_UNION) {
 		return nullptr;
 	}

@@ -360,6 +360,20 @@ def test_unions_that_are_not_friends_and_friends_of_friends_keep_their_dedupe():
     ]
     for sql in near_misses:
         assert "GG_WALK_ENDPOINTS" not in d.explain(sql), sql
+    # distinct rule 2: SELECT DISTINCT <end vertex> of a pinned walk of h >= 2 edges is the set image of h hops
+    three = ("select distinct k3.k_person2id from knows k1, knows k2, knows k3 where k1.k_person1id = {} "
+             "and k1.k_person2id = k2.k_person1id and k2.k_person2id = k3.k_person1id{}")
+    for sql in (two.format(a, "").replace("select ", "select distinct ", 1),
+                two.format(a, " and k2.k_person2id <> {}".format(a)).replace("select ", "select distinct ", 1),
+                three.format(a, ""), three.format(a, " and k3.k_person2id > 1000")):
+        plan = d.explain(sql)
+        assert "GG_WALK_ENDPOINTS" in plan and "HASH_GROUP_BY" not in plan, (sql, plan)
+    for sql in (three.format(a, " and k2.k_person2id <> 5"),                                  # predicate on an inner vertex
+                three.format(a, "").replace("distinct k3.k_person2id", "distinct k2.k_person2id"),  # not the end vertex
+                three.format(a, "").replace("distinct k3.k_person2id", "distinct k1.k_person1id, k3.k_person2id"),
+                "select distinct k2.k_person2id from knows k1, knows k2 where k1.k_person2id = k2.k_person1id",  # no source
+                "select distinct k2.b from knows_nullable k1, knows_nullable k2 where k1.a = {} and k1.b = k2.a".format(a)):
+        assert "GG_WALK_ENDPOINTS" not in d.explain(sql), sql
     d.close()
 
 
