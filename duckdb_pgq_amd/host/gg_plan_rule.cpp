@@ -136,6 +136,9 @@ struct PatternInput {
 	vector<std::pair<LeafColumn, LeafColumn>> equalities;
 	vector<LeafConstant> constants;
 	vector<LeafFilter> filters;
+	//! filters pushed into a leaf's scan on a column that is no integer key (VARCHAR, DATE, ...): only ever a predicate
+	//! on a PAYLOAD column of an edge instance (join rule 3 evaluates it above the rows it fetches by rowid)
+	vector<LeafFilter> other_filters;
 	vector<unique_ptr<TableFilter>> owned_filters; // filters rebuilt from a LogicalFilter above a leaf
 	//! pure column projections above a leaf (column pruning leaves one after a filter whose column is not
 	//! needed further up): projection table index -> the leaf column behind each of its outputs
@@ -155,6 +158,14 @@ struct WalkPattern {
 	//! above the GPU scan.  (walk position, the pushed-down filter) — the filter outlives planning inside
 	//! the logical operator tree only, so it is turned into an expression before the rule returns
 	vector<std::pair<idx_t, TableFilter *>> residual;
+	//! predicates on payload columns of edge instances (k2.creationDate > D, k1.weight = 3): (1-based edge number,
+	//! column of the edge table, the pushed-down filter) — evaluated on the columns PhysicalGGPathEdges fetches by rowid
+	struct PayloadFilter {
+		idx_t edge;
+		column_t column;
+		TableFilter *filter;
+	};
+	vector<PayloadFilter> payload_filters;
 	//! per leaf: walk position of its src column (edge leaves: position of dst is +1) or of its key
 	vector<idx_t> edge_position;   // leaf -> 1-based edge number, 0 for vertex leaves
 	vector<idx_t> vertex_position; // leaf -> walk position (vertex leaves only)
@@ -479,6 +490,68 @@ unique_ptr<TableFilter> ExpressionToFilter(Expression &expr, idx_t &ref_index) {
 	}
 }
 
+//! A pushed-down filter on a column of ANY type, of the shapes FilterCombiner emits (filter_combiner.cpp): comparisons
+//! with a constant, IS [NOT] NULL, AND / OR of those.
+bool PayloadFilterSupported(TableFilter &filter) {
+	switch (filter.filter_type) {
+	case TableFilterType::IS_NULL:
+	case TableFilterType::IS_NOT_NULL:
+	case TableFilterType::CONSTANT_COMPARISON:
+		return true;
+	case TableFilterType::CONJUNCTION_AND:
+		for (auto &child : ((ConjunctionAndFilter &)filter).child_filters) {
+			if (!PayloadFilterSupported(*child)) {
+				return false;
+			}
+		}
+		return true;
+	case TableFilterType::CONJUNCTION_OR:
+		for (auto &child : ((ConjunctionOrFilter &)filter).child_filters) {
+			if (!PayloadFilterSupported(*child)) {
+				return false;
+			}
+		}
+		return true;
+	default:
+		return false;
+	}
+}
+
+//! The same filter as an expression over scan column `column` of type `type`
+unique_ptr<Expression> PayloadFilterToExpression(TableFilter &filter, idx_t column, const LogicalType &type) {
+	switch (filter.filter_type) {
+	case TableFilterType::IS_NULL:
+	case TableFilterType::IS_NOT_NULL: {
+		auto result = make_unique<BoundOperatorExpression>(filter.filter_type == TableFilterType::IS_NULL
+		                                                       ? ExpressionType::OPERATOR_IS_NULL
+		                                                       : ExpressionType::OPERATOR_IS_NOT_NULL,
+		                                                   LogicalType::BOOLEAN);
+		result->children.push_back(make_unique<BoundReferenceExpression>(type, column));
+		return move(result);
+	}
+	case TableFilterType::CONSTANT_COMPARISON: {
+		auto &constant = (ConstantFilter &)filter;
+		return make_unique<BoundComparisonExpression>(constant.comparison_type,
+		                                              make_unique<BoundReferenceExpression>(type, column),
+		                                              make_unique<BoundConstantExpression>(constant.constant.CastAs(type)));
+	}
+	case TableFilterType::CONJUNCTION_AND:
+	case TableFilterType::CONJUNCTION_OR: {
+		const bool is_and = filter.filter_type == TableFilterType::CONJUNCTION_AND;
+		auto &children = is_and ? ((ConjunctionAndFilter &)filter).child_filters
+		                        : ((ConjunctionOrFilter &)filter).child_filters;
+		auto result = make_unique<BoundConjunctionExpression>(is_and ? ExpressionType::CONJUNCTION_AND
+		                                                             : ExpressionType::CONJUNCTION_OR);
+		for (auto &child : children) {
+			result->children.push_back(PayloadFilterToExpression(*child, column, type));
+		}
+		return move(result);
+	}
+	default:
+		throw InternalException("gg: unexpected table filter");
+	}
+}
+
 //! Flatten a tree of inner equi-joins over sequential scans; false if anything else is in it.
 bool CollectJoinTree(LogicalOperator &op, PatternInput &in) {
 	switch (op.type) {
@@ -497,8 +570,15 @@ bool CollectJoinTree(LogicalOperator &op, PatternInput &in) {
 		for (auto &entry : get.table_filters.filters) {
 			int64_t value;
 			string ignored;
-			if (entry.first >= bind.table->columns.size() || !ColumnIsIntegerKey(*bind.table, entry.first)) {
+			if (entry.first >= bind.table->columns.size()) {
 				return false;
+			}
+			if (!ColumnIsIntegerKey(*bind.table, entry.first)) {
+				if (!PayloadFilterSupported(*entry.second)) {
+					return false;
+				}
+				in.other_filters.push_back({{in.leaves.size() - 1, entry.first}, entry.second.get()});
+				continue;
 			}
 			if (IsEqualityWithConstant(*entry.second, value)) {
 				in.constants.push_back({{in.leaves.size() - 1, entry.first}, value, entry.second.get()});
@@ -818,9 +898,27 @@ bool SolveWithRoles(PatternInput &in, ColumnClasses &classes, TableCatalogEntry 
 	out.all_sources = true;
 	out.sources.clear();
 	out.residual.clear();
+	out.payload_filters.clear();
+	// a filter on a column of an EDGE instance that is neither of its keys is a predicate on that edge's payload
+	auto payload_of = [&](const LeafColumn &column, TableFilter *filter) {
+		const auto l = column.leaf;
+		if (!out.edge_position[l] || column.column == src || column.column == dst) {
+			return false;
+		}
+		out.payload_filters.push_back({out.edge_position[l], column.column, filter});
+		return true;
+	};
+	for (auto &filter : in.other_filters) {
+		if (!payload_of(filter.column, filter.filter)) {
+			return false;
+		}
+	}
 	for (auto &constant : in.constants) {
 		idx_t position;
 		if (!position_of(constant.column, position)) {
+			if (payload_of(constant.column, constant.filter)) {
+				continue;
+			}
 			return false;
 		}
 		if (position == 0) {
@@ -836,6 +934,9 @@ bool SolveWithRoles(PatternInput &in, ColumnClasses &classes, TableCatalogEntry 
 	for (auto &filter : in.filters) {
 		idx_t position;
 		if (!position_of(filter.column, position)) {
+			if (payload_of(filter.column, filter.filter)) {
+				continue;
+			}
 			return false;
 		}
 		out.residual.emplace_back(position, filter.filter);
@@ -1151,7 +1252,7 @@ bool SolveSameNeighbourWithRoles(PatternInput &in, ColumnClasses &classes, SameN
 }
 
 bool SolveSameNeighbourPattern(PatternInput &in, SameNeighbourPattern &out) {
-	if (in.leaves.size() < 3 || !in.constants.empty() || !in.filters.empty()) {
+	if (in.leaves.size() < 3 || !in.constants.empty() || !in.filters.empty() || !in.other_filters.empty()) {
 		return false;
 	}
 	vector<TableCatalogEntry *> tables;
@@ -1434,14 +1535,29 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 		}
 		select_list.push_back(move(ref));
 	}
+	// predicates on payload columns of the edge instances: the columns join the fetched ones (whether or not the
+	// statement projects them) and the predicate is evaluated above the scan, on every walk with ITS edges' values
+	vector<unique_ptr<Expression>> payload_predicates;
+	for (auto &entry : pattern.payload_filters) {
+		if (pattern.hops > 4) {
+			return nullptr;
+		}
+		const auto key = std::make_pair(entry.edge, entry.column);
+		idx_t at = std::find(payload.begin(), payload.end(), key) - payload.begin();
+		if (at == payload.size()) {
+			payload.push_back(key);
+		}
+		payload_predicates.push_back(PayloadFilterToExpression(*entry.filter, 2 + pattern.hops + at,
+		                                                       pattern.edge_table->columns[entry.column].type));
+	}
 	if (!payload.empty() && (!g_plan_context || Transaction::GetTransaction(*g_plan_context).ChangesMade())) {
 		return nullptr; // (rows this transaction has appended have no rowid the base table could be asked for)
 	}
 	auto scan = payload.empty() ? MakeExpandScan(pattern, false, op.estimated_cardinality)
 	                            : MakeEdgeScan(pattern, payload, op.estimated_cardinality);
-	if (!pattern.residual.empty()) {
+	if (!pattern.residual.empty() || !payload_predicates.empty()) {
 		// predicates on walk positions other than the source: a filter over the scan's (hops, v0, v1, ...)
-		vector<unique_ptr<Expression>> predicates;
+		vector<unique_ptr<Expression>> predicates = move(payload_predicates);
 		for (auto &entry : pattern.residual) {
 			predicates.push_back(FilterToExpression(*entry.second, 1 + entry.first));
 		}
@@ -1462,7 +1578,7 @@ unique_ptr<PhysicalOperator> PlanJoinChain(LogicalComparisonJoin &op) {
 //! (src/execution/join_hashtable.cpp:304-476).  NULL keys join nothing on either side (the sinks skip them).
 unique_ptr<PhysicalOperator> MakeKeyJoinCountScan(PatternInput &in) {
 	if (in.leaves.size() != 2 || in.equalities.size() != 1 || !in.constants.empty() || !in.filters.empty() ||
-	    !in.aliases.empty()) {
+	    !in.other_filters.empty() || !in.aliases.empty()) {
 		return nullptr;
 	}
 	auto a = in.equalities[0].first, b = in.equalities[0].second;
@@ -1636,7 +1752,7 @@ unique_ptr<PhysicalOperator> PlanCountOverJoinChain(LogicalAggregate &op) {
 		return nullptr;
 	}
 	const bool is_walk = SolveWalkPattern(in, pattern);
-	if (is_walk && !pattern.residual.empty()) {
+	if (is_walk && (!pattern.residual.empty() || !pattern.payload_filters.empty())) {
 		return nullptr; // (with a residual predicate the walks must be looked at: the join rule takes the join)
 	}
 	// scan columns: (hops, rows, digest, traversed_edges), one row; every count(*) is `rows`
@@ -2258,7 +2374,7 @@ unique_ptr<PhysicalOperator> PlanDistinctEndpoints(LogicalDistinct &op) {
 	PatternInput in;
 	WalkPattern pattern;
 	if (!CollectJoinTree(join, in) || !SolveWalkPattern(in, pattern) || pattern.hops < 2 || pattern.hops > GG_MAX_HOPS ||
-	    pattern.all_sources || pattern.sources.size() != 1 || pattern.vertex_table) {
+	    pattern.all_sources || pattern.sources.size() != 1 || pattern.vertex_table || !pattern.payload_filters.empty()) {
 		return nullptr;
 	}
 	const idx_t hops = pattern.hops;
@@ -2371,7 +2487,7 @@ unique_ptr<PhysicalOperator> PlanDistinctUnion(LogicalDistinct &op) {
 	WalkPattern pattern;
 	auto &join = *two->children[0];
 	if (!CollectJoinTree(join, in2) || !SolveWalkPattern(in2, pattern) || pattern.hops != 2 || pattern.all_sources ||
-	    pattern.sources.size() != 1 || pattern.vertex_table) {
+	    pattern.sources.size() != 1 || pattern.vertex_table || !pattern.payload_filters.empty()) {
 		return nullptr;
 	}
 	for (auto &entry : pattern.residual) {
@@ -2391,7 +2507,7 @@ unique_ptr<PhysicalOperator> PlanDistinctUnion(LogicalDistinct &op) {
 	// the 1-hop branch: the same table, source and endpoint columns, the same constant, nothing else
 	PatternInput in1;
 	if (!CollectJoinTree(*one, in1) || in1.leaves.size() != 1 || in1.leaves[0].table != pattern.edge_table ||
-	    !in1.filters.empty() || in1.constants.size() != 1 || in1.constants[0].column.column != pattern.src_column ||
+	    !in1.filters.empty() || !in1.other_filters.empty() || in1.constants.size() != 1 || in1.constants[0].column.column != pattern.src_column ||
 	    in1.constants[0].value != pattern.sources[0] || in1.aliases.empty()) {
 		return nullptr;
 	}

@@ -730,6 +730,11 @@ def test_join_chains_with_payload_columns_of_their_edges(db):
         f"SELECT k1.w, k2.tag, k2.b FROM kw k1, kw k2 WHERE k1.b = k2.a AND k1.a = {s}",
         "SELECT count(*), sum(k1.w), sum(k3.w), count(k2.tag), min(k3.tag) FROM kw k1, kw k2, kw k3 "
         "WHERE k1.b = k2.a AND k2.b = k3.a",
+        # PREDICATES on payload columns of the edge instances (round 4): evaluated on the fetched columns, per walk
+        "SELECT k1.a, k2.b FROM kw k1, kw k2 WHERE k1.b = k2.a AND k2.w > 50",
+        "SELECT k1.a, k1.w, k2.b FROM kw k1, kw k2 WHERE k1.b = k2.a AND k1.w < 20 AND k2.tag = 't3'",
+        f"SELECT k2.b, k2.tag FROM kw k1, kw k2 WHERE k1.b = k2.a AND k1.a = {s} AND k2.tag >= 't5'",
+        "SELECT count(*) FROM kw k1, kw k2, kw k3 WHERE k1.b = k2.a AND k2.b = k3.a AND k2.w >= 1000 AND k3.tag = 'dup'",
     ]
     for sql in cases:
         d.execute("PRAGMA disable_gpu_graph")

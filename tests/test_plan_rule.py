@@ -26,7 +26,7 @@ def db():
     d.execute("CREATE TABLE knows_nullable (a BIGINT, b BIGINT)")
     d.execute("CREATE TABLE e32 (a INTEGER NOT NULL, b INTEGER NOT NULL)")
     d.execute("INSERT INTO person VALUES (1), (2), (3)")
-    d.execute("INSERT INTO knows VALUES (1, 2, 0), (2, 3, 0), (3, 1, 0)")
+    d.execute("INSERT INTO knows VALUES (1, 2, 1), (2, 3, 2), (3, 1, 3)")
     # (statistics propagation turns joins over empty tables into EMPTY_RESULT before any rule sees them)
     d.execute("INSERT INTO person_nokey VALUES (1), (2), (3)")
     d.execute("INSERT INTO knows_nullable VALUES (1, 2), (2, 3), (3, NULL)")
@@ -61,6 +61,11 @@ TAKEN = [
     (R.sql_khop(1), "GG_PATH_COUNT", "vertices: person.p_personid"),
     (R.sql_khop(2), "GG_PATH_COUNT", "vertices: person.p_personid"),
     (R.sql_khop_rows(2), "GG_PATH_EXPAND", "2 hops"),
+    # a predicate on an edge instance's payload column: evaluated above the rows fetched by rowid
+    ("SELECT k1.k_weight FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id AND k2.k_weight > 1",
+     "GG_PATH_EDGES", "2 hops"),
+    ("SELECT k2.k_person2id FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id AND k1.k_weight = 2 "
+     "AND k1.k_person1id = 2", "GG_PATH_EDGES", "2 hops"),
     # payload columns of the edge instances: the walks come with their edges' rowids, the columns by rowid
     (chain(2, select="k1.k_weight"), "GG_PATH_EDGES", "with 1 edge column by rowid"),
     (chain(3, select="k1.k_person1id, k1.k_weight, k3.k_weight, k3.k_person2id, k1.k_weight"), "GG_PATH_EDGES",
@@ -91,8 +96,7 @@ LEFT_ALONE = [
     # chain(2), is one equi-join's cardinality and NULL-safe: GG_JOIN_COUNT takes it)
     chain(3, table="knows_nullable", a="a", b="b"),
     chain(2, table="knows_nullable", a="a", b="b", select="k1.a, k2.b"),
-    # non-equality predicates, outer joins, other filters; a predicate on an edge's payload column
-    "SELECT k1.k_weight FROM knows k1, knows k2 WHERE k1.k_person2id = k2.k_person1id AND k2.k_weight > 0",
+    # non-equality predicates, outer joins, other filters
     "SELECT count(*) FROM knows k1, knows k2 WHERE k1.k_person2id < k2.k_person1id",
     "SELECT count(*) FROM knows k1 LEFT JOIN knows k2 ON k1.k_person2id = k2.k_person1id",
     # aggregates other than an ungrouped count(*) keep their aggregate; the join under them is still a walk
@@ -165,7 +169,7 @@ BFS_LEFT_ALONE = [
     friends(inc="f.hopCount+2"),
     friends(agg="max(hopCount)"),
     friends(nxt="k.k_person1id"),                                 # does not advance along the edge
-    friends(step_where="f.friend = k.k_person1id AND f.hopCount < 5 AND k.k_weight > 0"),
+    friends(step_where="f.friend = k.k_person1id AND f.hopCount < 5 AND k.k_weight > 1"),
     friends(step_from="friends f, knows_nullable k", step_where="f.friend = k.a AND f.hopCount < 5", nxt="k.b"),
     friends(step_from="friends f, knows k, person_nokey p",
             step_where="f.friend = k.k_person1id AND k.k_person2id = p.p_personid AND f.hopCount < 5"),
