@@ -2595,13 +2595,15 @@ extern "C" int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uin
 extern "C" int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min,
                                          gg_khop_stats *stats, gg_result **out_result) {
   ApiScope scope(ctx);
-  GG_TRY(check_args(ctx, csr, k_min, 2, stats));
+  gg_khop_stats unused;
+  GG_TRY(check_args(ctx, csr, k_min, 2, stats ? stats : &unused));
   if (!out_result) return GG_ERR_INVALID_ARG;
   *out_result = nullptr;
   if (mid_hi > csr->V) mid_hi = csr->V;
   if (mid_lo > mid_hi) mid_lo = mid_hi;
   GG_HIP(hipSetDevice(ctx->device));
-  GG_TRY(khop_count_mid(ctx, csr, mid_lo, mid_hi, k_min, stats));
+  // (stats == NULL: the rows only — no counting expansion in front of the materialisation; gg_result_rows has the counts)
+  if (stats) GG_TRY(khop_count_mid(ctx, csr, mid_lo, mid_hi, k_min, stats));
   gg_result *res = new gg_result();
   res->ctx = ctx;
   res->k_min = k_min;

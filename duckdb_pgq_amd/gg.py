@@ -497,12 +497,14 @@ class GG:
         self._chk(self.lib.gg_expand_khop_mid(self.ctx, csr.handle, lo, hi, k_min, k_max, C.byref(st)))
         return self._stats_dict(st)
 
-    def expand_khop_mid_result(self, csr: Csr, lo: int, hi: int, k_min: int = 2) -> "KhopResult":
-        """The 2-hop rows (k_min == 1: also the 1-hop rows) with the middle vertex in [lo, hi), materialised in HBM."""
+    def expand_khop_mid_result(self, csr: Csr, lo: int, hi: int, k_min: int = 2, with_stats: bool = True) -> "KhopResult":
+        """The 2-hop rows (k_min == 1: also the 1-hop rows) with the middle vertex in [lo, hi), materialised in HBM.
+        with_stats=False: no counting expansion (count + digest) in front of the rows; KhopResult.rows() still works."""
         st = KhopStats()
         res = C.c_void_p()
-        self._chk(self.lib.gg_expand_khop_mid_result(self.ctx, csr.handle, lo, hi, k_min, C.byref(st), C.byref(res)))
-        return KhopResult(self, res, self._stats_dict(st))
+        self._chk(self.lib.gg_expand_khop_mid_result(self.ctx, csr.handle, lo, hi, k_min,
+                                                     C.byref(st) if with_stats else None, C.byref(res)))
+        return KhopResult(self, res, self._stats_dict(st) if with_stats else None)
 
     def khop_partition_mid(self, csr: Csr, n_parts: int):
         b = (C.c_uint64 * (n_parts + 1))()

@@ -583,9 +583,14 @@ void PhysicalGGPathExpand::MaterialisePart(GGExpandStream &stream) const {
 	lock_guard<mutex> device_guard(part.lock);
 	const auto range = stream.parts[stream.part];
 	if (stream.by_middle) {
-		GGGraph::Check(gg_expand_khop_mid_result(part.ctx, part.csr, range.first, range.second, k_min, &stream.stats,
+		// (no stats: the counting expansion in front of the rows would only produce a digest nobody reads here)
+		GGGraph::Check(gg_expand_khop_mid_result(part.ctx, part.csr, range.first, range.second, k_min, nullptr,
 		                                         &stream.result),
 		               "gg_expand_khop_mid_result");
+		memset(&stream.stats, 0, sizeof(stream.stats));
+		for (int h = k_min; h <= 2; h++) {
+			GGGraph::Check(gg_result_rows(stream.result, h, &stream.stats.rows[h]), "gg_result_rows");
+		}
 	} else if (all_sources) {
 		GGGraph::Check(gg_expand_khop_range(part.ctx, part.csr, range.first, range.second, k_min, k_max, 1,
 		                                    &stream.stats, &stream.result),

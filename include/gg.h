@@ -192,7 +192,8 @@ int gg_expand_khop_mid(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_h
  * (gg_csr_build_shard) the rows are those whose middle vertex is owned AND in the range: N ranks that each materialise
  * [0, V) of their shard — in gg_khop_partition_mid parts if need be — produce the whole result once, no exchange. */
 int gg_expand_khop_mid_result(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mid_hi, int k_min,
-                              gg_khop_stats *stats, gg_result **out_result);
+                              gg_khop_stats *stats /* nullable: no counts + digests in front of the rows */,
+                              gg_result **out_result);
 /* gg_expand_khop(all sources, k_min..2, count) with the result LEFT ON THE DEVICE and no host synchronisation: six
  * uint64 words (rows of 1-hop walks, rows of 2-hop walks, digest 1, digest 2, traversed edges, frontier entries; the
  * digests 32-bit sums in the low half) in a buffer owned by the context (*stats_dev; overwritten by the next such call).

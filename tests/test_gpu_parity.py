@@ -220,6 +220,12 @@ def test_two_hop_rows_by_middle_vertex_ranges_partition_the_materialised_result(
             got = [res.fetch(h, o) for o in range(0, n, 1024)]
             if got:
                 rows[h].append(np.concatenate(got))
+        # the same range without the counting expansion in front (stats == NULL): the same rows
+        bare = gg.expand_khop_mid_result(csr, lo, hi, k_min=1, with_stats=False)
+        assert bare.stats is None
+        for h in (1, 2):
+            assert bare.digest(csr, h) == (res.rows(h), res.stats["digest"][h]) and bare.rows(h) == res.rows(h)
+        bare.close()
         res.close()
     for h in (1, 2):
         allrows = np.concatenate(rows[h])
