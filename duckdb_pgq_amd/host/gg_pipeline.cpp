@@ -203,6 +203,23 @@ string PhysicalGGGraphScan::ParamsToString() const {
 	return description;
 }
 
+//! Scan tasks of a pipeline that ends in a staging sink.  The reference's executor would put every thread it has on
+//! the table scan (pipeline.cpp:91-118: min(source MaxThreads, scheduler threads)); the sink ends in ONE PCIe link,
+//! which eight appenders saturate (scripts/bench_staging_native.cpp: 4-64 threads all within 47-51 GB/s of the
+//! link's 57), and past that the threads only queue for the staging block: the SF100 `count(*)` statement took
+//! 15.5 ms with PRAGMA threads = 8..32, 16.2 with 64, 19.5-23.8 with 256 (this host's default) — and a MEDIAN of 68 ms
+//! there, 256 sleepers being woken per block.  So the scan offers at most GG_INGEST_TASKS tasks (default 8, the same
+//! ceiling the scan-function route's ingest uses, gg_ingest.cpp) whatever PRAGMA threads says.
+static idx_t GGStagingScanMaxThreads(ClientContext &context, const FunctionData *bind_data_p) {
+	static const idx_t task_cap = [] {
+		auto env = std::getenv("GG_INGEST_TASKS");
+		const idx_t n = env ? (idx_t)std::strtoull(env, nullptr, 10) : 8;
+		return MaxValue<idx_t>(1, n);
+	}();
+	auto &bind_data = (const TableScanBindData &)*bind_data_p;
+	return MinValue<idx_t>(bind_data.table->storage->MaxThreads(context), task_cap); // (table_scan.cpp:81-85)
+}
+
 //! PhysicalTableScan of the given columns of a base table (what plan_get.cpp:47-60 builds for a seq_scan)
 unique_ptr<PhysicalOperator> GGBaseTableScan(const GGScanSource &source) {
 	auto &table = *source.table;
@@ -215,8 +232,10 @@ unique_ptr<PhysicalOperator> GGBaseTableScan(const GGScanSource &source) {
 		names.push_back(column.name);
 	}
 	auto bind = make_unique<TableScanBindData>(&table);
-	return make_unique<PhysicalTableScan>(move(types), TableScanFunction::GetFunction(), move(bind), source.columns,
-	                                      move(names), nullptr, table.storage->GetTotalRows());
+	auto function = TableScanFunction::GetFunction();
+	function.max_threads = GGStagingScanMaxThreads;
+	return make_unique<PhysicalTableScan>(move(types), move(function), move(bind), source.columns, move(names), nullptr,
+	                                      table.storage->GetTotalRows());
 }
 
 bool GGPipelineSinksAvailable(ClientContext &context, const GGGraphSpec &spec) {
