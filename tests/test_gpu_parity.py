@@ -1424,3 +1424,16 @@ def test_walk_endpoints_equal_the_union_of_the_hop_sets(gg, orc, k_max):
         assert np.array_equal(ids, o_vid[keep]) and np.array_equal(masks, want[keep])
     csr.close()
     g.close()
+
+
+def test_randomised_differential_run_against_the_oracle():
+    """scripts/fuzz_gg.py for a fixed number of iterations (its own context on cuda:0): random graphs, id shapes, build
+    modes, operations and knobs, everything compared with the oracle.  Longer runs: profiles/r04_fuzz.txt."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_gg.py"), "--seed", "7", "--iterations", "60",
+                          "--max-rows", "400000", "--max-vertices", "100000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fuzz ok: 60 iterations" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
