@@ -212,7 +212,7 @@ struct gg_ctx {
     size_t bytes;  // per column
   };
   std::vector<PlacedSet> placed_sets;
-  int place_probes = 6;                                        // GG_PLACE_PROBES: candidate blocks per set (<= 3: no probing)
+  int place_probes = 12;                                       // GG_PLACE_PROBES: at most this many candidate blocks per set (<= 3: no probing)
   uint64_t placed_built = 0, placed_fast_pairs = 0;            // diagnostics: sets built, fast pairs in the last one
   void dev_free(void *p);
   void keep(void *p);  // the block outlives the API call that allocated it

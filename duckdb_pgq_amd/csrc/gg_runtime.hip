@@ -1,5 +1,6 @@
 // gg_runtime.hip — context, staging (Sink side), caching allocator, event timing, scans.
 // HIP for gfx950; host side of the C-ABI declared in include/gg.h.
+#include <string>
 #include <chrono>
 #include <thread>
 
@@ -110,9 +111,9 @@ int gg_ctx::dev_alloc(void **out, size_t bytes) {
 // two streams in the same class run at 5.8 TB/s, in different classes at 7.15; three streams 5.75 when all share a
 // class, 7.0 with two classes, 7.2 with three — independent of the order of the writes and of offsets inside a class.
 // Nothing in a virtual address says which class it is in, so the pool asks the hardware: for columns of >= 1 GiB it
-// allocates `place_probes` candidate blocks (with spacers between them, so that they reach into different classes),
-// times every pair with a sparse lockstep fill over the blocks' whole extent, keeps the three blocks with the most
-// fast pairs as a SET and returns the rest to the driver.  A set is recycled as a set (its blocks are reserved: the
+// allocates up to `place_probes` candidate blocks one after the other (with spacers between them, so that they reach
+// into different classes), sorts each into a class by sparse lockstep fills against one block per class found so far,
+// stops when it has three classes, keeps one block of each as a SET and returns the rest to the driver.  A set is recycled as a set (its blocks are reserved: the
 // general pool does not hand them out), so the probing is paid once per context and column size.
 // ------------------------------------------------------------------------------------------
 typedef long long place_ll2 __attribute__((ext_vector_type(2)));
@@ -164,16 +165,49 @@ int gg_ctx::dev_alloc_columns(void **cols, size_t col_bytes) {
       return GG_OK;
     }
   }
-  // build a set: candidates (spacers between them are freed at the end), pair probes, best triple
+  // build a set
+  const bool place_trace = getenv("GG_PLACE_TRACE") != nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     (void)hipGetLastError();
     if (e0) (void)hipEventDestroy(e0);
     e0 = e1 = nullptr;
   }
+  // Candidates one at a time, each CLASSIFIED as it arrives: "slow pair" is an equivalence (two blocks of the same
+  // class: 5.2-5.7 TB/s; of different classes: 6.7-7.1 — 6.3 divides them), so a new block is probed against one
+  // representative per class found so far and either joins the class of the first slow partner or founds a class.
+  // Three classes found = three pairwise fast blocks: stop.  (Six candidates with every pair probed, the first form,
+  // found only two classes on some boxes — 0.833 instead of 0.855 of HBM for k_mat_mid2 — because 6 x 16 GiB of
+  // address space need not reach the third.)  Spacers stay allocated until the end so that the candidates advance
+  // through the device; an eighth of the device is left alone.
   std::vector<void *> cand, spacers;
+  std::vector<int> cls;      // class of each candidate
+  std::vector<size_t> reps;  // first candidate of each class
   const size_t spacer = bytes < (size_t(16) << 30) ? (size_t(16) << 30) - bytes : 0;
-  for (int t = 0; t < place_probes && e0; t++) {
+  const uint64_t pairs = stride / 16;
+  const uint64_t chunks = (pairs + PROBE_CHUNK - 1) / PROBE_CHUNK;
+  const uint32_t sample = chunks >= 4096 ? 8 : 1;  // (columns of >= 1 GiB: an eighth of the chunks, over the whole extent)
+  const unsigned grid = (unsigned)((chunks + sample - 1) / sample);
+  bool probed = e0 != nullptr;
+  std::string trace;
+  auto probe = [&](void *x, void *y) -> double {
+    float best = 1e30f;
+    for (int rep = 0; rep < 2; rep++) {  // (the first launch after an allocation pays for its page tables)
+      float ms = 0.f;
+      (void)hipEventRecord(e0, stream);
+      hipLaunchKernelGGL(k_place_probe, dim3(grid), dim3(256), 0, stream, (place_ll2 *)x, (place_ll2 *)y, pairs, sample);
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
+        (void)hipGetLastError();
+        probed = false;
+        return 0.0;
+      }
+      best = ms < best ? ms : best;
+    }
+    const double written = 2.0 * 16.0 * (double)std::min<uint64_t>(pairs, (uint64_t)grid * PROBE_CHUNK);
+    return written / (best * 1e-3);
+  };
+  for (int t = 0; t < place_probes && e0 && reps.size() < 3; t++) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
     if (t >= 3 && free_b < bytes + spacer + total_b / 8) break;  // (leave an eighth of the device alone)
@@ -183,7 +217,18 @@ int gg_ctx::dev_alloc_columns(void **cols, size_t col_bytes) {
       break;
     }
     cand.push_back(p);
-    if (spacer && t + 1 < place_probes && free_b > bytes + 2 * spacer + total_b / 8) {
+    int c = -1;
+    for (size_t r = 0; r < reps.size() && probed && c < 0; r++) {
+      const double rate = probe(p, cand[reps[r]]);
+      if (place_trace) trace += " " + std::to_string(t) + "-" + std::to_string(reps[r]) + " " + std::to_string(rate / 1e12).substr(0, 4);
+      if (probed && rate < 6.3e12) c = cls[reps[r]];
+    }
+    if (c < 0 && probed) {
+      c = (int)reps.size();
+      reps.push_back((size_t)t);
+    }
+    cls.push_back(c < 0 ? 0 : c);
+    if (reps.size() < 3 && spacer && t + 1 < place_probes && free_b > bytes + 2 * spacer + total_b / 8) {
       void *sp = nullptr;
       if (hipMalloc(&sp, spacer) == hipSuccess)
         spacers.push_back(sp);
@@ -192,69 +237,37 @@ int gg_ctx::dev_alloc_columns(void **cols, size_t col_bytes) {
     }
   }
   for (void *sp : spacers) (void)hipFree(sp);
+  if (e0) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
   if (cand.size() < 3) {  // not enough memory for separate blocks (or no events): whatever the pool has
     for (void *p : cand) (void)hipFree(p);
-    if (e0) {
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-    }
     char *base = nullptr;
     GG_TRY(dev_alloc((void **)&base, 3 * stride));
     for (int c = 0; c < 3; c++) cols[c] = base + c * stride;
     return GG_OK;
   }
   const size_t n = cand.size();
-  const uint64_t pairs = stride / 16;
-  const uint64_t chunks = (pairs + PROBE_CHUNK - 1) / PROBE_CHUNK;
-  const uint32_t sample = chunks >= 4096 ? 8 : 1;  // (columns of >= 1 GiB: an eighth of the chunks, over the whole extent)
-  const unsigned grid = (unsigned)((chunks + sample - 1) / sample);
-  std::vector<double> rate(n * n, 0.0);
-  bool probed = true;
-  for (size_t i = 0; i < n && probed; i++)
-    for (size_t j = i + 1; j < n && probed; j++) {
-      float best = 1e30f;
-      for (int rep = 0; rep < 2; rep++) {  // (the first launch after an allocation pays for its page tables)
-        float ms = 0.f;
-        (void)hipEventRecord(e0, stream);
-        hipLaunchKernelGGL(k_place_probe, dim3(grid), dim3(256), 0, stream, (place_ll2 *)cand[i], (place_ll2 *)cand[j], pairs,
-                           sample);
-        (void)hipEventRecord(e1, stream);
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) {
-          (void)hipGetLastError();
-          probed = false;
-          break;
-        }
-        best = ms < best ? ms : best;
-      }
-      const double written = 2.0 * 16.0 * (double)std::min<uint64_t>(pairs, (uint64_t)grid * PROBE_CHUNK);
-      rate[i * n + j] = rate[j * n + i] = probed ? written / (best * 1e-3) : 0.0;
-    }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  // the triple with the most fast pairs (two streams: 5.8 against 7.15 TB/s — 6.5 divides them), then the fastest
-  size_t pick[3] = {0, 1, 2};
-  double pick_score = -1.0;
+  // one block per class; with fewer than three classes the rest from the candidates in order (two classes: two of the
+  // three pairs are fast, 7.0 instead of 7.2 TB/s)
+  size_t pick[3];
+  size_t n_pick = 0;
+  for (size_t r : reps)
+    if (n_pick < 3) pick[n_pick++] = r;
+  for (size_t i = 0; i < n && n_pick < 3; i++) {
+    bool taken = false;
+    for (size_t k = 0; k < n_pick; k++) taken = taken || pick[k] == i;
+    if (!taken) pick[n_pick++] = i;
+  }
   int pick_fast = 0;
-  for (size_t i = 0; i < n; i++)
-    for (size_t j = i + 1; j < n; j++)
-      for (size_t k = j + 1; k < n; k++) {
-        const double r[3] = {rate[i * n + j], rate[i * n + k], rate[j * n + k]};
-        int fast = 0;
-        for (double x : r) fast += x >= 6.5e12;
-        const double score = fast * 1e14 + r[0] + r[1] + r[2];
-        if (score > pick_score) {
-          pick_score = score;
-          pick_fast = fast;
-          pick[0] = i;
-          pick[1] = j;
-          pick[2] = k;
-        }
-      }
-  if (getenv("GG_PLACE_TRACE")) {
-    fprintf(stderr, "[gg] column set of 3 x %.1f GiB: %zu candidates, pair rates (TB/s):", bytes / 1073741824.0, n);
-    for (size_t i = 0; i < n; i++)
-      for (size_t j = i + 1; j < n; j++) fprintf(stderr, " %zu-%zu %.2f", i, j, rate[i * n + j] / 1e12);
-    fprintf(stderr, " -> blocks %zu %zu %zu (%d fast pairs)\n", pick[0], pick[1], pick[2], pick_fast);
+  for (int x = 0; x < 3; x++)
+    for (int y = x + 1; y < 3; y++) pick_fast += probed && cls[pick[x]] != cls[pick[y]];
+  if (place_trace) {
+    fprintf(stderr, "[gg] column set of 3 x %.1f GiB: %zu candidates, classes", bytes / 1073741824.0, n);
+    for (size_t i = 0; i < n; i++) fprintf(stderr, " %d", cls[i]);
+    fprintf(stderr, "; probes (TB/s):%s -> blocks %zu %zu %zu (%d fast pairs)\n", trace.c_str(), pick[0], pick[1], pick[2],
+            pick_fast);
   }
   for (size_t i = 0; i < n; i++)
     if (i != pick[0] && i != pick[1] && i != pick[2]) (void)hipFree(cand[i]);
@@ -475,7 +488,7 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   GG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   if (const char *e = getenv("GG_MAT_GROUPS")) ctx->mat_groups = (uint32_t)strtoul(e, nullptr, 10);
-  if (const char *e = getenv("GG_PLACE_PROBES")) ctx->place_probes = atoi(e) > 0 ? (atoi(e) < 12 ? atoi(e) : 12) : 1;
+  if (const char *e = getenv("GG_PLACE_PROBES")) ctx->place_probes = atoi(e) > 0 ? (atoi(e) < 16 ? atoi(e) : 16) : 1;
   for (int i = 0; i < 2; i++) {
     GG_HIP(hipHostMalloc((void **)&ctx->pin_v[i], gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
     GG_HIP(hipEventCreateWithFlags(&ctx->pin_v_free[i], hipEventDisableTiming));
