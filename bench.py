@@ -889,6 +889,9 @@ def main():
             "rows_per_s": mat["rows_steps"][-1] * args.mat_steps / mat["elapsed"],
             "bytes_written_per_s": mat["rows_steps"][-1] * 24 * args.mat_steps / mat["elapsed"],
             "kernels": m_kernels,
+            "placement": dict(zip(("column_sets_placed_by_probing", "fast_pairs_of_last_set"), gg.placement()),
+                              note="3 fast pairs = each of the three result columns in its own memory rank class "
+                                   "(DESIGN.md 4.2 Placement; GG_PLACE_TRACE=1 prints the probes)"),
             "parity": bool(all(r == rows2 for r in mat["rows_steps"]) and mat["verify_rows"] == rows2 and
                            mat["verify_digest"] == dig2),
             "parity_note": "rows of every timed step, and rows + device-side digest over ALL materialised rows of an untimed "

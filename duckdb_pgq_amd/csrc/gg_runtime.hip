@@ -420,6 +420,13 @@ extern "C" int gg_debug_max_grid_tiles(gg_ctx *ctx, uint64_t max_tiles) {
   return GG_OK;
 }
 
+extern "C" int gg_debug_placement(gg_ctx *ctx, uint64_t *sets_built, uint64_t *fast_pairs_of_last_set) {
+  if (!ctx) return GG_ERR_INVALID_ARG;
+  if (sets_built) *sets_built = ctx->placed_built;
+  if (fast_pairs_of_last_set) *fast_pairs_of_last_set = ctx->placed_fast_pairs;
+  return GG_OK;
+}
+
 extern "C" int gg_debug_reset(gg_ctx *ctx) {
   if (!ctx) return GG_ERR_INVALID_ARG;
   ctx->force_frontier = 0;

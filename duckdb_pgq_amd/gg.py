@@ -19,7 +19,7 @@ SYMBOLS = [
     "gg_ctx_set_edge_rowid", "gg_csr_build", "gg_csr_build_shard", "gg_csr_destroy", "gg_csr_info", "gg_csr_export",
     "gg_expand_khop", "gg_expand_khop_range", "gg_khop_count", "gg_expand_khop_dev", "gg_stream_wait", "gg_join_probe", "gg_khop_partition", "gg_expand_khop_mid", "gg_khop_partition_mid", "gg_expand_khop_mid_result",
     "gg_debug_force_frontier", "gg_debug_force_legacy_build", "gg_debug_scan_fault", "gg_debug_rank_mode",
-    "gg_debug_max_grid_tiles", "gg_debug_reset",
+    "gg_debug_max_grid_tiles", "gg_debug_reset", "gg_debug_placement",
     "gg_result_rows", "gg_result_fetch", "gg_result_destroy", "gg_expand_khop_result", "gg_result_digest",
     "gg_expand_khop_edges", "gg_result_fetch_edges",
     "gg_result_filter_common_neighbour", "gg_staging_clear_edges", "gg_vertices_from_edges",
@@ -104,6 +104,7 @@ def load_library(path: str | None = None):
     lib.gg_debug_scan_fault.argtypes = [P, C.c_uint32, u64]
     lib.gg_debug_max_grid_tiles.argtypes = [P, u64]
     lib.gg_debug_reset.argtypes = [P]
+    lib.gg_debug_placement.argtypes = [P, C.POINTER(u64), C.POINTER(u64)]
     lib.gg_result_rows.argtypes = [P, C.c_int, C.POINTER(u64)]
     lib.gg_result_fetch.argtypes = [P, C.c_int, u64, C.c_uint32, C.POINTER(i64p), C.POINTER(C.c_uint32)]
     lib.gg_expand_khop_result.argtypes = [P, P, i64p, u64, C.c_int, C.c_int, C.POINTER(KhopStats), C.POINTER(P)]
@@ -533,6 +534,12 @@ class GG:
     def debug_reset(self):
         """Every testing knob and the edge-rowid switch back to its default."""
         self._chk(self.lib.gg_debug_reset(self.ctx))
+
+    def placement(self):
+        """(column sets placed by probing, fast pairs of the last set: 3 = each result column in its own memory rank)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.gg_debug_placement(self.ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def khop_partition(self, csr: Csr, n_parts: int):
         b = (C.c_uint64 * (n_parts + 1))()

@@ -349,6 +349,10 @@ int gg_debug_max_grid_tiles(gg_ctx *ctx, uint64_t max_tiles);
 /* Every testing knob above and gg_ctx_set_edge_rowid back to its default (a test suite that shares one context
  * calls this between tests). */
 int gg_debug_reset(gg_ctx *ctx);
+/* Diagnostics of the pool's placement of large result columns (DESIGN.md 4.2 "Placement"): how many column sets this
+ * context has placed by probing, and how many of the three pairs of the LAST set lie in different memory ranks (3 = every
+ * column in its own rank class, the 7.2 TB/s case; 2 = two classes, 7.0; 0 = one class or never probed).  Read-only. */
+int gg_debug_placement(gg_ctx *ctx, uint64_t *sets_built, uint64_t *fast_pairs_of_last_set);
 
 int gg_profile_enable(gg_ctx *ctx, int on);
 /* Time only the kernels named in the comma-separated list (NULL: every kernel).  Two event records per
