@@ -964,9 +964,13 @@ struct SetStatus {
   unsigned long long overflow;  // the table got fuller than `limit` or a probe sequence exceeded its bound
 };
 
+// (the three kernels of the general path stride over their input: 2E endpoints or a table grown past 2^32 slots are
+// more items than one launch has threads — gg_internal.h, GG_LAUNCH)
+constexpr unsigned SET_MAX_BLOCKS = 1u << 22;
+
 __global__ __launch_bounds__(256) void k_set_init(int64_t *__restrict__ set, uint64_t cap) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cap) set[i] = HT_EMPTY;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) set[i] = HT_EMPTY;
 }
 
 __global__ __launch_bounds__(256) void k_set_insert(const int64_t *__restrict__ src, const int64_t *__restrict__ dst,
@@ -976,36 +980,35 @@ __global__ __launch_bounds__(256) void k_set_insert(const int64_t *__restrict__ 
   __shared__ uint32_t s_new;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool inserted = false;
-  if (i < 2 * E + n_extra && *(volatile unsigned long long *)&st->overflow == 0ULL) {
+  const uint64_t total = 2 * E + n_extra, stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t mine = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    if (*(volatile unsigned long long *)&st->overflow != 0ULL) break;
     const int64_t key = i < E ? src[i] : (i < 2 * E ? dst[i - E] : extra[i - 2 * E]);
     if (key == HT_EMPTY) {
       st->has_min = 1ULL;  // benign race: every writer stores the same value
-    } else {
-      uint64_t slot = ht_slot(key, cap);
-      uint32_t probes = 0;
-      while (true) {
-        int64_t k = set[slot];
+      continue;
+    }
+    uint64_t slot = ht_slot(key, cap);
+    uint32_t probes = 0;
+    while (true) {
+      int64_t k = set[slot];
+      if (k == HT_EMPTY) {
+        k = (int64_t)atomicCAS((unsigned long long *)&set[slot], (unsigned long long)HT_EMPTY, (unsigned long long)key);
         if (k == HT_EMPTY) {
-          k = (int64_t)atomicCAS((unsigned long long *)&set[slot], (unsigned long long)HT_EMPTY,
-                                 (unsigned long long)key);
-          if (k == HT_EMPTY) {
-            inserted = true;
-            break;
-          }
-        }
-        if (k == key) break;
-        if (++probes > max_probes) {  // only reachable while the table may still fill up: ask for a bigger one
-          st->overflow = 1ULL;
+          mine++;
           break;
         }
-        slot = ht_next(slot, cap);
       }
+      if (k == key) break;
+      if (++probes > max_probes) {  // only reachable while the table may still fill up: ask for a bigger one
+        st->overflow = 1ULL;
+        break;
+      }
+      slot = ht_next(slot, cap);
     }
   }
-  const uint64_t m = __ballot(inserted);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_new, (uint32_t)__popcll(m));
+  if (mine) atomicAdd(&s_new, mine);
   __syncthreads();
   if (threadIdx.x == 0 && s_new) {
     const unsigned long long before = atomicAdd(&st->count, (unsigned long long)s_new);
@@ -1019,24 +1022,28 @@ __global__ __launch_bounds__(256) void k_set_compact(const int64_t *__restrict__
                                                      uint32_t *__restrict__ lo, uint32_t *__restrict__ hi) {
   __shared__ uint32_t s_cnt[4];
   __shared__ unsigned long long s_base;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t k = i < cap ? set[i] : HT_EMPTY;
-  const bool live = k != HT_EMPTY;
-  const uint64_t m = __ballot(live);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ULL;
-  }
-  __syncthreads();
-  if (live) {
-    uint32_t before = 0;
-    for (int w = 0; w < wave; w++) before += s_cnt[w];
-    const uint64_t pos = s_base + before + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
-    lo[pos] = (uint32_t)(uint64_t)k;
-    hi[pos] = (uint32_t)((uint64_t)k >> 32) ^ 0x80000000u;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < cap; base += stride) {  // (block-uniform trip count)
+    const uint64_t i = base + threadIdx.x;
+    const int64_t k = i < cap ? set[i] : HT_EMPTY;
+    const bool live = k != HT_EMPTY;
+    const uint64_t m = __ballot(live);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ULL;
+    }
+    __syncthreads();
+    if (live) {
+      uint32_t before = 0;
+      for (int w = 0; w < wave; w++) before += s_cnt[w];
+      const uint64_t pos = s_base + before + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+      lo[pos] = (uint32_t)(uint64_t)k;
+      hi[pos] = (uint32_t)((uint64_t)k >> 32) ^ 0x80000000u;
+    }
+    __syncthreads();  // (s_cnt and s_base are rewritten by the next trip)
   }
 }
 
@@ -1085,8 +1092,10 @@ static int vertices_from_edges_general(gg_ctx *ctx, int keep_staged_vertices, ui
     const bool cannot_fill = cap > 2 * E + n_old + 1;
     GG_TRY(ctx->dev_alloc((void **)&set, cap * sizeof(int64_t)));
     GG_HIP(hipMemsetAsync(st, 0, sizeof(SetStatus), s));
-    GG_LAUNCH(ctx, "set_init", k_set_init, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, set, cap);
-    GG_LAUNCH(ctx, "set_insert", k_set_insert, dim3((unsigned)((2 * E + n_old + 255) / 256)), dim3(256), 0,
+    GG_LAUNCH(ctx, "set_init", k_set_init, dim3((unsigned)std::min<uint64_t>((cap + 255) / 256, SET_MAX_BLOCKS)), dim3(256), 0,
+              set, cap);
+    GG_LAUNCH(ctx, "set_insert", k_set_insert, dim3((unsigned)std::min<uint64_t>((2 * E + n_old + 255) / 256, SET_MAX_BLOCKS)),
+              dim3(256), 0,
               ctx->c_src.dev, ctx->c_dst.dev, E, (const int64_t *)ctx->c_vid.dev, n_old, set, cap,
               cannot_fill ? ~0ULL : cap / 2, cannot_fill ? 0xFFFFFFFFu : 4096u, st);
     GG_HIP(hipMemcpyAsync(ctx->pin_scratch, st, sizeof(SetStatus), hipMemcpyDeviceToHost, s));
@@ -1110,8 +1119,8 @@ static int vertices_from_edges_general(gg_ctx *ctx, int keep_staged_vertices, ui
     GG_TRY(ctx->dev_alloc((void **)&cursor, sizeof(unsigned long long)));
     GG_TRY(ctx->dev_alloc((void **)&tot, sizeof(unsigned long long)));
     GG_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s));
-    GG_LAUNCH(ctx, "set_compact", k_set_compact, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, set, cap, cursor,
-              lo[0], hi[0]);
+    GG_LAUNCH(ctx, "set_compact", k_set_compact, dim3((unsigned)std::min<uint64_t>((cap + 255) / 256, SET_MAX_BLOCKS)),
+              dim3(256), 0, set, cap, cursor, lo[0], hi[0]);
     // three stable LSD rounds over (22, 22, 20)-bit chunks, the two id halves riding along as payloads
     int cur = 0;
     for (int round = 0; round < 3; round++) {

@@ -276,8 +276,18 @@ struct ApiScope {
 };
 
 // RAII-free helper: launch wrapper that records events when profiling is on.
+// (A launch of 2^32 threads or more is not refused by the runtime: the global size WRAPS and the kernel silently covers
+// a fraction of its input — seen with one thread per endpoint of 2.4 G edge rows.  Kernels over that many items stride;
+// the macro refuses whatever would still get there.)
 #define GG_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                         \
   do {                                                                                \
+    {                                                                                 \
+      const dim3 g_ = (grid), b_ = (block);                                           \
+      if ((unsigned long long)g_.x * g_.y * g_.z * b_.x * b_.y * b_.z >= (1ULL << 32)) { \
+        set_error(name ": a launch of 2^32 threads or more");                         \
+        return GG_ERR_TOO_LARGE;                                                      \
+      }                                                                               \
+    }                                                                                 \
     int prof_rec_ = (ctx)->profiling ? (ctx)->prof_begin(name) : -1;                  \
     hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);       \
     if (prof_rec_ >= 0) (ctx)->prof_end(prof_rec_);                                   \

@@ -45,6 +45,9 @@ for name, legacy in (("bucketed", False), ("multipass", True)):
 g.force_legacy_build(False)
 a, b = res["bucketed"], res["multipass"]
 out["edges_kept"] = int(a[4])
+for name in ("bucketed", "multipass"):
+    r = res[name]
+    out[name] = {"E": int(r[4]), "offsets_last": int(r[1][-1]), "rows": [int(x) for x in r[0]["rows"][:3]]}
 out["offsets_equal"] = bool(np.array_equal(a[1], b[1]))
 out["neighbours_equal"] = bool(np.array_equal(a[2], b[2]))
 out["vertex_ids_equal"] = bool(np.array_equal(a[3], b[3]))
