@@ -71,7 +71,9 @@ extern "C" {
 #define GG_ERR_HIP (-2)
 #define GG_ERR_OOM (-3)
 #define GG_ERR_DUPLICATE_VERTEX (-4)
-#define GG_ERR_TOO_LARGE (-5)
+#define GG_ERR_TOO_LARGE (-5) /* > 2^32-2 edge rows or distinct ids; a frontier LEVEL of >= 2^32 walks in an expansion that must
+                               materialise it (k >= 4, or k = 3 from a source list with the frontier forms forced); one result
+                               part of that many rows from the row-at-a-time kernels — refused, never wrapped */
 #define GG_ERR_STATE (-6)
 #define GG_ERR_NO_DEVICE (-7)
 
