@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--iterations", type=int, default=0)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--pinned", action="store_true", help="the graphs of knows / knows_n pinned on the device, the connection opted in")
     ap.add_argument("--cpu-only", action="store_true", help="the reference's plan only (checks the generator's SQL where there is no GPU)")
     a = ap.parse_args()
     if not R.rules_route():
@@ -175,6 +176,12 @@ def main():
             if d:
                 d.close()
             d, vid, src, dst = make_db(a.seed * 1000 + i, a.threads)
+            if a.pinned and not a.cpu_only:
+                d.execute("PRAGMA gg_use_pinned_graphs")
+                for edge in ("knows", "knows_n"):
+                    d.execute(f"SELECT * FROM gg_graph_pin('', '', '{edge}', 'k_person1id', 'k_person2id')")
+                    for vertex in ("person", "person_pk"):
+                        d.execute(f"SELECT * FROM gg_graph_pin('{vertex}', 'p_personid', '{edge}', 'k_person1id', 'k_person2id')")
         kind = rnd.choice(["chain"] * 6 + ["friends", "shortest", "keyjoin"])
         sql = {"chain": chain_statement, "friends": friends_statement, "shortest": shortest_statement,
                "keyjoin": key_join_statement}[kind](rnd, vid)

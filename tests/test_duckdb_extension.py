@@ -1010,3 +1010,16 @@ def test_repeated_statements_and_pin_cycles_on_both_ingest_routes(db, monkeypatc
         monkeypatch.delenv("GG_NO_PIPELINE_SINKS", raising=False)
         d.execute("PRAGMA gg_ignore_pinned_graphs")
         d.execute("PRAGMA disable_gpu_graph")
+
+
+@pytest.mark.skipif(not bool(R.rules_route()), reason="plan hook shim not built")
+def test_randomised_statements_with_the_rules_off_and_on():
+    """scripts/fuzz_sql.py for a fixed number of statements (its own database): random join chains, friends unions,
+    shortest-path CTEs and key joins, each with the planner rules off and on — the same rows.  Longer runs:
+    profiles/r04_fuzz.txt."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_sql.py"), "--seed", "11", "--iterations", "300"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fuzz_sql ok: 300 statements" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
