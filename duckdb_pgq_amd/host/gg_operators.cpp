@@ -31,6 +31,17 @@ struct FetchClaim {
 //===--------------------------------------------------------------------===//
 // GGGraph
 //===--------------------------------------------------------------------===//
+shared_ptr<const vector<int64_t>> GGGraph::VertexIds() {
+	if (!vertex_ids) {
+		uint64_t V = 0;
+		Check(gg_csr_info(csr, &V, nullptr, nullptr), "gg_csr_info");
+		auto ids = make_shared<vector<int64_t>>(V);
+		Check(gg_csr_export(csr, nullptr, nullptr, nullptr, ids->data()), "gg_csr_export");
+		vertex_ids = move(ids);
+	}
+	return vertex_ids;
+}
+
 void GGGraph::Check(int rc, const char *what) {
 	if (rc != GG_OK) {
 		throw IOException(string(what) + ": " + gg_last_error());
@@ -441,6 +452,7 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
 		// the same vertex table, and keeps the CSR rows of the vertices it owns
 		const int parts = graph->Parts();
 		graph->ForEachPart([&](int p, GGGraph &part) {
+			part.vertex_ids.reset();
 			if (part.csr) {
 				gg_csr_destroy(part.csr);
 				part.csr = nullptr;
@@ -454,6 +466,9 @@ SinkFinalizeType PhysicalGGEdgeSink::Finalize(Pipeline &pipeline, Event &event, 
 		return SinkFinalizeType::READY;
 	}
 	gg_csr *&target = as_filter ? graph->filter_csr : graph->csr;
+	if (!as_filter) {
+		graph->vertex_ids.reset(); // (of the CSR that goes)
+	}
 	if (target) {
 		gg_csr_destroy(target);
 		target = nullptr;
@@ -1343,7 +1358,7 @@ public:
 		return max_threads;
 	}
 	vector<int64_t> uniq;            // the sources, deduplicated, in 64-lane batches
-	vector<int64_t> vid;             // vertex ids by dense index (the rows come back packed, see RunBatch)
+	shared_ptr<const vector<int64_t>> vid; // vertex ids by dense index (the rows come back packed, see RunBatch)
 	idx_t batch_base = 0;            // first source of the batch whose rows are in `result`
 	gg_result *result = nullptr;     // packed (lane, distance, dense vertex) rows of the current batch, in HBM
 	idx_t rows = 0;                  // ... and how many
@@ -1411,10 +1426,7 @@ unique_ptr<GlobalSourceState> PhysicalGGShortestPath::GetGlobalSourceState(Clien
 		}
 	}
 	if (!state->uniq.empty()) {
-		uint64_t V = 0;
-		GGGraph::Check(gg_csr_info(graph->csr, &V, nullptr, nullptr), "gg_csr_info");
-		state->vid.resize(V);
-		GGGraph::Check(gg_csr_export(graph->csr, nullptr, nullptr, nullptr, state->vid.data()), "gg_csr_export");
+		state->vid = graph->VertexIds();
 		RunBatch(*state);
 	}
 	// the first batch's size is the only estimate there is of how much the threads will have to drain
@@ -1488,7 +1500,7 @@ void PhysicalGGShortestPath::GetData(ExecutionContext &context, DataChunk &chunk
 	auto frnd = FlatVector::GetData<int64_t>(chunk.data[1]);
 	auto hops = FlatVector::GetData<int32_t>(chunk.data[2]);
 	const int64_t *lane_source = gstate.uniq.data() + slab.table;
-	const int64_t *vertex_id = gstate.vid.data();
+	const int64_t *vertex_id = gstate.vid->data();
 	const int64_t *packed = slab.column[0] + slab.pos;
 	for (idx_t i = 0; i < n; i++) { // lane << 58 | distance << 32 | dense vertex index
 		const uint64_t w = (uint64_t)packed[i];

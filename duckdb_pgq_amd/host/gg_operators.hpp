@@ -60,6 +60,11 @@ struct GGGraph {
 	gg_csr *filter_csr = nullptr; // optional second edge table over the same vertex set (same-neighbour filter)
 	std::mutex lock; // gg calls other than the appends are externally serialised (gg.h)
 	vector<unique_ptr<GGGraph>> peers;
+	//! Host copy of the path CSR's vertex table (dense index -> id), exported once per build and shared by the
+	//! statements that unpack dense indices on the host (a pinned graph serves many: 3.6 MB through pageable memory
+	//! per SF100 statement otherwise).  Callers hold `lock`; PhysicalGGEdgeSink::Finalize drops it with the CSR.
+	shared_ptr<const vector<int64_t>> VertexIds();
+	shared_ptr<const vector<int64_t>> vertex_ids;
 };
 
 //! Copy one integer key column of a chunk into `out` (BIGINT or INTEGER physical type, any vector
