@@ -200,6 +200,22 @@ struct gg_ctx {
   uint32_t mat_groups = 1;  // k_mat_mid2: places of the result columns the resident workgroups write at (GG_MAT_GROUPS)
   unsigned long long *stats_dev = nullptr;  // gg_expand_khop_dev: the six result words of the last such call (8 x u64)
   hipEvent_t xstream_event = nullptr;       // gg_stream_wait
+  // Result fetches (gg_result_fetch[_edges]) go over FETCH_LANES streams of their own, round robin: the pipeline's
+  // threads drain a result in copies of ~1 MB per column, and one stream moves copies of that size at 33-37 GB/s
+  // (a gap between copies; profiles/r04_ubench_h2d_numa.txt: 1 MiB pieces 36.6 GB/s on one stream, 51-55 on two or
+  // four), so the lanes overlap one copy's tail with the next one's head.  A lane is ordered behind the library's
+  // stream by an event per call (the result may still be in flight there) and serialises its own callers.
+  static constexpr int FETCH_LANES = 4;
+  struct FetchLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    std::mutex mu;
+  };
+  FetchLane fetch_lane[FETCH_LANES];
+  std::atomic<uint32_t> fetch_next{0};
+  uint32_t fetch_lanes_used = FETCH_LANES;  // GG_FETCH_LANES (1..FETCH_LANES)
+  // copy n_cols column slices to the host over one lane and wait for them (dst[c] <- src[c], bytes each)
+  int fetch_columns(void *const *dst, const void *const *src, int n_cols, size_t bytes);
 
   uint64_t next_serial = 1;
   int dev_alloc(void **out, size_t bytes);

@@ -2529,15 +2529,17 @@ extern "C" int gg_result_fetch_edges(const gg_result *res, int hops, uint64_t of
   }
   uint64_t take = total - offset;
   if (take > max_rows) take = max_rows;
+  void *dst[GG_MAX_HOPS + 1];
+  const void *src[GG_MAX_HOPS + 1];
   for (int c = 0; c < hops; c++) {
     if (!ecols[c] || !res->ecols[hops][c]) {
       set_error("gg_result_fetch_edges: the result carries no edge columns (gg_expand_khop_edges makes them)");
       return GG_ERR_INVALID_ARG;
     }
-    GG_HIP(hipMemcpyAsync(ecols[c], res->ecols[hops][c] + offset, take * sizeof(int64_t), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    dst[c] = ecols[c];
+    src[c] = res->ecols[hops][c] + offset;
   }
-  GG_HIP(hipStreamSynchronize(ctx->stream));
+  GG_TRY(ctx->fetch_columns(dst, src, hops, take * sizeof(int64_t)));
   *n_out = (uint32_t)take;
   return GG_OK;
 }
@@ -2698,12 +2700,14 @@ extern "C" int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, 
   }
   uint64_t take = total - offset;
   if (take > max_rows) take = max_rows;
+  void *dst[GG_MAX_HOPS + 1];
+  const void *src[GG_MAX_HOPS + 1];
   for (int c = 0; c <= hops; c++) {
     if (!cols[c]) return GG_ERR_INVALID_ARG;
-    GG_HIP(hipMemcpyAsync(cols[c], res->cols[hops][c] + offset, take * sizeof(int64_t), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    dst[c] = cols[c];
+    src[c] = res->cols[hops][c] + offset;
   }
-  GG_HIP(hipStreamSynchronize(ctx->stream));
+  GG_TRY(ctx->fetch_columns(dst, src, hops + 1, take * sizeof(int64_t)));
   *n_out = (uint32_t)take;
   return GG_OK;
 }

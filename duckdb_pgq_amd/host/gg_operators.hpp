@@ -83,7 +83,10 @@ idx_t GGKeyColumns(DataChunk &input, const vector<idx_t> &cols, vector<vector<in
 //! pipeline threads drain one result concurrently, each through its own slab.
 class GGResultSlab : public LocalSourceState {
 public:
-	static constexpr idx_t SLAB_ROWS = 1u << 17;
+	//! 2 MB per column and fetch: a result drains at 44 GB/s in copies of that size over the library's fetch lanes
+	//! (36 at 1 MB, 48 at 4 MB, 51 at 8 MB — scripts/bench_fetch.py, profiles/r04_bench_fetch.txt; 22-29 GB/s before
+	//! the lanes) against twice / four times the page-locked memory per thread
+	static constexpr idx_t SLAB_ROWS = 1u << 18;
 
 	explicit GGResultSlab(shared_ptr<GGGraph> graph);
 	~GGResultSlab() override;
