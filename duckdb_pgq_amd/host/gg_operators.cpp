@@ -1002,12 +1002,16 @@ OperatorResultType PhysicalGGKeyJoin::Execute(ExecutionContext &context, DataChu
 	state.offset += n;
 	SelectionVector sel(STANDARD_VECTOR_SIZE);
 	auto ids = FlatVector::GetData<row_t>(rowids);
+	const idx_t build_rows = build_table->storage->GetTotalRows();
 	for (uint32_t r = 0; r < n; r++) {
 		if ((uint64_t)state.positions[r] >= state.valid_rows.size()) {
 			// (never a wrong row quietly: whatever came back is not a match of this chunk)
 			throw InternalException("GG_KEY_JOIN: a probe position outside the chunk came back from the device index");
 		}
 		sel.set_index(r, state.valid_rows[(idx_t)state.positions[r]]);
+		if (ids[r] >= 0 && ids[r] < MAX_ROW_ID && (idx_t)ids[r] >= build_rows) {
+			throw InternalException("GG_KEY_JOIN: a rowid past the end of the build table came back from the device index");
+		}
 		if (ids[r] < 0 || ids[r] >= MAX_ROW_ID) {
 			throw NotImplementedException("GG_KEY_JOIN: build rows that this transaction has not committed yet cannot be "
 			                              "fetched by rowid (PRAGMA disable_gpu_joins for this statement)");

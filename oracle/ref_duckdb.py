@@ -66,6 +66,8 @@ class RefDuckDB:
         self.L.duckdb_column_data.argtypes = [C.POINTER(_Result), C.c_uint64]
         self.L.duckdb_column_type.restype = C.c_int
         self.L.duckdb_column_type.argtypes = [C.POINTER(_Result), C.c_uint64]
+        self.L.duckdb_nullmask_data.restype = C.c_void_p
+        self.L.duckdb_nullmask_data.argtypes = [C.POINTER(_Result), C.c_uint64]
         self.G.ggref_append_int64_columns.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.POINTER(C.c_int64)),
                                                       C.c_uint64, C.c_char_p, C.c_int]
         self.db, self.con = C.c_void_p(), C.c_void_p()
@@ -110,6 +112,13 @@ class RefDuckDB:
             else:
                 for i in range(r.row_count):
                     out[i, c] = self.L.duckdb_value_int64(C.byref(r), c, i)
+            # a NULL reads as 0: the data slot under a NULL is whatever the producing operator left there (the two
+            # plans of a differential test need not leave the same bytes), duckdb.h:365-372
+            mask = self.L.duckdb_nullmask_data(C.byref(r), C.c_uint64(c))
+            if r.row_count and mask and typ in (INT64, INT32):
+                nulls = np.ctypeslib.as_array(C.cast(mask, C.POINTER(C.c_bool)), shape=(r.row_count,))
+                if nulls.any():
+                    out[nulls, c] = 0
         self.L.duckdb_destroy_result(C.byref(r))
         return out
 
