@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=0)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--pinned", action="store_true", help="the graphs of knows / knows_n pinned on the device, the connection opted in")
+    ap.add_argument("--writes", action="store_true", help="INSERT / DELETE / UPDATE on the edge tables every 40 statements")
     ap.add_argument("--cpu-only", action="store_true", help="the reference's plan only (checks the generator's SQL where there is no GPU)")
     a = ap.parse_args()
     if not R.rules_route():
@@ -168,7 +169,7 @@ def main():
         return
     rnd = random.Random(a.seed)
     t0 = last = time.time()
-    i = taken = 0
+    i = taken = writes = 0
     d = None
     kinds = {}
     while (a.iterations and i < a.iterations) or (not a.iterations and time.time() - t0 < a.seconds):
@@ -182,6 +183,20 @@ def main():
                     d.execute(f"SELECT * FROM gg_graph_pin('', '', '{edge}', 'k_person1id', 'k_person2id')")
                     for vertex in ("person", "person_pk"):
                         d.execute(f"SELECT * FROM gg_graph_pin('{vertex}', 'p_personid', '{edge}', 'k_person1id', 'k_person2id')")
+        if a.writes and i % 40 == 39:  # the tables change under the statements (and under the pins, which must go)
+            w = rnd.choice(["insert", "insert", "delete", "update", "repin"])
+            table = rnd.choice(["knows", "knows_n"])
+            if w == "insert":
+                vals = ", ".join(f"({pick_ids(rnd, vid, 1)[0]}, {pick_ids(rnd, vid, 1)[0]}, {rnd.randint(0, 22)}"
+                                 + (", 'tx')" if table == "knows_n" else ")") for _ in range(rnd.randint(1, 6)))
+                d.execute(f"INSERT INTO {table} VALUES {vals}")
+            elif w == "delete":
+                d.execute(f"DELETE FROM {table} WHERE w = {rnd.randint(0, 22)} AND k_person1id % 3 = {rnd.randint(0, 2)}")
+            elif w == "update":
+                d.execute(f"UPDATE {table} SET w = (w + 1) % 23 WHERE w = {rnd.randint(0, 22)}")
+            elif a.pinned:
+                d.execute(f"SELECT * FROM gg_graph_pin('', '', '{table}', 'k_person1id', 'k_person2id')")
+            writes += 1
         kind = rnd.choice(["chain"] * 6 + ["friends", "shortest", "keyjoin"])
         sql = {"chain": chain_statement, "friends": friends_statement, "shortest": shortest_statement,
                "keyjoin": key_join_statement}[kind](rnd, vid)
@@ -213,7 +228,7 @@ def main():
         if time.time() - last > 20:
             last = time.time()
             print(f"[{last - t0:5.0f} s] {i} statements, {taken} on GG operators; by kind (all, taken): {kinds}", flush=True)
-    print(f"fuzz_sql ok: {i} statements in {time.time() - t0:.0f} s, {taken} on GG operators (seed {a.seed}); by kind: {kinds}", flush=True)
+    print(f"fuzz_sql ok: {i} statements in {time.time() - t0:.0f} s, {taken} on GG operators (seed {a.seed}), {writes} writes in between; by kind: {kinds}", flush=True)
     if d:
         d.close()
 
