@@ -197,7 +197,6 @@ struct gg_ctx {
   uint32_t scan_spin_limit = 1u << 24;    // polls per predecessor before a scan tile gives up
   uint64_t scan_mute_tile = ~0ull;        // gg_debug_scan_fault: this scan tile never publishes (tests)
 
-  uint32_t mat_groups = 1;  // k_mat_mid2: places of the result columns the resident workgroups write at (GG_MAT_GROUPS)
   unsigned long long *stats_dev = nullptr;  // gg_expand_khop_dev: the six result words of the last such call (8 x u64)
   hipEvent_t xstream_event = nullptr;       // gg_stream_wait
   // Result fetches (gg_result_fetch[_edges]) go over FETCH_LANES streams of their own, round robin: the pipeline's

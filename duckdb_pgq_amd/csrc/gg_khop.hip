@@ -1614,18 +1614,15 @@ __global__ __launch_bounds__(256) void k_mat_mid2(const uint32_t *__restrict__ o
                                                   const int64_t *__restrict__ vid, const uint64_t *__restrict__ foff,
                                                   const uint32_t *__restrict__ tile_entry, uint64_t e0, uint64_t n,
                                                   uint64_t M2, int64_t *__restrict__ c0, int64_t *__restrict__ c1,
-                                                  int64_t *__restrict__ c2, uint32_t n_tiles, uint32_t groups) {
+                                                  int64_t *__restrict__ c2, uint32_t n_tiles) {
   __shared__ int64_t s_uid[256 + 1];
   __shared__ int64_t s_oid[MAT_CAP + 1];
   __shared__ uint64_t s_base[256];
   __shared__ uint32_t s_x[256], s_run[257], s_wcnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // groups > 1: workgroup b takes tile (b % groups) * (grid / groups) + b / groups (the grid is padded to a multiple of
-  // `groups`): the workgroups resident at any moment write at `groups` places spread over the whole of every column
-  // instead of moving through the columns as one narrow window of three cursors
-  uint32_t tile = blockIdx.x;
-  if (groups > 1) tile = (blockIdx.x % groups) * (gridDim.x / groups) + blockIdx.x / groups;
-  if (tile >= n_tiles) return;
+  // (tiles in launch order: a scattered order — the resident workgroups writing at 16 or 256 places spread over every
+  // column instead of one moving window — changed nothing; what matters is which memory ranks the columns lie in, §4.2)
+  const uint32_t tile = blockIdx.x;
   const uint64_t t_lo = mat_tile_start(tile, n_tiles, M2), t_hi = mat_tile_start(tile + 1ull, n_tiles, M2);
   const uint64_t e_lo = tile_entry[tile];
   uint64_t e_hi = (uint64_t)tile_entry[tile + 1] + 1;  // (that entry holds the next tile's first row, and maybe ours)
@@ -1905,11 +1902,9 @@ int khop_materialise_mid2(gg_ctx *ctx, gg_csr *csr, uint64_t mid_lo, uint64_t mi
     GG_TRY(ctx->dev_alloc((void **)&tile_entry, (n_tiles + 1) * sizeof(uint32_t)));
     GG_LAUNCH(ctx, "mat_tile_entries", k_mat_tile_entries, dim3((unsigned)((n_tiles + 256) / 256)), dim3(256), 0,
               (const uint64_t *)foff, n, n_tiles, M2, tile_entry);
-    const uint32_t groups = ctx->mat_groups > 1 && n_tiles >= 4ull * ctx->mat_groups ? ctx->mat_groups : 1;
-    const uint64_t grid = groups > 1 ? (n_tiles + groups - 1) / groups * groups : n_tiles;
-    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)grid), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
+    GG_LAUNCH(ctx, "mat_mid2", k_mat_mid2, dim3((unsigned)n_tiles), dim3(256), 0, csr->off, csr->nbr, csr->rrow,
               csr->rnbr, csr->vid, (const uint64_t *)foff, (const uint32_t *)tile_entry, e0, n, M2, res->cols[2][0],
-              res->cols[2][1], res->cols[2][2], (uint32_t)n_tiles, groups);
+              res->cols[2][1], res->cols[2][2], (uint32_t)n_tiles);
     ctx->dev_free(tile_entry);
   }
   if (k_min <= 1) {

@@ -496,7 +496,6 @@ extern "C" int gg_ctx_create(int device, gg_ctx **out) {
   GG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   if (const char *e = getenv("GG_FETCH_LANES"))
     ctx->fetch_lanes_used = atoi(e) >= 1 && atoi(e) <= gg_ctx::FETCH_LANES ? (uint32_t)atoi(e) : gg_ctx::FETCH_LANES;
-  if (const char *e = getenv("GG_MAT_GROUPS")) ctx->mat_groups = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("GG_PLACE_PROBES")) ctx->place_probes = atoi(e) > 0 ? (atoi(e) < 16 ? atoi(e) : 16) : 1;
   for (int i = 0; i < 2; i++) {
     GG_HIP(hipHostMalloc((void **)&ctx->pin_v[i], gg_ctx::STAGE_ROWS * sizeof(int64_t), hipHostMallocDefault));
