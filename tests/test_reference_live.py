@@ -84,3 +84,17 @@ def test_hoisted_build_variant_of_the_reference_returns_the_same_relation():
     assert out["stock"]["variant"] == "stock" and out["hoisted"]["variant"] == "hoisted"
     assert out["stock"]["rows"] == out["hoisted"]["rows"] > 0
     assert out["stock"]["checksum"] == out["hoisted"]["checksum"]
+
+
+@pytest.mark.skipif(not os.path.exists(R.EXTENSION), reason="extension not built")
+def test_statement_generator_of_the_sql_fuzzer_is_valid_sql_for_the_reference():
+    """scripts/fuzz_sql.py --cpu-only: every statement shape the differential fuzzer draws (join chains, friends unions,
+    shortest-path CTEs, key joins, with writes in between) parses, binds and runs on the reference's own plans — so a
+    failure of the GPU run is never the generator's."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_sql.py"), "--cpu-only", "--writes", "--seed", "9",
+                          "--iterations", "150"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fuzz_sql ok: 150 statements" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
