@@ -559,7 +559,7 @@ extern "C" void gg_ctx_destroy(gg_ctx *ctx) {
 }
 
 int gg_ctx::fetch_columns(void *const *dst, const void *const *src, int n_cols, size_t bytes) {
-  // The lanes are for destinations in page-locked memory of this context (gg_host_alloc: the operators' slabs), where
+  // The lanes are for destinations in page-locked memory (gg_host_alloc of this or another context: the operators' slabs), where
   // the rate matters.  A copy into pageable memory is staged by the runtime and gains nothing from them (GG_KEY_JOIN's
   // <= 1024 pairs per chunk, the ctypes harness): those keep the library's stream.
   static const bool lanes_for_all = getenv("GG_FETCH_LANES_PAGEABLE") != nullptr;  // (diagnostic: the behaviour described above)
@@ -571,6 +571,20 @@ int gg_ctx::fetch_columns(void *const *dst, const void *const *src, int n_cols, 
       for (auto &h : host_blocks)
         found = found || ((const char *)dst[c] >= (const char *)h.ptr && (const char *)dst[c] + bytes <= (const char *)h.ptr + h.bytes);
       pinned = found;
+    }
+  }
+  if (!pinned && !lanes_for_all) {
+    // not this context's: the slab may be another context's (a sharded graph's streams fetch every part's rows into
+    // slabs of part 0) — ask the runtime whether the memory is page-locked
+    pinned = true;
+    for (int c = 0; c < n_cols && pinned; c++) {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, dst[c]) != hipSuccess) {
+        (void)hipGetLastError();  // (an ordinary host pointer is an error to this call)
+        pinned = false;
+      } else {
+        pinned = attr.type == hipMemoryTypeHost;
+      }
     }
   }
   if (!pinned) {

@@ -212,7 +212,7 @@ int gg_khop_partition_mid(gg_ctx *ctx, gg_csr *csr, int n_parts, uint64_t *bound
 
 int gg_result_rows(const gg_result *res, int hops, uint64_t *n_rows);
 /* Copy rows [offset, offset+max_rows) of the h-hop table into cols[0..h] (host arrays of >= max_rows).  Destinations
- * inside memory from gg_host_alloc of the same context are filled over the context's fetch lanes (concurrent callers
+ * in page-locked memory (gg_host_alloc) are filled over the context's fetch lanes (concurrent callers
  * overlap their copies: ~44 GB/s in 2 MB pieces); any other destination over the library's stream. */
 int gg_result_fetch(const gg_result *res, int hops, uint64_t offset, uint32_t max_rows, int64_t *const *cols,
                     uint32_t *n_out);
