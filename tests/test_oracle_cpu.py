@@ -143,3 +143,41 @@ def test_threaded_csr_build_of_the_oracle_is_the_stable_counting_sort(orc):
     assert np.array_equal(off, np.concatenate([[0], np.cumsum(np.bincount(u, minlength=vid.size))]))
     assert g.dropped == int((~ok).sum())
     g.close()
+
+
+def test_khop_join_equals_csr_on_the_fuzzers_graph_shapes(orc):
+    """The two restatements inside the oracle — the reference's join hash table run as k chained joins, and the CSR
+    formulation every GPU result is compared with — on the graph shapes scripts/fuzz_gg.py draws (ids anywhere in int64,
+    negative, clustered, dense; power-law, hub, chain and sorted edge tables; duplicate rows): same rows, counts and
+    digests."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_gg.py")
+    spec = importlib.util.spec_from_file_location("fuzz_gg_generator", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(fuzz)  # (imports the package: the library itself is only loaded by GG(), not here)
+    except Exception as e:  # pragma: no cover
+        pytest.skip(f"fuzz_gg not importable here: {e}")
+    seen = set()
+    for i in range(40):
+        rng = np.random.default_rng(1000 + i)
+        g = fuzz.draw_graph(rng, max_rows=600, max_vertices=120)
+        vid, src, dst = g["vid"], g["src"], g["dst"]
+        seen.add((g["ids"], g["model"]))
+        rc, c = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        deg = max(1.0, src.size / max(1, vid.size))
+        kmax = 3 if src.size * deg * deg <= 300_000 else 2
+        j = orc.khop_join(vid, src, dst, 1, kmax)
+        rows = c.khop_rows(1, kmax)
+        st = c.khop(1, kmax)
+        for h in range(1, kmax + 1):
+            jr = vid[j[h]] if j[h].size else j[h]
+            assert sort_rows(jr).tolist() == sort_rows(rows[h]).tolist(), (i, g["ids"], g["model"], h)
+            assert st["rows"][h] == j[h].shape[0] and st["digest"][h] == orc.digest_rows(j[h])
+        c.close()
+    assert len(seen) >= 12  # (the draw reached most (id shape, degree model) combinations)
