@@ -181,3 +181,33 @@ def test_khop_join_equals_csr_on_the_fuzzers_graph_shapes(orc):
             assert st["rows"][h] == j[h].shape[0] and st["digest"][h] == orc.digest_rows(j[h])
         c.close()
     assert len(seen) >= 12  # (the draw reached most (id shape, degree model) combinations)
+
+
+def test_cte_shortest_equals_bfs_on_the_fuzzers_graph_shapes(orc):
+    """The recursive-CTE restatement (UNION dedupe + min over hop counts, as the reference executes bi-10's `friends`)
+    against the oracle's 64-lane bitset BFS — the form the GPU BFS is compared with — on the fuzzer's graph shapes."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_gg.py")
+    spec = importlib.util.spec_from_file_location("fuzz_gg_generator", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(fuzz)
+    except Exception as e:  # pragma: no cover
+        pytest.skip(f"fuzz_gg not importable here: {e}")
+    for i in range(25):
+        rng = np.random.default_rng(2000 + i)
+        g = fuzz.draw_graph(rng, max_rows=400, max_vertices=80)
+        vid, src, dst = g["vid"], g["src"], g["dst"]
+        rc, c = orc.csr_build(vid, src, dst)
+        assert rc == 0
+        sources = vid[rng.integers(0, vid.size, int(rng.integers(1, 12)))]
+        sources = np.concatenate([sources, sources[:1]])  # (a duplicate seed: UNION keeps one)
+        max_hops = int(rng.choice([0, 1, 2, 4, 7]))
+        ref = orc.cte_shortest(vid, src, dst, sources, max_hops)
+        uniq = np.array(list(dict.fromkeys(sources.tolist())), np.int64)
+        dist, _ = c.bfs64(c.lookup(uniq), max_hops)
+        got = {(int(s), int(vid[v]), int(dist[k, v])) for k, s in enumerate(uniq) for v in np.nonzero(dist[k] >= 0)[0]}
+        assert got == {tuple(r) for r in ref.tolist()}, (i, g["ids"], g["model"], max_hops)
+        c.close()
